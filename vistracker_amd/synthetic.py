@@ -1,0 +1,350 @@
+"""Deterministic synthetic stand-ins for the licensed / absent inputs of the fit path.
+
+Nothing here is read from the reference tree.  The real SMPL-H model file
+(``SMPLH_{male,female}.pkl``), the SIF-Net checkpoint and the BEHAVE sequences are not
+redistributable, so tests, the golden-vector generator (``tools/gen_golden.py``) and
+``bench.py`` all build their inputs from the seeded generators below.  Shapes, dtypes,
+sparsity and value ranges follow what the reference loads:
+
+* SMPL-H buffers  -- ``lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:46-71``
+  (``v_template (6890,3)``, ``shapedirs (6890,3,10)``, ``posedirs (6890,3,459)``,
+  ``J_regressor (52,6890)``, ``weights (6890,52)``, ``kintree_table (2,52)``).
+* landmark regressors -- ``lib_smpl/body_landmark.py:16-28`` (6890x{25,70,42} sparse, columns sum to 1).
+* priors -- ``lib_smpl/th_smpl_prior.py:20-39`` (63 mean, 63x63 precision) and
+  ``lib_smpl/th_hand_prior.py:46-72`` (2x45 mean, 45x45 precision each).
+* SIF-Net decoders -- ``model/chore.py:113-126`` (Conv1d 611-128-128-128-k, k in {2,9,14,3,1}).
+* feature maps -- ``model/chore_triplane.py:97-164`` channel counts (256,64,3x32,3x64).
+
+All generators take an integer seed and use ``numpy.random.default_rng`` only, so the GPU
+box regenerates bit-identical inputs without any file from this container.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NUM_VERTS = 6890
+NUM_JOINTS = 52
+NUM_BETAS = 10
+NUM_POSE = 156
+NUM_POSEDIRS = 459  # 51 * 9
+NUM_PARTS = 14
+
+# SMPL-H kinematic tree (22 body joints, 15 left-hand, 15 right-hand); root parent = -1.
+SMPLH_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+     20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35,
+     21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50], dtype=np.int64)
+
+# decoder heads in the order CHORETriplaneVisibility.decode returns them
+# (model/chore_tri_vis.py:30-50): df, pca, parts, centers, vis
+HEAD_NAMES = ("df", "pca", "parts", "centers", "vis")
+HEAD_DIMS = (2, 9, 14, 3, 1)
+FEAT_DIM = 611
+HIDDEN = 128
+
+# feature maps in the concatenation order of CHORETriplane.query (chore_triplane.py:139-151):
+#   im_feat 256 | xyz 3 | tmpx 64 | tri_tmpx(right,back,top) 3x32 | tri_feat(right,back,top) 3x64
+MAP_SPECS = (
+    ("im_feat", 256, 128, "persp"),
+    ("tmpx", 64, 256, "persp"),
+    ("tri_tmpx0", 32, 256, "right"),
+    ("tri_tmpx1", 32, 256, "back"),
+    ("tri_tmpx2", 32, 256, "top"),
+    ("tri_feat0", 64, 128, "right"),
+    ("tri_feat1", 64, 128, "back"),
+    ("tri_feat2", 64, 128, "top"),
+)
+
+
+def _rest_joints() -> np.ndarray:
+    """Approximate rest-pose joint positions (metres, y up) of a 1.7 m person."""
+    J = np.zeros((52, 3), dtype=np.float64)
+    body = {
+        0: (0.0, -0.24, 0.03), 1: (0.07, -0.33, 0.02), 2: (-0.07, -0.33, 0.02), 3: (0.0, -0.12, 0.0),
+        4: (0.10, -0.71, 0.01), 5: (-0.10, -0.71, 0.01), 6: (0.0, 0.02, 0.0), 7: (0.09, -1.11, -0.03),
+        8: (-0.09, -1.11, -0.03), 9: (0.0, 0.08, 0.02), 10: (0.12, -1.17, 0.09), 11: (-0.12, -1.17, 0.09),
+        12: (0.0, 0.29, -0.03), 13: (0.08, 0.20, -0.01), 14: (-0.08, 0.20, -0.01), 15: (0.0, 0.38, 0.02),
+        16: (0.18, 0.23, -0.02), 17: (-0.18, 0.23, -0.02), 18: (0.44, 0.22, -0.04), 19: (-0.44, 0.22, -0.04),
+        20: (0.69, 0.22, -0.04), 21: (-0.69, 0.22, -0.04),
+    }
+    for k, v in body.items():
+        J[k] = v
+    # 5 fingers x 3 phalanges per hand, fanning out from the wrist
+    for side, wrist, base in ((1.0, 20, 22), (-1.0, 21, 37)):
+        for f in range(5):
+            ang = (f - 2) * 0.25
+            d = np.array([side * np.cos(ang), -0.2 * np.sin(ang), np.sin(ang)])
+            for p in range(3):
+                J[base + 3 * f + p] = J[wrist] + d * (0.09 + 0.03 * p)
+    return J
+
+
+def smplh_model(seed: int = 0) -> dict:
+    """A synthetic SMPL-H model with the real topology and tensor shapes.
+
+    Vertices are scattered around the bones of the rest skeleton, skinning weights fall off
+    with distance to the nearest joints (4 non-zeros per vertex as in SMPL), the joint
+    regressor averages the vertices nearest to each joint.  Blend shapes are small random
+    fields with the magnitudes the survey prescribes (shape ~1e-2, pose ~1e-3).
+    """
+    rng = np.random.default_rng(seed)
+    J = _rest_joints()
+    par = SMPLH_PARENTS
+    # bone budget: body bones get most vertices, fingers few
+    bones = np.arange(1, 52)
+    share = np.where(bones < 22, 1.0, 0.12)
+    share = share / share.sum()
+    counts = np.floor(share * NUM_VERTS).astype(int)
+    counts[0] += NUM_VERTS - counts.sum()
+    verts = np.zeros((NUM_VERTS, 3))
+    o = 0
+    for b, c in zip(bones, counts):
+        t = rng.uniform(0.0, 1.0, size=(c, 1))
+        rad = 0.07 if b < 22 else 0.008
+        verts[o:o + c] = J[par[b]] * (1 - t) + J[b] * t + rng.normal(0, rad, size=(c, 3))
+        o += c
+    verts = verts[rng.permutation(NUM_VERTS)]
+    d2 = ((verts[:, None, :] - J[None, :, :]) ** 2).sum(-1)  # (V,52)
+    idx = np.argsort(d2, axis=1)[:, :4]
+    w = np.exp(-np.take_along_axis(d2, idx, 1) / (2 * 0.06 ** 2)) + 1e-6
+    w = w / w.sum(1, keepdims=True)
+    W = np.zeros((NUM_VERTS, NUM_JOINTS))
+    np.put_along_axis(W, idx, w, 1)
+    # joint regressor: dense row-normalised, dominated by the 64 closest vertices
+    Jreg = rng.uniform(0.0, 1e-3, size=(NUM_JOINTS, NUM_VERTS))
+    near = np.argsort(d2.T, axis=1)[:, :64]
+    for j in range(NUM_JOINTS):
+        Jreg[j, near[j]] += 1.0
+    Jreg = Jreg / Jreg.sum(1, keepdims=True)
+    shapedirs = rng.normal(0, 0.01, size=(NUM_VERTS, 3, NUM_BETAS))
+    # first two betas scale the body (height / girth) so that "top betas" matter like in SMPL
+    shapedirs[:, :, 0] += verts * 0.03
+    shapedirs[:, 0, 1] += verts[:, 0] * 0.03
+    shapedirs[:, 2, 1] += verts[:, 2] * 0.03
+    posedirs = rng.normal(0, 0.001, size=(NUM_VERTS, 3, NUM_POSEDIRS))
+    # closed-ish triangle list (topology is irrelevant to the fit; only the count matters)
+    faces = np.stack([np.arange(13776) % NUM_VERTS,
+                      (np.arange(13776) * 7 + 1) % NUM_VERTS,
+                      (np.arange(13776) * 13 + 5) % NUM_VERTS], 1).astype(np.int32)
+    kintree = np.stack([np.where(par < 0, 2 ** 32 - 1, par).astype(np.int64), np.arange(52)], 0)
+    return {
+        "v_template": verts.astype(np.float32),
+        "shapedirs": shapedirs.astype(np.float32),
+        "posedirs": posedirs.astype(np.float32),
+        "J_regressor": Jreg.astype(np.float32),
+        "weights": W.astype(np.float32),
+        "parents": par.copy(),
+        "kintree_table": kintree,
+        "f": faces,
+    }
+
+
+def landmark_regressors(model: dict, seed: int = 1) -> dict:
+    """Sparse (K x 6890) regressors in CSR form: body25, face70, hand42.
+
+    nnz per row is chosen to reproduce the densities of the real asset files
+    (8481/25, 12260/70, 16599/42 ~= 339, 175, 395).  Rows sum to one.
+    """
+    rng = np.random.default_rng(seed)
+    v = model["v_template"].astype(np.float64)
+    J = _rest_joints()
+    # body25 (OpenPose order) anchored to SMPL joints; 8 = mid-hip = "SMPL centre"
+    b25 = [15, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 15, 15, 15, 15, 10, 10, 7, 11, 11, 8]
+    anchors = {
+        "body25": (J[b25] + rng.normal(0, 0.01, (25, 3)), 339),
+        "face": (J[15] + rng.normal(0, 0.05, (70, 3)), 175),
+        "hand": (np.concatenate([J[22:37], J[20:21].repeat(6, 0), J[37:52], J[21:22].repeat(6, 0)])
+                 + rng.normal(0, 0.005, (42, 3)), 395),
+    }
+    out = {}
+    for name, (anc, nnz) in anchors.items():
+        K = anc.shape[0]
+        d2 = ((anc[:, None, :] - v[None, :, :]) ** 2).sum(-1)
+        cols = np.sort(np.argsort(d2, axis=1)[:, :nnz], axis=1)
+        vals = rng.uniform(0.2, 1.0, size=(K, nnz)) * np.exp(-np.take_along_axis(d2, cols, 1) / 0.02)
+        vals = vals / vals.sum(1, keepdims=True)
+        out[name] = {
+            "indptr": (np.arange(K + 1) * nnz).astype(np.int32),
+            "indices": cols.reshape(-1).astype(np.int32),
+            "data": vals.reshape(-1).astype(np.float32),
+            "shape": (K, NUM_VERTS),
+        }
+    return out
+
+
+def csr_to_dense(csr: dict) -> np.ndarray:
+    K, V = csr["shape"]
+    d = np.zeros((K, V), dtype=np.float32)
+    for r in range(K):
+        s, e = csr["indptr"][r], csr["indptr"][r + 1]
+        d[r, csr["indices"][s:e]] = csr["data"][s:e]
+    return d
+
+
+def priors(seed: int = 2) -> dict:
+    """Body pose prior (63) and left/right hand priors (45 each): mean + precision factor."""
+    rng = np.random.default_rng(seed)
+
+    def prec(n, scale):
+        a = rng.normal(0, scale, (n, n)) / np.sqrt(n)
+        return (np.tril(a) + np.eye(n) * scale * 2).astype(np.float32)
+
+    return {
+        "body_mean": rng.normal(0, 0.15, 63).astype(np.float32),
+        "body_prec": prec(63, 6.0),
+        "lhand_mean": rng.normal(0, 0.1, 45).astype(np.float32),
+        "lhand_prec": prec(45, 3.0),
+        "rhand_mean": rng.normal(0, 0.1, 45).astype(np.float32),
+        "rhand_prec": prec(45, 3.0),
+    }
+
+
+def part_labels(model: dict) -> np.ndarray:
+    """(6890,) int32 in [0,14): body part of each vertex (dominant skinning joint -> part)."""
+    j2p = np.array([11, 12, 13, 11, 3, 8, 11, 1, 6, 11, 1, 6, 0, 11, 11, 0, 5, 10, 4, 9, 2, 7]
+                   + [2] * 15 + [7] * 15, dtype=np.int32)
+    return j2p[np.argmax(model["weights"], axis=1)].astype(np.int32)
+
+
+def sifnet_decoders(seed: int = 3, gain: float = 1.0) -> dict:
+    """Five point decoders Conv1d(611,128)-(128,128)-(128,128)-(128,k); weights (out,in), bias (out,)."""
+    rng = np.random.default_rng(seed)
+    dec = {}
+    for name, k in zip(HEAD_NAMES, HEAD_DIMS):
+        dims = [(HIDDEN, FEAT_DIM), (HIDDEN, HIDDEN), (HIDDEN, HIDDEN), (k, HIDDEN)]
+        layers = []
+        for (o, i) in dims:
+            w = rng.normal(0, gain * np.sqrt(2.0 / i), size=(o, i)).astype(np.float32)
+            b = rng.normal(0, 0.05, size=(o,)).astype(np.float32)
+            layers.append((w, b))
+        dec[name] = layers
+    return dec
+
+
+def _upsample_bilinear(a: np.ndarray, r: int) -> np.ndarray:
+    """(..., h, w) -> (..., r, r), align_corners=True linear interpolation (numpy, deterministic)."""
+    def interp(x, axis, n_out):
+        n_in = x.shape[axis]
+        pos = np.linspace(0, n_in - 1, n_out)
+        i0 = np.clip(np.floor(pos).astype(int), 0, n_in - 2)
+        w = (pos - i0).astype(np.float32)
+        shp = [1] * x.ndim
+        shp[axis] = n_out
+        w = w.reshape(shp)
+        return np.take(x, i0, axis) * (1 - w) + np.take(x, i0 + 1, axis) * w
+    return interp(interp(a, a.ndim - 2, r), a.ndim - 1, r).astype(np.float32)
+
+
+def feature_maps(batch: int, seed: int = 4, res_scale: float = 1.0, smooth: int = 1) -> dict:
+    """Random feature maps, NCHW float32, true channel counts; ``res_scale`` shrinks H=W.
+
+    The query is resolution agnostic (grid_sample with align_corners=True), so tests use
+    res_scale 1/8 ... 1/4 to keep fixtures small; bench.py uses 1.0 (71.3 MB / frame).
+    ``smooth=k`` draws the noise at 1/k resolution and bilinearly upsamples it, which gives a
+    slowly varying field (well-conditioned trajectories).
+    """
+    rng = np.random.default_rng(seed)
+    maps = {}
+    for name, c, res, _ in MAP_SPECS:
+        r = max(4, int(round(res * res_scale)))
+        if smooth > 1:
+            lo = max(2, r // smooth)
+            maps[name] = _upsample_bilinear(rng.normal(0, 1.0, size=(batch, c, lo, lo)).astype(np.float32), r)
+        else:
+            maps[name] = rng.normal(0, 1.0, size=(batch, c, r, r)).astype(np.float32)
+    return maps
+
+
+def object_template(seed: int = 5, n_lat: int = 25, n_lon: int = 50):
+    """Closed genus-0 'chair-sized' mesh: 1252 verts / 2500 faces (chairwood_f2500 counts).
+
+    A UV-sphere with 25 latitude rings x 50 meridians + 2 poles, anisotropically scaled
+    and bumped, centred at its vertex mean (recon/opt_utils.py:90-103 centres templates).
+    """
+    rng = np.random.default_rng(seed)
+    th = (np.arange(n_lat) + 1) * np.pi / (n_lat + 1)
+    ph = np.arange(n_lon) * 2 * np.pi / n_lon
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    r = 1.0 + 0.15 * np.sin(3 * T) * np.cos(2 * P) + 0.1 * np.cos(5 * P)
+    ring = np.stack([r * np.sin(T) * np.cos(P), r * np.cos(T), r * np.sin(T) * np.sin(P)], -1).reshape(-1, 3)
+    verts = np.concatenate([[[0, 1.05, 0]], ring, [[0, -1.05, 0]]], 0) * np.array([0.28, 0.45, 0.25])
+    verts = verts + rng.normal(0, 0.002, verts.shape)
+    faces = []
+    for j in range(n_lon):  # caps
+        faces.append([0, 1 + (j + 1) % n_lon, 1 + j])
+        base = 1 + (n_lat - 1) * n_lon
+        faces.append([len(verts) - 1, base + j, base + (j + 1) % n_lon])
+    for i in range(n_lat - 1):
+        for j in range(n_lon):
+            a = 1 + i * n_lon + j
+            b = 1 + i * n_lon + (j + 1) % n_lon
+            c = a + n_lon
+            d = b + n_lon
+            faces.append([a, b, c])
+            faces.append([b, d, c])
+    verts = verts - verts.mean(0)
+    return verts.astype(np.float32), np.asarray(faces, dtype=np.int32)
+
+
+def sample_surface(verts: np.ndarray, faces: np.ndarray, n: int, seed: int = 6) -> np.ndarray:
+    """Area-weighted surface samples (stand-in for trimesh.sample, recon_fit_base.py:141-145)."""
+    rng = np.random.default_rng(seed)
+    tri = verts[faces].astype(np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    f = rng.choice(len(faces), size=n, p=area / area.sum())
+    u = rng.uniform(size=(n, 2))
+    flip = u.sum(1) > 1
+    u[flip] = 1 - u[flip]
+    t = tri[f]
+    pts = t[:, 0] + u[:, :1] * (t[:, 1] - t[:, 0]) + u[:, 1:] * (t[:, 2] - t[:, 0])
+    return pts.astype(np.float32)
+
+
+def random_rotations(n: int, rng: np.random.Generator) -> np.ndarray:
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)
+    return R.reshape(n, 3, 3).astype(np.float32)
+
+
+def sequence_params(n_frames: int, seed: int = 7, grab_hand_mean: np.ndarray | None = None) -> dict:
+    """Smooth random SMPL-H / object trajectory (OU process) for an n-frame synthetic sequence.
+
+    Returns the *initial* estimates handed to the fit (pose, betas, trans, obj_R, obj_t),
+    body keypoints in crop space, crop/body centres and occlusion ratios, following
+    SURVEY.md 8(d) config 2/3.
+    """
+    rng = np.random.default_rng(seed)
+
+    def ou(dim, sigma, theta=0.05):
+        x = np.zeros((n_frames, dim))
+        x[0] = rng.normal(0, sigma, dim)
+        for t in range(1, n_frames):
+            x[t] = x[t - 1] * (1 - theta) + rng.normal(0, sigma * np.sqrt(2 * theta), dim)
+        return x
+
+    pose = np.zeros((n_frames, NUM_POSE))
+    pose[:, :3] = ou(3, 0.15) + np.array([np.pi, 0, 0])  # camera looks down +z, person upright in image (y down)
+    pose[:, 3:66] = ou(63, 0.2)
+    if grab_hand_mean is not None:
+        pose[:, 66:] = grab_hand_mean[None]
+    betas = np.zeros((n_frames, NUM_BETAS))
+    betas[:, 0] = 2.2
+    trans = np.array([0.0, 0.1, 2.2]) + ou(3, 0.1, 0.02)
+    obj_t = trans + ou(3, 0.25, 0.02)
+    aa = ou(3, 0.6, 0.02)
+    ang = np.linalg.norm(aa, axis=1, keepdims=True) + 1e-12
+    ax = aa / ang
+    K = np.zeros((n_frames, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0] = -ax[:, 2], ax[:, 1], ax[:, 2]
+    K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 0], -ax[:, 1], ax[:, 0]
+    s, c = np.sin(ang)[:, :, None], np.cos(ang)[:, :, None]
+    obj_R = np.eye(3)[None] + s * K + (1 - c) * (K @ K)
+    return {
+        "pose": pose.astype(np.float32), "betas": betas.astype(np.float32), "trans": trans.astype(np.float32),
+        "obj_R": obj_R.astype(np.float32), "obj_t": obj_t.astype(np.float32),
+        "occ_ratios": rng.uniform(0.3, 1.0, n_frames).astype(np.float32),
+    }
