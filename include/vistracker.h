@@ -1,0 +1,233 @@
+/*
+ * vistracker.h -- C ABI of libvistracker_hip.so: the MI355X (gfx950) implementation of the VisTracker
+ * per-frame SMPL-H / object fitting hot path.
+ *
+ * The reference has no FFI: its "operator API" for this path is the set of duck-typed Python callables the
+ * fitters invoke.  Each entry point below names the reference callable it replaces
+ * (paths relative to the reference tree).  The Python shims in vistracker_amd/ bind these with ctypes and
+ * re-expose the reference's call signatures (smpl(), get_landmarks(), model.query()/get_preds(),
+ * SilLossROI(...), chamfer_distance(...)).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous row-major array (float = fp32, int = int32)
+ *     unless the parameter is documented "host".
+ *   - the library never allocates outputs or scratch: the caller passes them (sizes documented per call);
+ *     handles own only immutable constants uploaded at creation.
+ *   - every call enqueues on the caller's HIP stream (`stream` = hipStream_t cast to void*) and returns
+ *     without synchronising; no global mutable state besides the per-thread error string.
+ *   - return value: 0 = ok, negative = error (see vt_last_error()).
+ */
+#ifndef VISTRACKER_H
+#define VISTRACKER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_OK 0
+#define VT_ERR_ARG -1
+#define VT_ERR_HIP -2
+
+#define VT_SMPL_V 6890
+#define VT_SMPL_J 52
+#define VT_SMPL_NB 10
+#define VT_SMPL_NP 459
+#define VT_FEAT 611
+#define VT_HID 128
+
+const char *vt_last_error(void);
+int vt_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * SMPL-H layer.  Replaces SMPL_Layer.forward (lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:73-176),
+ * th_posemap_axisang / batch_rodrigues (tensutils.py:6-19, rodrigues_layer.py:38-52) and its autograd backward.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct vt_smplh vt_smplh;
+
+/* HOST pointers: v_template (V,3), shapedirs (V,3,NB), posedirs (V,3,NP), J_regressor (J,V) dense,
+ * weights (V,J), parents (J) [parents[0] ignored].  smpl_layer.py:46-71. */
+int vt_smplh_create(vt_smplh **out, const float *v_template, const float *shapedirs, const float *posedirs,
+                    const float *J_regressor, const float *weights, const int *parents, void *stream);
+void vt_smplh_destroy(vt_smplh *h);
+
+/* floats of per-call workspace `ws` for batch B (kept by the caller between forward and backward) */
+long vt_smplh_workspace_floats(int B);
+
+/* pose (B,156) betas (B,10) trans (B,3) -> verts (B,6890,3), jtr (B,52,3), v_posed (B,6890,3)  */
+int vt_smplh_forward(const vt_smplh *h, const float *pose, const float *betas, const float *trans, int B,
+                     float *verts, float *jtr, float *v_posed, float *ws, void *stream);
+
+/* dverts (B,6890,3), djtr (B,52,3) or NULL -> dpose (B,156), dbetas (B,10), dtrans (B,3)  (overwritten).
+ * `ws` and `v_posed` must be the buffers the matching forward filled.  scratch: vt_smplh_bwd_scratch_floats(B). */
+long vt_smplh_bwd_scratch_floats(int B);
+int vt_smplh_backward(const vt_smplh *h, const float *pose, const float *betas, int B, const float *dverts,
+                      const float *djtr, const float *v_posed, const float *ws, float *scratch,
+                      float *dpose, float *dbetas, float *dtrans, void *stream);
+
+/* batch_rodrigues alone: aa (n,3) -> R (n,9); and its VJP */
+int vt_rodrigues_forward(const float *aa, int n, float *R, void *stream);
+int vt_rodrigues_backward(const float *aa, int n, const float *dR, float *daa, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sparse landmark regressors.  Replaces load_regressors + batch_sparse_dense_matmul
+ * (lib_smpl/body_landmark.py:16-28, lib_smpl/torch_functions.py:52-76).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct vt_landmarks vt_landmarks;
+/* HOST CSR of the (K x V) regressor */
+int vt_landmarks_create(vt_landmarks **out, const int *indptr, const int *indices, const float *data, int K, int V,
+                        void *stream);
+void vt_landmarks_destroy(vt_landmarks *h);
+/* verts (B,V,3) -> out (B,K,3) */
+int vt_landmarks_forward(const vt_landmarks *h, const float *verts, int B, float *out, void *stream);
+/* dout (B,K,3) -> dverts (B,V,3) += (accumulate != 0) or = (accumulate == 0; rows without entries zeroed) */
+int vt_landmarks_backward(const vt_landmarks *h, const float *dout, int B, float *dverts, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Mahalanobis priors.  Replaces th_Mahalanobis.__call__ (lib_smpl/th_smpl_prior.py:30-38) and
+ * HandPrior.__call__ (lib_smpl/th_hand_prior.py:57-72):  value[b] = | (x[b, off:off+n] - mean) @ prec |^2.
+ * dx (B,stride) += gscale * d value[b] / dx  when dx != NULL.   mean (n), prec (n,n) device, n <= 64.
+ * ------------------------------------------------------------------------------------------------- */
+int vt_mahalanobis(const float *x, int B, int stride, int off, int n, const float *mean, const float *prec,
+                   float *value, float *dx, float gscale, void *stream);
+
+/* Loss-term accumulators: every `double *term` below is a DEVICE fp64 scalar the kernels add to with atomics
+ * (fp64 keeps the sum order-independent to ~1e-16, so step losses and the early-stop decision are reproducible).
+ * Zero them (vt_fill_f64) before the step. */
+int vt_fill_f64(double *p, long n, double value, void *stream);
+/* *term += scale * sum(value[0..n)) */
+int vt_sum_to_term(const float *value, int n, float scale, double *term, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * SIF-Net point query.  Replaces CHORETriplane.query + CHORETriplaneVisibility.decode + get_preds
+ * (model/chore_triplane.py:97-164,207-251; model/chore_tri_vis.py:17-50; model/camera.py:45-90;
+ * model/geometry.py:4-14) and the autograd backward to the query coordinates.
+ * Heads (bit index in head masks): 0 df(2) 1 pca(9) 2 parts(14) 3 centers(3) 4 vis(1).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct vt_sifnet vt_sifnet;
+/* HOST weights: w[h*4+l] is (out,in) row-major (torch Conv1d.weight[:, :, 0]), b[h*4+l] is (out);
+ * cam (host, 5 floats) = {fx_px, fy_px, cx_px, cy_px, crop_size} (camera.py:26-41). */
+int vt_sifnet_create(vt_sifnet **out, const float *const *w, const float *const *b, const float *cam, void *stream);
+void vt_sifnet_destroy(vt_sifnet *h);
+
+/* Feature maps are consumed channel-last.  Converts one NCHW map (B,C,H,W) to NHWC (B,H,W,C). */
+int vt_nchw_to_nhwc(const float *src, int B, int C, int H, int W, float *dst, void *stream);
+
+/* maps (host array of 8 device pointers, NHWC) in the order im_feat(256) tmpx(64) tri_tmpx{right,back,top}(32)
+ * tri_feat{right,back,top}(64); res (host, 8 ints) = H (=W) of each map. */
+typedef struct {
+    const float *maps[8];
+    int res[8];
+} vt_maps;
+
+/* pts (B,N,3), crop_center (B,2), body_center (B,3).  Outputs may be NULL (head skipped); layout as the
+ * reference: df (B,2,N), pca (B,9,N), parts (B,14,N), centers (B,3,N), vis (B,1,N). */
+int vt_query_forward(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
+                     const float *body_center, int B, int N,
+                     float *df, float *pca, float *parts, float *centers, float *vis, void *stream);
+/* upstream gradients in the same layouts (NULL = zero) -> dpts (B,N,3) (overwritten) */
+int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
+                      const float *body_center, int B, int N,
+                      const float *d_df, const float *d_pca, const float *d_parts, const float *d_centers,
+                      const float *d_vis, float *dpts, void *stream);
+
+/* Fused objective kernels of the two fit loops (no autograd tape, one launch per step):
+ *  human:  loss += w_dfh * mean_{B,N} clamp(df[:,0], max=.1) + w_part * mean_B sum_N CE(parts, labels)
+ *          (recon_fit_base.py:640-647, recon_fit_behave.py:486); labels (N) int32
+ *  object: loss += w_obj * mean_B( mean_N clamp(df[:,1], max=.8) * occ[b] )   (recon_fit_trivis_full.py:155-162)
+ * dpts (B,N,3) is overwritten with the weighted gradient; terms[0..1] (device fp64) receive the UNWEIGHTED term
+ * values (df_h, part) or (object, -) accumulated with atomics -- zero them before the call. */
+int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
+                        const float *body_center, int B, int N, const int *labels, float w_dfh, float w_part,
+                        float *dpts, double *terms, void *stream);
+int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
+                         const float *body_center, int B, int N, const float *occ, float w_obj,
+                         float *dpts, double *terms, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * SO(3) projection.  Replaces ReconFitterBase.project_so3 / decopose_axis (recon/recon_fit_base.py:179-199,
+ * 462-469): R = U diag(1,1,det(U V^T)) V^T of M; noise (B,3,3) or NULL is the U[0,1) sample, M = M0 + 1e-4*noise.
+ * ------------------------------------------------------------------------------------------------- */
+int vt_so3_project_forward(const float *M0, const float *noise, int B, float *R, void *stream);
+int vt_so3_project_backward(const float *M0, const float *noise, int B, const float *dR, float *dM, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Rigid transform.  Replaces transform_obj_verts (recon/recon_fit_base.py:455-459): X = (X0 @ R + t) * s.
+ * X0 (N,3) shared by all frames if shared_x0 != 0 else (B,N,3).
+ * ------------------------------------------------------------------------------------------------- */
+int vt_rigid_forward(const float *X0, int shared_x0, const float *R, const float *t, const float *s, int B, int N,
+                     float *X, void *stream);
+/* dX (B,N,3) -> dR (B,3,3), dt (B,3)  (+= if accumulate) */
+int vt_rigid_backward(const float *X0, int shared_x0, const float *s, int B, int N, const float *dX,
+                      float *dR, float *dt, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Temporal stencils (recon/recon_fit_trivis_full.py:170-177,379-391; preprocess/fit_SMPLH_30fps.py:189-200).
+ *   accel:    mse(v[1:-1]-v[:-2], v[2:]-v[1:-1]) (optionally weighted per element by elem_w (D))
+ *   velocity: mse(v[1:], v[:-1])
+ * v (B,D).  *term (device scalar) += value;  dv (B,D) += gscale * gradient (dv may be NULL).
+ * ------------------------------------------------------------------------------------------------- */
+int vt_accel_loss(const float *v, int B, int D, const float *elem_w, float gscale, double *term, float *dv, void *stream);
+int vt_velocity_loss(const float *v, int B, int D, float gscale, double *term, float *dv, void *stream);
+
+/* 2D keypoint terms.  mode 0: BaseFitter.compute_loss 'kpts' (preprocess/fit_SMPLH_kpts.py:280-310):
+ *   mean_{B,25,2}((proj - k_xy)^2 * conf), full-image pinhole.
+ * mode 1: projection_loss 'j2d' (recon/recon_fit_base.py:781-802): mean_{B,25}(sum_xy(proj - k)^2 * conf) with the
+ *   crop-space projection scaled by net_size / crop_size; crop_center (B,2).
+ * J (B,K,3), kpts (B,K,3);  *term += value;  dJ (B,K,3) = gscale * gradient (overwritten). cam (host,5). */
+int vt_kpts_loss(const float *J, const float *kpts, const float *crop_center, int B, int K, int mode,
+                 const float *cam, float net_size, float gscale, double *term, float *dJ, void *stream);
+
+/* sum_i w_i (a_i - b_i)^2 / denom  over n elements laid out with row strides (rows x cols):
+ * pinit terms (fit_SMPLH_30fps.py:178; recon_fit_behave.py:493-495) and 'trans' (recon_fit_trivis_full.py:223). */
+int vt_sqdiff_loss(const float *a, int a_stride, const float *b, int b_stride, int rows, int cols, float denom,
+                   float gscale, double *term, float *da, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Ragged contact Chamfer.  Replaces pytorch3d.loss.chamfer_distance(Pointclouds, Pointclouds)[0]
+ * (recon/recon_fit_trivis_full.py:454-457; pytorch3d defaults, see DESIGN.md "unpinned").
+ * x (nx_total,3), y (ny_total,3), offx/offy (P+1) int32 device.  *term += value.
+ * dx, dy (+=, may be NULL) receive gscale * gradient.
+ * ------------------------------------------------------------------------------------------------- */
+int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int *offy, int P, float gscale,
+                      double *term, float *dx, float *dy, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Silhouette.  Replaces neural_renderer.Renderer(K, R=I, t=0, orig_size=1, anti_aliasing=False)(verts, faces,
+ * mode='silhouettes') and its backward as used by SilLossROI.forward (recon/obj_pose_roi.py:77-94,183-207).
+ * verts (B,NV,3) camera space, faces (NF,3) int32 shared, K (B,9), image (B,size,size) row 0 = top.
+ * face_index (B,size,size) int32 and proj (B,NV,3) float are outputs the backward reads again
+ * (face id in [0,2*NF) of the doubled fill_back list, -1 = background; projected vertices u,v in [-1,1], z).
+ * ------------------------------------------------------------------------------------------------- */
+int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
+                   float *image, int *face_index, float *proj, void *stream);
+/* d_image (B,size,size) -> dverts (B,NV,3) (overwritten).  gproj (B,NV,2) float scratch. eps = NMR's 1e-4. */
+int vt_sil_backward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
+                    const int *face_index, const float *proj, const float *d_image, float eps, float *gproj,
+                    float *dverts, void *stream);
+/* fused occlusion-aware mask term (obj_pose_roi.py:191-198; recon_fit_trivis_full.py:164-168):
+ * per[b] = sum_px (keep*sil - ref)^2 ; *term += mean_b(per[b]*occ[b]); d_image = gscale * d/d sil */
+int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size,
+                     float gscale, double *term, float *per_frame, float *d_image, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Adam.  Replaces torch.optim.Adam(...).step() (defaults betas=(.9,.999), eps=1e-8) on one parameter tensor.
+ * `stop_flag` (device int, may be NULL): when *stop_flag != 0 the update is skipped (device-side early stop).
+ * ------------------------------------------------------------------------------------------------- */
+int vt_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr, float beta1, float beta2,
+                 float eps, const int *stop_flag, void *stream);
+
+/* Early-stop rule of the fit loops evaluated on the device (recon_fit_behave.py:447-455,
+ * recon_fit_trivis_full.py:372-373, fit_SMPLH_kpts.py:161):
+ *   loss = sum_k w[k]*terms[k];  if (armed && |prev-loss|/prev < prev*tol) *stop_flag = 1;  prev = loss;
+ * terms (nterms) device, w (host, nterms), state (device, 2 floats: prev_loss, last_loss), history (device) or NULL
+ * receives loss at index `slot`. */
+int vt_loss_reduce_and_stop(const double *terms, const float *w, int nterms, float tol, int armed, float *state,
+                            int *stop_flag, float *history, int slot, void *stream);
+
+/* small utilities */
+int vt_fill(float *p, long n, float value, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISTRACKER_H */

@@ -1,0 +1,298 @@
+"""GPU (-m gpu): the HIP path (through the C ABI) against the CPU oracle and the golden vectors of the reference.
+fp32 tolerances are stated per assertion; bar of the north star = 1e-3 m on vertices."""
+import numpy as np
+import pytest
+
+from conftest import golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def cu(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def hip(synth):
+    from vistracker_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return {
+        "ops": ops,
+        "smpl": ops.SmplhHandle(synth["model"]),
+        "b25": ops.LandmarkHandle(synth["regs"]["body25"]),
+        "face": ops.LandmarkHandle(synth["regs"]["face"]),
+        "hand": ops.LandmarkHandle(synth["regs"]["hand"]),
+        "net": ops.SifNetHandle(synth["decoders"]),
+    }
+
+
+def test_mfma_operand_layout():
+    """A (16x4) . B (4x16) with asymmetric data: pins the v_mfma_f32_16x16x4_f32 lane maps the query kernel assumes."""
+    from vistracker_amd import _lib as L
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(16, 4)).astype(np.float32); Bm = rng.normal(size=(4, 16)).astype(np.float32)
+    out = torch.zeros(16, 16, device="cuda")
+    L.check(L.lib().vt_selftest_mfma(L.dptr(cu(A)), L.dptr(cu(Bm)), L.dptr(out), L.stream_ptr()))
+    assert np.abs(npy(out) - A @ Bm).max() < 1e-5
+
+
+def test_rodrigues(hip):
+    g = golden("rodrigues"); ops = hip["ops"]
+    assert np.abs(npy(ops.rodrigues(cu(g["aa"]))) - g["R"]).max() < 2e-6
+    d = npy(ops.rodrigues_bwd(cu(g["aa"]), cu(g["gR"])))
+    assert rel(d[2:], g["daa"][2:]) < 1e-4
+
+
+def test_smplh_vs_golden(hip):
+    g = golden("smplh"); vs = int(g["vsub"]); ops = hip["ops"]
+    pose, betas, trans = (cu(g[k]).requires_grad_(True) for k in ("pose", "betas", "trans"))
+    verts, jtr, vposed = ops.smplh_forward(hip["smpl"], pose, betas, trans)
+    assert np.abs(npy(verts)[:, ::vs] - g["verts_sub"]).max() < 2e-5
+    assert np.abs(npy(jtr) - g["jtr"]).max() < 2e-5
+    assert np.abs(npy(vposed)[:, ::vs] - g["vposed_sub"]).max() < 2e-5
+    gv = cu(np.load(GOLDEN + "/smplh_gv.npy").astype(np.float32))
+    ((verts * gv).sum() + (jtr * cu(g["gj"])).sum()).backward()
+    assert rel(npy(pose.grad), g["dpose"]) < 3e-4
+    assert rel(npy(betas.grad), g["dbetas"]) < 3e-4
+    assert rel(npy(trans.grad), g["dtrans"]) < 3e-4
+
+
+@pytest.mark.parametrize("B", [1, 13, 96])
+def test_smplh_vs_oracle_ragged_batches(hip, synth, B):
+    from oracle import oracle as O
+    rng = np.random.default_rng(B)
+    pose = rng.normal(0, 0.3, (B, 156)).astype(np.float32); betas = rng.normal(0, 1, (B, 10)).astype(np.float32)
+    trans = rng.normal(0, 0.3, (B, 3)).astype(np.float32)
+    gv = rng.normal(0, 1, (B, 6890, 3)).astype(np.float32)
+    m = O.SmplModel(synth["model"])
+    v_o, j_o, _ = m.forward(pose, betas, trans)
+    dp_o, db_o, dt_o = m.backward(pose, betas, trans, gv)
+    p, b_, t = (cu(x).requires_grad_(True) for x in (pose, betas, trans))
+    verts, jtr, _ = hip["ops"].smplh_forward(hip["smpl"], p, b_, t)
+    assert np.abs(npy(verts) - v_o).max() < 3e-5 and np.abs(npy(jtr) - j_o).max() < 3e-5
+    (verts * cu(gv)).sum().backward()
+    assert rel(npy(p.grad), dp_o) < 3e-4 and rel(npy(b_.grad), db_o) < 3e-4 and rel(npy(t.grad), dt_o) < 3e-4
+
+
+def test_landmarks(hip, synth):
+    from oracle import oracle as O
+    g = golden("landmarks"); s = golden("smplh"); ops = hip["ops"]
+    verts, _, _ = O.SmplModel(synth["model"]).forward(s["pose"], s["betas"], s["trans"])
+    v = cu(verts).requires_grad_(True)
+    for key, name in (("b25", "J"), ("face", "face"), ("hand", "hands")):
+        assert np.abs(npy(ops.landmarks(hip[key], v)) - g[name]).max() < 2e-5
+    (ops.landmarks(hip["b25"], v) * cu(g["gJ"])).sum().backward()
+    assert np.abs(npy(v.grad)[:, ::7] - g["dverts_sub"]).max() < 1e-6
+
+
+def test_priors(hip, synth):
+    g = golden("priors"); p = synth["priors"]; ops = hip["ops"]
+    x = cu(g["pose"]).requires_grad_(True)
+    body = ops.mahalanobis(x, 3, cu(p["body_mean"]), cu(p["body_prec"]))
+    hl = ops.mahalanobis(x, 66, cu(p["lhand_mean"]), cu(p["lhand_prec"]))
+    hr = ops.mahalanobis(x, 111, cu(p["rhand_mean"]), cu(p["rhand_prec"]))
+    assert rel(npy(body), g["body"]) < 1e-5
+    assert abs(npy(hl + hr).sum() - g["hand"].sum()) < 1e-5 * g["hand"].sum()
+    (body.sum() * 0.5 + (hl + hr).sum() * 0.25).backward()
+    assert rel(npy(x.grad), g["dpose"]) < 1e-5
+
+
+def _maps(hip, B, seed, res_scale, smooth=1):
+    from vistracker_amd import synthetic as syn
+    return hip["ops"].FeatureMaps.from_nchw(syn.feature_maps(B, seed, res_scale=res_scale, smooth=smooth))
+
+
+def test_nchw_to_nhwc(hip):
+    from vistracker_amd import synthetic as syn
+    m = syn.feature_maps(2, 9, res_scale=1 / 8)
+    fm = hip["ops"].FeatureMaps.from_nchw(m)
+    for k, t in zip(hip["ops"].MAP_ORDER, fm.t):
+        assert np.array_equal(npy(t), m[k].transpose(0, 2, 3, 1))
+
+
+def test_query_vs_golden(hip):
+    g = golden("query"); ops = hip["ops"]
+    maps = _maps(hip, 4, 4, float(g["res_scale"]))
+    pts = cu(g["pts"]).requires_grad_(True)
+    outs = ops.sifnet_query(hip["net"], maps, pts, cu(g["crop_center"]), cu(g["body_center"]))
+    for name, o in zip(ops.HEADS, outs):
+        assert np.abs(npy(o) - g[name]).max() < 5e-5 * max(1.0, np.abs(g[name]).max()), name
+    assert (npy(outs[0])[0, :, :4] == 5.0).all()
+    for i, name in enumerate(ops.HEADS):
+        pts.grad = None
+        (outs[i] * cu(g["g_" + name])).sum().backward(retain_graph=True)
+        assert rel(npy(pts.grad), g["dpts_" + name]) < 3e-4, name
+    # two heads at once (the G = 2 instantiation)
+    pts.grad = None
+    ((outs[0] * cu(g["g_df"])).sum() + (outs[2] * cu(g["g_parts"])).sum()).backward()
+    assert rel(npy(pts.grad), g["dpts_df"] + g["dpts_parts"]) < 3e-4
+
+
+def test_query_fused_objectives_vs_oracle(hip, synth):
+    """vt_query_human_loss / vt_query_object_loss == oracle forward + loss + backward (N not a multiple of 64)."""
+    import ctypes as C
+    from oracle import oracle as O
+    from vistracker_amd import synthetic as syn, _lib as L
+    B, N = 3, 150
+    rng = np.random.default_rng(5)
+    mp = syn.feature_maps(B, 21, res_scale=1 / 8)
+    net_o = O.SifNet(synth["decoders"], mp)
+    pts = (rng.normal(0, 0.3, (B, N, 3)) + [0, 0, 2.2]).astype(np.float32)
+    pts[0, :3, 0] += 3.0
+    cc = (np.array([[1018.952, 779.486]]) + rng.normal(0, 30, (B, 2))).astype(np.float32)
+    bc = (np.array([[0, 0, 2.2]]) + rng.normal(0, 0.1, (B, 3))).astype(np.float32)
+    labels = rng.integers(0, 14, N).astype(np.int32); occ = rng.uniform(0.3, 1, B).astype(np.float32)
+    df, _, parts, _, _ = net_o.query(pts, cc, bc)
+    w_dfh, w_part, w_obj = 100.0, 0.0025, 900.0
+    dfh = df[:, 0].astype(np.float64)
+    t_dfh = np.minimum(dfh, 0.1).mean()
+    d_df = np.zeros_like(df); d_df[:, 0] = (dfh <= 0.1) * (w_dfh / dfh.size)
+    lg = parts.astype(np.float64); lg -= lg.max(1, keepdims=True); logp = lg - np.log(np.exp(lg).sum(1, keepdims=True))
+    lab = np.broadcast_to(labels[None], (B, N))
+    t_part = (-np.take_along_axis(logp, lab[:, None], 1)[:, 0]).sum(-1).mean()
+    sm = np.exp(logp); np.put_along_axis(sm, lab[:, None], np.take_along_axis(sm, lab[:, None], 1) - 1, 1)
+    dpts_h = net_o.query_bwd(pts, cc, bc, d_df=d_df.astype(np.float32), d_parts=(sm * w_part / B).astype(np.float32))
+    dfo = df[:, 1].astype(np.float64)
+    t_obj = (np.minimum(dfo, 0.8).mean(-1) * occ).mean()
+    d_df2 = np.zeros_like(df); d_df2[:, 1] = (dfo <= 0.8) * (occ[:, None] * w_obj / (N * B))
+    dpts_o = net_o.query_bwd(pts, cc, bc, d_df=d_df2.astype(np.float32))
+
+    maps = hip["ops"].FeatureMaps.from_nchw(mp)
+    terms = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, N, 3, device="cuda")
+    L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(cu(pts)), L.dptr(cu(cc)), L.dptr(cu(bc)), B, N,
+                                        L.dptr(cu(labels)), w_dfh, w_part, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+    t = npy(terms)
+    assert abs(t[0] - t_dfh) < 1e-5 * abs(t_dfh) + 1e-7 and abs(t[1] - t_part) < 1e-4 * abs(t_part)
+    assert rel(npy(dp), dpts_h) < 3e-4
+    terms.zero_()
+    L.check(L.lib().vt_query_object_loss(hip["net"].h, C.byref(maps.c), L.dptr(cu(pts)), L.dptr(cu(cc)), L.dptr(cu(bc)), B, N,
+                                         L.dptr(cu(occ)), w_obj, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+    assert abs(npy(terms)[0] - t_obj) < 1e-5 * abs(t_obj) + 1e-7
+    assert rel(npy(dp), dpts_o) < 3e-4
+
+
+def test_so3(hip):
+    g = golden("so3"); ops = hip["ops"]
+    M = cu(g["M"]).requires_grad_(True)
+    R = ops.so3_project(M)
+    assert np.abs(npy(R) - g["R"]).max() < 3e-6
+    (R * cu(g["gR"])).sum().backward()
+    assert rel(npy(M.grad), g["dM64"]) < 2e-4        # stable fp64 reference of the same autograd expression
+    assert rel(npy(M.grad)[:6], g["dM"][:6]) < 1e-3
+
+
+def test_rigid_and_stencils(hip):
+    from oracle import oracle as O
+    ops = hip["ops"]; rng = np.random.default_rng(3)
+    B, N = 6, 333
+    X0 = rng.normal(0, 0.3, (N, 3)).astype(np.float32); R = rng.normal(0, 1, (B, 3, 3)).astype(np.float32)
+    t = rng.normal(0, 1, (B, 3)).astype(np.float32); s = rng.uniform(0.8, 1.2, B).astype(np.float32)
+    gX = rng.normal(0, 1, (B, N, 3)).astype(np.float32)
+    Rt, tt = cu(R).requires_grad_(True), cu(t).requires_grad_(True)
+    X = ops.rigid_transform(cu(X0), Rt, tt, cu(s))
+    assert np.abs(npy(X) - O.rigid(X0, R, t, s)).max() < 1e-5
+    (X * cu(gX)).sum().backward()
+    dR_o, dt_o = O.rigid_bwd(X0, R, t, s, gX)
+    assert rel(npy(Rt.grad), dR_o) < 1e-4 and rel(npy(tt.grad), dt_o) < 1e-4
+    for Bv in (3, 4, 17):
+        v = rng.normal(0, 1, (Bv, 50, 3)).astype(np.float32); w = rng.uniform(1, 10, 150).astype(np.float32)
+        for ew in (None, w):
+            vt = cu(v).requires_grad_(True)
+            val = ops.accel_loss(vt, None if ew is None else cu(ew)); val.backward()
+            dv = np.zeros_like(v); ref = O.accel_loss(v, ew, 1.0, dv)
+            assert abs(val.item() - ref) < 1e-5 * abs(ref) and rel(npy(vt.grad), dv) < 1e-4
+        vt = cu(v).requires_grad_(True)
+        val = ops.velocity_loss(vt); val.backward()
+        dv = np.zeros_like(v); ref = O.velocity_loss(v, 1.0, dv)
+        assert abs(val.item() - ref) < 1e-5 * abs(ref) and rel(npy(vt.grad), dv) < 1e-4
+
+
+def test_chamfer_ragged(hip):
+    from oracle import oracle as O
+    ops = hip["ops"]; rng = np.random.default_rng(4)
+    sizes = [(1, 1), (5, 1700), (1300, 40), (64, 64)]
+    xs = [rng.normal(0, 1, (a, 3)).astype(np.float32) for a, _ in sizes]
+    ys = [rng.normal(0, 1, (b, 3)).astype(np.float32) for _, b in sizes]
+    val, dx, dy, offx, offy = O.chamfer_ragged(xs, ys, 1.0, True)
+    x = cu(np.concatenate(xs)).requires_grad_(True); y = cu(np.concatenate(ys)).requires_grad_(True)
+    out = ops.chamfer_ragged(x, y, cu(offx), cu(offy)); out.backward()
+    assert abs(out.item() - val) < 1e-5 * abs(val)
+    assert rel(npy(x.grad), dx) < 1e-4 and rel(npy(y.grad), dy) < 1e-4
+
+
+def _sil_case(B=3, seed=8):
+    from vistracker_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    verts0, faces = syn.object_template()
+    R = syn.random_rotations(B, rng); t = (rng.normal(0, 0.1, (B, 3)) + [0, 0, 2.3]).astype(np.float32)
+    verts = np.einsum("nc,bcd->bnd", verts0, R) + t[:, None]
+    K = np.tile(np.array([[1.6, 0, 0.5], [0, 1.6, 0.5], [0, 0, 1]], np.float32).reshape(1, 9), (B, 1))
+    K[:, 2] += rng.normal(0, 0.05, B); K[:, 5] += rng.normal(0, 0.05, B)
+    return verts.astype(np.float32), faces, K.astype(np.float32)
+
+
+def test_silhouette(hip):
+    from oracle import oracle as O
+    ops = hip["ops"]
+    verts, faces, K = _sil_case()
+    img_o = O.sil_forward(verts, faces, K, 256)
+    v = cu(verts).requires_grad_(True)
+    img = ops.silhouette(v, cu(faces), cu(K), 256)
+    diff = np.abs(npy(img) - img_o)
+    assert 0.05 < img_o.mean() < 0.95
+    assert diff.sum() <= 4, diff.sum()       # identical coverage up to fp32 edge ties
+    rng = np.random.default_rng(1)
+    ref = np.roll(img_o, 5, axis=2)
+    gimg = (2 * (img_o - ref)).astype(np.float32)
+    (img * cu(gimg)).sum().backward()
+    dv_o = O.sil_backward(verts, faces, K, gimg, 256, 1e-4)
+    assert rel(npy(v.grad), dv_o) < 2e-3
+
+
+def test_adam(hip):
+    g = golden("adam"); ops = hip["ops"]
+    p = cu(g["p0"].copy()); opt = ops.FusedAdam([p], lr=float(g["lr"]))
+    for k, gr in enumerate(g["grads"]):
+        opt.step([cu(gr)])
+        assert np.abs(npy(p) - g["traj"][k]).max() < 1e-6
+
+
+def test_kpts_and_sqdiff(hip):
+    from vistracker_amd import _lib as L
+    rng = np.random.default_rng(6)
+    B, K = 5, 25
+    J = (rng.normal(0, 0.3, (B, K, 3)) + [0, 0, 2.2]).astype(np.float32)
+    k2 = np.concatenate([rng.uniform(0, 2000, (B, K, 2)), rng.uniform(0, 1, (B, K, 1))], -1).astype(np.float32)
+    cc = rng.uniform(900, 1100, (B, 2)).astype(np.float32)
+    cam = np.array([979.7844, 979.840, 1018.952, 779.486, 1200.0], np.float32)
+    for mode in (0, 1):
+        Jt = torch.tensor(J, dtype=torch.float64, requires_grad=True)
+        px = cam[0] * Jt[..., 0] / Jt[..., 2] + cam[2]; py = cam[1] * Jt[..., 1] / Jt[..., 2] + cam[3]
+        if mode == 1:
+            px = (600 + px - torch.tensor(cc[:, :1], dtype=torch.float64)) * (512 / 1200); py = (600 + py - torch.tensor(cc[:, 1:], dtype=torch.float64)) * (512 / 1200)
+        e = ((px - torch.tensor(k2[..., 0], dtype=torch.float64)) ** 2 + (py - torch.tensor(k2[..., 1], dtype=torch.float64)) ** 2) * torch.tensor(k2[..., 2], dtype=torch.float64)
+        ref = e.sum() / (B * K * 2) if mode == 0 else e.mean()
+        (ref * 0.7).backward()
+        term = torch.zeros(1, dtype=torch.float64, device="cuda"); dJ = torch.empty(B, K, 3, device="cuda")
+        L.check(L.lib().vt_kpts_loss(L.dptr(cu(J)), L.dptr(cu(k2)), L.dptr(cu(cc)), B, K, mode, cam.ctypes.data, 512.0, 0.7,
+                                     L.dptr(term), L.dptr(dJ), L.stream_ptr()))
+        assert abs(term.item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert rel(npy(dJ), Jt.grad.numpy()) < 1e-4
+    a = rng.normal(0, 1, (B, 156)).astype(np.float32); b = rng.normal(0, 1, (B, 69)).astype(np.float32)
+    term = torch.zeros(1, dtype=torch.float64, device="cuda"); at = cu(a); da = torch.zeros_like(at)
+    L.check(L.lib().vt_sqdiff_loss(at[:, 3:].data_ptr(), 156, L.dptr(cu(b)), 69, B, 69, float(B), 2.0, L.dptr(term), da[:, 3:].data_ptr(), L.stream_ptr()))
+    d = a[:, 3:72].astype(np.float64) - b
+    assert abs(term.item() - (d ** 2).sum() / B) < 1e-5 * (d ** 2).sum() / B
+    assert rel(npy(da)[:, 3:72], 2 * d / B * 2.0) < 1e-5 and np.abs(npy(da)[:, 72:]).max() == 0

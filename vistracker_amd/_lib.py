@@ -1,0 +1,112 @@
+"""ctypes binding of ``libvistracker_hip.so`` (the C ABI declared in ``include/vistracker.h``).
+
+The library is the product: every hot-path op of this package goes through it.  There is no
+CPU fallback -- if the shared object is missing or a GPU op is requested without a GPU the
+call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvistracker_hip.so")
+
+vp = C.c_void_p
+fp = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
+ci = C.c_int
+cl = C.c_long
+cf = C.c_float
+cd = C.c_double
+
+
+class VtMaps(C.Structure):
+    _fields_ = [("maps", C.c_void_p * 8), ("res", C.c_int * 8)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check the export list against the header
+SIGNATURES = {
+    "vt_last_error": (C.c_char_p, []),
+    "vt_version": (ci, []),
+    "vt_smplh_create": (ci, [C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp]),
+    "vt_smplh_destroy": (None, [vp]),
+    "vt_smplh_workspace_floats": (cl, [ci]),
+    "vt_smplh_bwd_scratch_floats": (cl, [ci]),
+    "vt_smplh_forward": (ci, [vp, fp, fp, fp, ci, fp, fp, fp, fp, vp]),
+    "vt_smplh_backward": (ci, [vp, fp, fp, ci, fp, fp, fp, fp, fp, fp, fp, fp, vp]),
+    "vt_rodrigues_forward": (ci, [fp, ci, fp, vp]),
+    "vt_rodrigues_backward": (ci, [fp, ci, fp, fp, vp]),
+    "vt_landmarks_create": (ci, [C.POINTER(vp), vp, vp, vp, ci, ci, vp]),
+    "vt_landmarks_destroy": (None, [vp]),
+    "vt_landmarks_forward": (ci, [vp, fp, ci, fp, vp]),
+    "vt_landmarks_backward": (ci, [vp, fp, ci, fp, ci, vp]),
+    "vt_mahalanobis": (ci, [fp, ci, ci, ci, ci, fp, fp, fp, fp, cf, vp]),
+    "vt_fill_f64": (ci, [fp, cl, cd, vp]),
+    "vt_sum_to_term": (ci, [fp, ci, cf, fp, vp]),
+    "vt_sifnet_create": (ci, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]),
+    "vt_sifnet_destroy": (None, [vp]),
+    "vt_nchw_to_nhwc": (ci, [fp, ci, ci, ci, ci, fp, vp]),
+    "vt_query_forward": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, fp, fp, fp, fp, vp]),
+    "vt_query_backward": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, fp, fp, fp, fp, fp, vp]),
+    "vt_query_human_loss": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, cf, cf, fp, fp, vp]),
+    "vt_query_object_loss": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, cf, fp, fp, vp]),
+    "vt_so3_project_forward": (ci, [fp, fp, ci, fp, vp]),
+    "vt_so3_project_backward": (ci, [fp, fp, ci, fp, fp, vp]),
+    "vt_rigid_forward": (ci, [fp, ci, fp, fp, fp, ci, ci, fp, vp]),
+    "vt_rigid_backward": (ci, [fp, ci, fp, ci, ci, fp, fp, fp, ci, vp]),
+    "vt_accel_loss": (ci, [fp, ci, ci, fp, cf, fp, fp, vp]),
+    "vt_velocity_loss": (ci, [fp, ci, ci, cf, fp, fp, vp]),
+    "vt_kpts_loss": (ci, [fp, fp, fp, ci, ci, ci, vp, cf, cf, fp, fp, vp]),
+    "vt_sqdiff_loss": (ci, [fp, ci, fp, ci, ci, ci, cf, cf, fp, fp, vp]),
+    "vt_chamfer_ragged": (ci, [fp, fp, fp, fp, ci, cf, fp, fp, fp, vp]),
+    "vt_sil_forward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, vp]),
+    "vt_sil_backward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, cf, fp, fp, vp]),
+    "vt_sil_mask_loss": (ci, [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp]),
+    "vt_adam_step": (ci, [fp, fp, fp, fp, cl, ci, cf, cf, cf, cf, fp, vp]),
+    "vt_loss_reduce_and_stop": (ci, [fp, vp, ci, cf, ci, fp, fp, fp, ci, vp]),
+    "vt_fill": (ci, [fp, cl, cf, vp]),
+    "vt_selftest_mfma": (ci, [fp, fp, fp, vp]),
+}
+
+_lib = None
+
+
+class VtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it was not built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VtError(f"{LIB_PATH} is missing: build it with `make -C vistracker_amd/csrc` "
+                          f"(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise VtError(f"libvistracker_hip error {rc}: {lib().vt_last_error().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dptr(t):
+    """device pointer of a contiguous float32/int32/float64 CUDA tensor (or None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VtError("libvistracker_hip ops need CUDA (HIP) tensors; there is no CPU fallback in the product path")
+    if not t.is_contiguous():
+        raise VtError("libvistracker_hip ops need contiguous tensors")
+    return t.data_ptr()

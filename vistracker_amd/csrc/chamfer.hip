@@ -1,0 +1,68 @@
+// chamfer.hip -- ragged contact Chamfer (pytorch3d.loss.chamfer_distance on Pointclouds, K=1 squared-L2 NN both ways,
+// point_reduction='mean' over each cloud's true length, batch_reduction='mean' over pairs).  PARITY UNPINNED: pytorch3d
+// is not vendored by the reference; semantics restated from its documented defaults.
+// One workgroup per (frame, part) pair; the far cloud is staged through LDS in 1024-point chunks (contact sets are
+// 1..~1600 points, recon_fit_trivis_full.py:393-457), brute force O(n_x n_y).
+#include "common.h"
+
+#define CH_CHUNK 1024
+
+template <bool XSIDE>
+__device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na, const float *__restrict__ bpts, int nb, float *sB,
+                                            float gs, float *ga, float *gb, double &acc)
+{
+    // for every point of a: nearest point of b
+    for (int i0 = 0; i0 < na; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (i < na) { ax = a[3 * i]; ay = a[3 * i + 1]; az = a[3 * i + 2]; }
+        float best = INFINITY; int bj = -1;
+        for (int c0 = 0; c0 < nb; c0 += CH_CHUNK) {
+            const int cn = min(CH_CHUNK, nb - c0);
+            __syncthreads();
+            for (int t = threadIdx.x; t < cn * 3; t += 256) sB[t] = bpts[3 * c0 + t];
+            __syncthreads();
+            if (i < na) for (int j = 0; j < cn; j++) {
+                const float d0 = ax - sB[3 * j], d1 = ay - sB[3 * j + 1], d2 = az - sB[3 * j + 2];
+                const float dd = d0 * d0 + d1 * d1 + d2 * d2;
+                if (dd < best) { best = dd; bj = c0 + j; }
+            }
+        }
+        if (i < na && bj >= 0) {
+            acc += (double)best / (double)na;
+            if (ga || gb) {
+                const float g0 = 2.f * (ax - bpts[3 * bj]) * gs / na, g1 = 2.f * (ay - bpts[3 * bj + 1]) * gs / na, g2 = 2.f * (az - bpts[3 * bj + 2]) * gs / na;
+                if (ga) { atomicAdd(ga + 3 * i, g0); atomicAdd(ga + 3 * i + 1, g1); atomicAdd(ga + 3 * i + 2, g2); }
+                if (gb) { atomicAdd(gb + 3 * bj, -g0); atomicAdd(gb + 3 * bj + 1, -g1); atomicAdd(gb + 3 * bj + 2, -g2); }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ x, const int *__restrict__ offx, const float *__restrict__ y,
+                                                      const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy)
+{
+    __shared__ float sB[CH_CHUNK * 3];
+    __shared__ double red[4];
+    const int p = blockIdx.x;
+    const int ox = offx[p], nx = offx[p + 1] - ox, oy = offy[p], ny = offy[p + 1] - oy;
+    double acc = 0;
+    if (nx > 0 && ny > 0) {
+        chamfer_dir<true>(x + 3 * (size_t)ox, nx, y + 3 * (size_t)oy, ny, sB, gs, dx ? dx + 3 * (size_t)ox : nullptr, dy ? dy + 3 * (size_t)oy : nullptr, acc);
+        chamfer_dir<false>(y + 3 * (size_t)oy, ny, x + 3 * (size_t)ox, nx, sB, gs, dy ? dy + 3 * (size_t)oy : nullptr, dx ? dx + 3 * (size_t)ox : nullptr, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && term) atomicAdd(term, (red[0] + red[1] + red[2] + red[3]) / (double)P);
+}
+
+extern "C" int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int *offy, int P, float gscale, double *term,
+                                 float *dx, float *dy, void *stream)
+{
+    VT_REQUIRE(x && offx && y && offy && P > 0, "vt_chamfer_ragged: bad argument");
+    hipLaunchKernelGGL(chamfer_kernel, dim3(P), dim3(256), 0, vt_stream(stream), x, offx, y, offy, P, gscale / (float)P, term, dx, dy);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

@@ -1,0 +1,535 @@
+// misc.hip -- the small ops of the fit step: landmark regressors, priors, SO(3) projection, rigid transform,
+// temporal stencils, keypoint terms, Adam, device-side early stop, layout conversion.  All HBM-bound and tiny
+// next to the point query; the design goal is "one launch each, no host sync, deterministic gradients".
+#include "common.h"
+
+thread_local char vt_err_buf[512] = {0};
+extern "C" const char *vt_last_error(void) { return vt_err_buf; }
+extern "C" int vt_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------
+// utilities
+// ---------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(float *p, long n, float v) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void fill64_kernel(double *p, long n, double v) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+extern "C" int vt_fill(float *p, long n, float value, void *stream)
+{
+    VT_REQUIRE(p && n > 0, "vt_fill: bad argument");
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, vt_stream(stream), p, n, value);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_fill_f64(double *p, long n, double value, void *stream)
+{
+    VT_REQUIRE(p && n > 0, "vt_fill_f64: bad argument");
+    hipLaunchKernelGGL(fill64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, vt_stream(stream), p, n, value);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_to_term_kernel(const float *v, int n, float scale, double *term)
+{
+    __shared__ double red[4];
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(term, (red[0] + red[1] + red[2] + red[3]) * (double)scale);
+}
+extern "C" int vt_sum_to_term(const float *value, int n, float scale, double *term, void *stream)
+{
+    VT_REQUIRE(value && term && n > 0, "vt_sum_to_term: bad argument");
+    hipLaunchKernelGGL(sum_to_term_kernel, dim3(1), dim3(256), 0, vt_stream(stream), value, n, scale, term);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// block-level fp64 accumulate into a term: every thread contributes `s`
+__device__ __forceinline__ void term_add(double s, double *term, double *red /* >= blockDim/64 doubles */)
+{
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < nw; i++) t += red[i]; if (term) atomicAdd(term, t); }
+}
+
+// NCHW -> NHWC, 32x32 LDS tile transpose per frame: src viewed as [C][HW], dst as [HW][C]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ src, int C, int HW, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * C * HW;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) { const int c = c0 + i, p = p0 + tx; tile[i][tx] = (c < C && p < HW) ? src[base + (size_t)c * HW + p] : 0.f; }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) { const int p = p0 + i, c = c0 + tx; if (p < HW && c < C) dst[base + (size_t)p * C + c] = tile[tx][i]; }
+}
+extern "C" int vt_nchw_to_nhwc(const float *src, int B, int C, int H, int W, float *dst, void *stream)
+{
+    VT_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "vt_nchw_to_nhwc: bad argument");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, vt_stream(stream), src, C, HW, dst);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// landmark regressors (body_landmark.py:16-28; torch_functions.py:52-76)
+// ---------------------------------------------------------------------------------------------------
+struct vt_landmarks {
+    int K, V;
+    int *indptr, *indices; float *data;      // CSR (K rows)
+    int *colptr, *rowidx; float *cdata;      // CSC (V columns) for the VJP
+};
+
+__global__ __launch_bounds__(64) void landmarks_fwd_kernel(const int *indptr, const int *indices, const float *data,
+                                                           const float *verts, int V, int K, float *out)
+{
+    const int k = blockIdx.x, b = blockIdx.y;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int e = indptr[k] + threadIdx.x; e < indptr[k + 1]; e += 64) {
+        const float w = data[e]; const float *v = verts + ((size_t)b * V + indices[e]) * 3;
+        a0 += w * v[0]; a1 += w * v[1]; a2 += w * v[2];
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (threadIdx.x == 0) { float *o = out + ((size_t)b * K + k) * 3; o[0] = a0; o[1] = a1; o[2] = a2; }
+}
+
+__global__ void landmarks_bwd_kernel(const int *colptr, const int *rowidx, const float *cdata, const float *dout,
+                                     int V, int K, int B, float *dverts, int accumulate)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (v >= V) return;
+    const int s = colptr[v], e = colptr[v + 1];
+    if (s == e && accumulate) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = s; i < e; i++) { const float w = cdata[i]; const float *g = dout + ((size_t)b * K + rowidx[i]) * 3; a0 += w * g[0]; a1 += w * g[1]; a2 += w * g[2]; }
+    float *o = dverts + ((size_t)b * V + v) * 3;
+    if (accumulate) { o[0] += a0; o[1] += a1; o[2] += a2; } else { o[0] = a0; o[1] = a1; o[2] = a2; }
+}
+
+extern "C" int vt_landmarks_create(vt_landmarks **out, const int *indptr, const int *indices, const float *data, int K, int V, void *stream)
+{
+    VT_REQUIRE(out && indptr && indices && data && K > 0 && V > 0, "vt_landmarks_create: bad argument");
+    hipStream_t st = vt_stream(stream);
+    const int nnz = indptr[K];
+    int *colptr = new int[V + 1](), *rowidx = new int[nnz]; float *cdata = new float[nnz];
+    for (int e = 0; e < nnz; e++) { VT_REQUIRE(indices[e] >= 0 && indices[e] < V, "vt_landmarks_create: column index out of range"); colptr[indices[e] + 1]++; }
+    for (int v = 0; v < V; v++) colptr[v + 1] += colptr[v];
+    int *fillp = new int[V];
+    memcpy(fillp, colptr, sizeof(int) * V);
+    for (int k = 0; k < K; k++) for (int e = indptr[k]; e < indptr[k + 1]; e++) { const int p = fillp[indices[e]]++; rowidx[p] = k; cdata[p] = data[e]; }
+    vt_landmarks *h = new vt_landmarks(); h->K = K; h->V = V;
+    int rc;
+    if ((rc = vt_upload(&h->indptr, indptr, (size_t)K + 1, st)) || (rc = vt_upload(&h->indices, indices, (size_t)nnz, st)) ||
+        (rc = vt_upload(&h->data, data, (size_t)nnz, st)) || (rc = vt_upload(&h->colptr, colptr, (size_t)V + 1, st)) ||
+        (rc = vt_upload(&h->rowidx, rowidx, (size_t)nnz, st)) || (rc = vt_upload(&h->cdata, cdata, (size_t)nnz, st))) return rc;
+    VT_HIP(hipStreamSynchronize(st));
+    delete[] colptr; delete[] rowidx; delete[] cdata; delete[] fillp;
+    *out = h;
+    return VT_OK;
+}
+extern "C" void vt_landmarks_destroy(vt_landmarks *h)
+{
+    if (!h) return;
+    hipFree(h->indptr); hipFree(h->indices); hipFree(h->data); hipFree(h->colptr); hipFree(h->rowidx); hipFree(h->cdata);
+    delete h;
+}
+extern "C" int vt_landmarks_forward(const vt_landmarks *h, const float *verts, int B, float *out, void *stream)
+{
+    VT_REQUIRE(h && verts && out && B > 0, "vt_landmarks_forward: bad argument");
+    hipLaunchKernelGGL(landmarks_fwd_kernel, dim3(h->K, B), dim3(64), 0, vt_stream(stream), h->indptr, h->indices, h->data, verts, h->V, h->K, out);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_landmarks_backward(const vt_landmarks *h, const float *dout, int B, float *dverts, int accumulate, void *stream)
+{
+    VT_REQUIRE(h && dout && dverts && B > 0, "vt_landmarks_backward: bad argument");
+    hipLaunchKernelGGL(landmarks_bwd_kernel, dim3((h->V + 255) / 256, B), dim3(256), 0, vt_stream(stream), h->colptr, h->rowidx, h->cdata, dout,
+                       h->V, h->K, B, dverts, accumulate);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Mahalanobis priors (th_smpl_prior.py:30-38; th_hand_prior.py:57-72)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mahalanobis_kernel(const float *x, int stride, int off, int n, const float *mean,
+                                                         const float *prec, float *value, float *dx, float gscale)
+{
+    __shared__ float d[64], t2[64];
+    const int b = blockIdx.x, j = threadIdx.x;
+    d[j] = (j < n) ? x[(size_t)b * stride + off + j] - mean[j] : 0.f;
+    __syncthreads();
+    float a = 0.f;
+    if (j < n) for (int i = 0; i < n; i++) a += d[i] * prec[i * n + j];
+    t2[j] = a;
+    const float val = wave_sum(a * a);
+    if (j == 0) value[b] = val;
+    __syncthreads();
+    if (dx && j < n) {
+        float g = 0.f;
+        for (int k = 0; k < n; k++) g += t2[k] * prec[j * n + k];
+        dx[(size_t)b * stride + off + j] += 2.f * g * gscale;
+    }
+}
+extern "C" int vt_mahalanobis(const float *x, int B, int stride, int off, int n, const float *mean, const float *prec,
+                              float *value, float *dx, float gscale, void *stream)
+{
+    VT_REQUIRE(x && mean && prec && value && B > 0 && n > 0 && n <= 64 && off >= 0 && off + n <= stride, "vt_mahalanobis: bad argument (n must be <= 64)");
+    hipLaunchKernelGGL(mahalanobis_kernel, dim3(B), dim3(64), 0, vt_stream(stream), x, stride, off, n, mean, prec, value, dx, gscale);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SO(3) projection (recon_fit_base.py:179-199): one thread per matrix, one-sided Jacobi SVD in registers.
+// VJP in polar form: dM = U D Z V^T, Q = D U^T G V, Z_ij = (Q_ij - Q_ji)/(h_i + h_j), h = (s1, s2, d*s3)
+// (the same derivative autograd takes through torch.svd/det, without its 1/(s_i^2 - s_j^2) cancellation).
+// ---------------------------------------------------------------------------------------------------
+struct Svd3 { float U[9], V[9], s[3], d; };
+
+__device__ __forceinline__ void jacobi_pair(float *A, float *V, const int p, const int q)
+{
+    float a = 0.f, b = 0.f, g = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { a += A[3 * r + p] * A[3 * r + p]; b += A[3 * r + q] * A[3 * r + q]; g += A[3 * r + p] * A[3 * r + q]; }
+    if (fabsf(g) <= 1e-30f) return;
+    const float zeta = (b - a) / (2.f * g);
+    const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+    const float c = 1.f / sqrtf(1.f + t * t), sn = c * t;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float x = A[3 * r + p], y = A[3 * r + q]; A[3 * r + p] = c * x - sn * y; A[3 * r + q] = sn * x + c * y;
+        x = V[3 * r + p]; y = V[3 * r + q]; V[3 * r + p] = c * x - sn * y; V[3 * r + q] = sn * x + c * y;
+    }
+}
+
+__device__ __forceinline__ void svd3(const float *M, Svd3 &o)
+{
+    float A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+    for (int e = 0; e < 9; e++) A[e] = M[e];
+    for (int sweep = 0; sweep < 8; sweep++) { jacobi_pair(A, V, 0, 1); jacobi_pair(A, V, 0, 2); jacobi_pair(A, V, 1, 2); }
+    float sv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) sv[c] = sqrtf(A[c] * A[c] + A[3 + c] * A[3 + c] + A[6 + c] * A[6 + c]);
+    // sort columns by singular value, descending (torch.svd order; the last one carries the det sign)
+#define SWAPC(i, j)                                                                                          \
+    if (sv[j] > sv[i]) {                                                                                     \
+        float t_ = sv[i]; sv[i] = sv[j]; sv[j] = t_;                                                         \
+        for (int r = 0; r < 3; r++) { t_ = A[3 * r + i]; A[3 * r + i] = A[3 * r + j]; A[3 * r + j] = t_;     \
+                                      t_ = V[3 * r + i]; V[3 * r + i] = V[3 * r + j]; V[3 * r + j] = t_; }   \
+    }
+    SWAPC(0, 1) SWAPC(0, 2) SWAPC(1, 2)
+#undef SWAPC
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        o.s[c] = sv[c];
+        const float inv = sv[c] > 0.f ? 1.f / sv[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { o.U[3 * r + c] = A[3 * r + c] * inv; o.V[3 * r + c] = V[3 * r + c]; }
+    }
+    // det(U V^T) = det(U) det(V)
+    const float *U = o.U, *W = o.V;
+    const float dU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) + U[2] * (U[3] * U[7] - U[4] * U[6]);
+    const float dV = W[0] * (W[4] * W[8] - W[5] * W[7]) - W[1] * (W[3] * W[8] - W[5] * W[6]) + W[2] * (W[3] * W[7] - W[4] * W[6]);
+    o.d = dU * dV;
+}
+
+__global__ void so3_fwd_kernel(const float *M0, const float *noise, int B, float *R)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float M[9]; Svd3 s;
+#pragma unroll
+    for (int e = 0; e < 9; e++) M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f);
+    svd3(M, s);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) R[9 * b + 3 * r + c] = s.U[3 * r] * s.V[3 * c] + s.U[3 * r + 1] * s.V[3 * c + 1] + s.d * s.U[3 * r + 2] * s.V[3 * c + 2];
+}
+
+__global__ void so3_bwd_kernel(const float *M0, const float *noise, int B, const float *dR, float *dM)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float M[9], G[9]; Svd3 s;
+#pragma unroll
+    for (int e = 0; e < 9; e++) { M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f); G[e] = dR[9 * b + e]; }
+    svd3(M, s);
+    const float D[3] = {1.f, 1.f, s.d}, h[3] = {s.s[0], s.s[1], s.d * s.s[2]};
+    float UtG[9], Q[9], Z[9], UDZ[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) UtG[3 * r + c] = s.U[r] * G[c] + s.U[3 + r] * G[3 + c] + s.U[6 + r] * G[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Q[3 * r + c] = D[r] * (UtG[3 * r] * s.V[c] + UtG[3 * r + 1] * s.V[3 + c] + UtG[3 * r + 2] * s.V[6 + c]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Z[3 * r + c] = (r == c) ? 0.f : (Q[3 * r + c] - Q[3 * c + r]) / (h[r] + h[c]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) UDZ[3 * r + c] = s.U[3 * r] * D[0] * Z[c] + s.U[3 * r + 1] * D[1] * Z[3 + c] + s.U[3 * r + 2] * D[2] * Z[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) dM[9 * b + 3 * r + c] = UDZ[3 * r] * s.V[3 * c] + UDZ[3 * r + 1] * s.V[3 * c + 1] + UDZ[3 * r + 2] * s.V[3 * c + 2];
+}
+
+extern "C" int vt_so3_project_forward(const float *M0, const float *noise, int B, float *R, void *stream)
+{
+    VT_REQUIRE(M0 && R && B > 0, "vt_so3_project_forward: bad argument");
+    hipLaunchKernelGGL(so3_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, vt_stream(stream), M0, noise, B, R);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_so3_project_backward(const float *M0, const float *noise, int B, const float *dR, float *dM, void *stream)
+{
+    VT_REQUIRE(M0 && dR && dM && B > 0, "vt_so3_project_backward: bad argument");
+    hipLaunchKernelGGL(so3_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, vt_stream(stream), M0, noise, B, dR, dM);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rigid transform (recon_fit_base.py:455-459)
+// ---------------------------------------------------------------------------------------------------
+__global__ void rigid_fwd_kernel(const float *X0, int shared, const float *R, const float *t, const float *s, int B, int N, float *X)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const float *x = X0 + ((shared ? 0 : (size_t)b * N) + n) * 3, *r = R + 9 * b;
+    const float x0 = x[0], x1 = x[1], x2 = x[2], sc = s[b];
+    float *o = X + ((size_t)b * N + n) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = (x0 * r[c] + x1 * r[3 + c] + x2 * r[6 + c] + t[3 * b + c]) * sc;
+}
+
+__global__ __launch_bounds__(256) void rigid_bwd_kernel(const float *X0, int shared, const float *s, int N, const float *dX,
+                                                        float *dR, float *dt, int accumulate)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float a[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) a[e] = 0.f;
+    const float sc = s[b];
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float *x = X0 + ((shared ? 0 : (size_t)b * N) + n) * 3, *g = dX + ((size_t)b * N + n) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; e++) {
+        const float v = block_sum<4>(a[e], red);
+        if (threadIdx.x == 0) {
+            float *dst = (e < 9) ? dR + 9 * b + e : dt + 3 * b + (e - 9);
+            *dst = accumulate ? *dst + v : v;
+        }
+    }
+}
+
+extern "C" int vt_rigid_forward(const float *X0, int shared_x0, const float *R, const float *t, const float *s, int B, int N, float *X, void *stream)
+{
+    VT_REQUIRE(X0 && R && t && s && X && B > 0 && N > 0, "vt_rigid_forward: bad argument");
+    hipLaunchKernelGGL(rigid_fwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, vt_stream(stream), X0, shared_x0, R, t, s, B, N, X);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_rigid_backward(const float *X0, int shared_x0, const float *s, int B, int N, const float *dX, float *dR, float *dt,
+                                 int accumulate, void *stream)
+{
+    VT_REQUIRE(X0 && s && dX && dR && dt && B > 0 && N > 0, "vt_rigid_backward: bad argument");
+    hipLaunchKernelGGL(rigid_bwd_kernel, dim3(B), dim3(256), 0, vt_stream(stream), X0, shared_x0, s, N, dX, dR, dt, accumulate);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// temporal stencils: thread == one column of v (B,D), walks the frames with a sliding window so that every
+// gradient element is written exactly once (no atomics):  a_b = 2 v_b - v_{b-1} - v_{b+1}
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict__ v, int B, int D, const float *__restrict__ elem_w,
+                                                         float gs, double *term, float *__restrict__ dv)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < D) {
+        const float w = elem_w ? elem_w[i] : 1.f;
+        float vm = v[i], v0 = v[(size_t)D + i], vp = v[(size_t)2 * D + i];
+        float a_prev = 0.f, a_cur = 2.f * v0 - vm - vp, a_next;
+        // b = index of a_cur's centre frame
+        for (int b = 1; b <= B - 2; b++) {
+            float vpp = 0.f;
+            if (b + 2 < B) { vpp = v[(size_t)(b + 2) * D + i]; a_next = 2.f * vp - v0 - vpp; } else a_next = 0.f;
+            acc += (double)(w * a_cur * a_cur);
+            if (dv) {
+                if (b == 1) dv[i] += gs * w * (-a_cur);
+                dv[(size_t)b * D + i] += gs * w * (2.f * a_cur - a_prev - a_next);
+                if (b == B - 2) dv[(size_t)(B - 1) * D + i] += gs * w * (-a_cur);
+            }
+            a_prev = a_cur; a_cur = a_next; vm = v0; v0 = vp; vp = vpp;
+        }
+    }
+    term_add(acc / ((double)(B - 2) * D), term, red);
+}
+
+__global__ __launch_bounds__(256) void velocity_loss_kernel(const float *__restrict__ v, int B, int D, float gs, double *term, float *__restrict__ dv)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < D) {
+        float prev = v[i], d_prev = 0.f;
+        for (int b = 1; b < B; b++) {
+            const float cur = v[(size_t)b * D + i], d = cur - prev;
+            acc += (double)(d * d);
+            if (dv) dv[(size_t)(b - 1) * D + i] += gs * (d_prev - d);
+            d_prev = d; prev = cur;
+        }
+        if (dv) dv[(size_t)(B - 1) * D + i] += gs * d_prev;
+    }
+    term_add(acc / ((double)(B - 1) * D), term, red);
+}
+
+extern "C" int vt_accel_loss(const float *v, int B, int D, const float *elem_w, float gscale, double *term, float *dv, void *stream)
+{
+    VT_REQUIRE(v && B >= 3 && D > 0, "vt_accel_loss: needs B >= 3 (the reference returns NaN for empty stencils)");
+    // d/dv of mean(w a^2): 2 w a / cnt per stencil element; a's own coefficient 2 is folded in the kernel
+    const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, elem_w, gs, term, dv);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_velocity_loss(const float *v, int B, int D, float gscale, double *term, float *dv, void *stream)
+{
+    VT_REQUIRE(v && B >= 2 && D > 0, "vt_velocity_loss: needs B >= 2");
+    const float gs = 2.f * gscale / ((float)(B - 1) * (float)D);
+    hipLaunchKernelGGL(velocity_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, gs, term, dv);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2D keypoint terms (fit_SMPLH_kpts.py:280-310; recon_fit_base.py:767-802)
+// ---------------------------------------------------------------------------------------------------
+struct Cam5 { float fx, fy, cx, cy, crop; };
+
+__global__ __launch_bounds__(256) void kpts_loss_kernel(const float *J, const float *kpts, const float *cc, int BK, int K, int mode, Cam5 cam,
+                                                        float net_size, float gscale, float inv_cnt, double *term, float *dJ)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < BK) {
+        const int b = i / K;
+        const float x = J[3 * i], y = J[3 * i + 1], z = J[3 * i + 2];
+        float px = cam.fx * x / z + cam.cx, py = cam.fy * y / z + cam.cy, sc = 1.f;
+        if (mode == 1) {
+            px = cam.crop / 2 + px - cc[2 * b]; py = cam.crop / 2 + py - cc[2 * b + 1];
+            sc = net_size / cam.crop; px *= sc; py *= sc;
+        }
+        const float ex = px - kpts[3 * i], ey = py - kpts[3 * i + 1], conf = kpts[3 * i + 2];
+        acc = (double)((ex * ex + ey * ey) * conf);
+        const float gpx = 2.f * ex * conf * gscale * inv_cnt * sc, gpy = 2.f * ey * conf * gscale * inv_cnt * sc;
+        dJ[3 * i] = gpx * cam.fx / z; dJ[3 * i + 1] = gpy * cam.fy / z;
+        dJ[3 * i + 2] = -gpx * cam.fx * x / (z * z) - gpy * cam.fy * y / (z * z);
+    }
+    term_add(acc * (double)inv_cnt, term, red);
+}
+extern "C" int vt_kpts_loss(const float *J, const float *kpts, const float *crop_center, int B, int K, int mode, const float *cam,
+                            float net_size, float gscale, double *term, float *dJ, void *stream)
+{
+    VT_REQUIRE(J && kpts && cam && dJ && B > 0 && K > 0 && (mode == 0 || (mode == 1 && crop_center)), "vt_kpts_loss: bad argument");
+    Cam5 c{cam[0], cam[1], cam[2], cam[3], cam[4]};
+    const float inv_cnt = 1.f / (mode == 0 ? (float)(B * K * 2) : (float)(B * K));
+    hipLaunchKernelGGL(kpts_loss_kernel, dim3((B * K + 255) / 256), dim3(256), 0, vt_stream(stream), J, kpts, crop_center, B * K, K, mode, c,
+                       net_size, gscale, inv_cnt, term, dJ);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+__global__ __launch_bounds__(256) void sqdiff_loss_kernel(const float *a, int as, const float *b, int bs, int rows, int cols, float inv_denom,
+                                                          float gscale, double *term, float *da)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < rows * cols) {
+        const int r = i / cols, c = i % cols;
+        const float d = a[(size_t)r * as + c] - b[(size_t)r * bs + c];
+        acc = (double)(d * d);
+        if (da) da[(size_t)r * as + c] += 2.f * d * inv_denom * gscale;
+    }
+    term_add(acc * (double)inv_denom, term, red);
+}
+extern "C" int vt_sqdiff_loss(const float *a, int a_stride, const float *b, int b_stride, int rows, int cols, float denom, float gscale,
+                              double *term, float *da, void *stream)
+{
+    VT_REQUIRE(a && b && rows > 0 && cols > 0 && denom > 0, "vt_sqdiff_loss: bad argument");
+    hipLaunchKernelGGL(sqdiff_loss_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, vt_stream(stream), a, a_stride, b, b_stride, rows, cols,
+                       1.f / denom, gscale, term, da);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor path) + device-side early stop
+// ---------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *p, const float *g, float *m, float *v, long n, float step_size, float bc2s, float beta1, float beta2,
+                            float eps, const int *stop_flag)
+{
+    if (stop_flag && *stop_flag) return;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+extern "C" int vt_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr, float beta1, float beta2, float eps,
+                            const int *stop_flag, void *stream)
+{
+    VT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vt_adam_step: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, vt_stream(stream), p, g, m, v, n, (float)(lr / bc1),
+                       (float)sqrt(bc2), beta1, beta2, eps, stop_flag);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+struct TermW { float w[16]; };
+__global__ void loss_reduce_kernel(const double *terms, TermW tw, int nterms, float tol, int armed, float *state, int *stop_flag,
+                                   float *history, int slot)
+{
+    if (stop_flag && *stop_flag) { if (history) history[slot] = nanf(""); return; }
+    double l = 0;
+    for (int k = 0; k < nterms; k++) l += (double)tw.w[k] * terms[k];
+    const float loss = (float)l, prev = state[0];
+    if (history) history[slot] = loss;
+    // reference: (abs(prev_loss - loss) / prev_loss < prev_loss * tol) and <iteration gate>
+    if (armed && stop_flag && (fabsf(prev - loss) / prev < prev * tol)) *stop_flag = 1;
+    state[0] = loss; state[1] = loss;
+}
+extern "C" int vt_loss_reduce_and_stop(const double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag,
+                                       float *history, int slot, void *stream)
+{
+    VT_REQUIRE(terms && w && state && nterms > 0 && nterms <= 16, "vt_loss_reduce_and_stop: bad argument (nterms <= 16)");
+    TermW tw; for (int k = 0; k < 16; k++) tw.w[k] = k < nterms ? w[k] : 0.f;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1), 0, vt_stream(stream), terms, tw, nterms, tol, armed, state, stop_flag, history, slot);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

@@ -1,0 +1,502 @@
+// smplh.hip -- SMPL-H forward / backward for gfx950.
+//
+// Replaces SMPL_Layer.forward (lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:73-176) and the autograd
+// backward the reference gets from ~15k eager ops per call.  Layout decisions (DESIGN.md "SMPL-H"):
+//   * model constants are re-laid out once at handle creation so that a thread == a vertex reads coalesced:
+//       posedirs  -> P_kcv [459][3][VP]   (forward, k-major)   and kept as P_vck [V*3][459] (backward, thread == k)
+//       shapedirs -> S_lcv [10][3][VP]                         and S_vcl [V*3][10]
+//       weights   -> W_jv  [52][VP]
+//     VP = 6912 = 27 * 256 (zero padded) so every workgroup is full.
+//   * the joint regressor is folded on the host: J = J_t + J_s . beta (J = Jreg . v_shaped is linear in beta),
+//     which removes the 52x6890 reduction from every call.
+//   * forward = 2 launches (pose/chain, vertices); backward = 2 launches (vertex tile partials, per-frame
+//     reduce + chain VJP).  Reductions are two-stage and deterministic (no float atomics).
+#include "common.h"
+
+#define V_ VT_SMPL_V
+#define J_ VT_SMPL_J
+#define NB_ VT_SMPL_NB
+#define NP_ VT_SMPL_NP
+#define VP_ 6912
+#define NVT_ 27 /* vertex tiles of 256 */
+
+// per-frame workspace layout (floats)
+#define WS_R 0
+#define WS_J (52 * 9)
+#define WS_G (WS_J + 52 * 3)
+#define WS_A (WS_G + 52 * 12)
+#define WS_FRAME (WS_A + 52 * 12) /* 1872 */
+// per (tile, frame) partial layout of the backward
+#define PT_DA 0
+#define PT_DTR 624
+#define PT_DPM 627
+#define PT_DB (627 + 459)
+#define PT_N (627 + 469) /* 1096 */
+
+struct SmplParents { int p[J_]; };
+
+struct vt_smplh {
+    float *P_kcv, *P_vck, *S_lcv, *S_vcl, *T_cv, *W_jv, *J_t, *J_s;
+    SmplParents par;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// batch_rodrigues (rodrigues_layer.py:13-52).  NB the norm is of (theta + 1e-8), the division uses theta.
+// ---------------------------------------------------------------------------------------------------
+struct RodCtx { float n, ax, ay, az, c, s, qn, w, x, y, z; };
+
+__device__ __forceinline__ void rodrigues_fwd(const float *t, float *R, RodCtx *k)
+{
+    const float xe = t[0] + 1e-8f, ye = t[1] + 1e-8f, ze = t[2] + 1e-8f;
+    const float n = sqrtf(xe * xe + ye * ye + ze * ze);
+    const float ax = t[0] / n, ay = t[1] / n, az = t[2] / n;
+    const float h = n * 0.5f;
+    const float c = cosf(h), s = sinf(h);
+    const float q0 = c, q1 = s * ax, q2 = s * ay, q3 = s * az;
+    const float qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float w = q0 / qn, x = q1 / qn, y = q2 / qn, z = q3 / qn;
+    const float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+    const float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;   R[2] = 2 * wy + 2 * xz;
+    R[3] = 2 * wz + 2 * xy;   R[4] = w2 - x2 + y2 - z2; R[5] = 2 * yz - 2 * wx;
+    R[6] = 2 * xz - 2 * wy;   R[7] = 2 * wx + 2 * yz;   R[8] = w2 - x2 - y2 + z2;
+    if (k) { k->n = n; k->ax = ax; k->ay = ay; k->az = az; k->c = c; k->s = s; k->qn = qn; k->w = w; k->x = x; k->y = y; k->z = z; }
+}
+
+__device__ __forceinline__ void rodrigues_bwd(const float *t, const float *dR, float *dt)
+{
+    float R[9]; RodCtx k; rodrigues_fwd(t, R, &k);
+    const float w = k.w, x = k.x, y = k.y, z = k.z;
+    const float dw = 2 * w * (dR[0] + dR[4] + dR[8]) + 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    const float dx = 2 * x * (dR[0] - dR[4] - dR[8]) + 2 * (y * dR[1] + z * dR[2] + y * dR[3] - w * dR[5] + z * dR[6] + w * dR[7]);
+    const float dy = 2 * y * (-dR[0] + dR[4] - dR[8]) + 2 * (x * dR[1] + w * dR[2] + x * dR[3] + z * dR[5] - w * dR[6] + z * dR[7]);
+    const float dz = 2 * z * (-dR[0] - dR[4] + dR[8]) + 2 * (-w * dR[1] + x * dR[2] + w * dR[3] + y * dR[5] + x * dR[6] + y * dR[7]);
+    const float dot = w * dw + x * dx + y * dy + z * dz;
+    const float dq0 = (dw - w * dot) / k.qn, dq1 = (dx - x * dot) / k.qn, dq2 = (dy - y * dot) / k.qn, dq3 = (dz - z * dot) / k.qn;
+    const float dh = -k.s * dq0 + k.c * (k.ax * dq1 + k.ay * dq2 + k.az * dq3);
+    const float dax = k.s * dq1, day = k.s * dq2, daz = k.s * dq3;
+    const float dn = 0.5f * dh - (t[0] * dax + t[1] * day + t[2] * daz) / (k.n * k.n);
+    dt[0] = dax / k.n + dn * (t[0] + 1e-8f) / k.n;
+    dt[1] = day / k.n + dn * (t[1] + 1e-8f) / k.n;
+    dt[2] = daz / k.n + dn * (t[2] + 1e-8f) / k.n;
+}
+
+__global__ void rodrigues_fwd_kernel(const float *aa, int n, float *R)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t[3] = {aa[3 * i], aa[3 * i + 1], aa[3 * i + 2]}, r[9];
+    rodrigues_fwd(t, r, nullptr);
+#pragma unroll
+    for (int e = 0; e < 9; e++) R[9 * i + e] = r[e];
+}
+
+__global__ void rodrigues_bwd_kernel(const float *aa, int n, const float *dR, float *daa)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t[3] = {aa[3 * i], aa[3 * i + 1], aa[3 * i + 2]}, g[9], d[3];
+#pragma unroll
+    for (int e = 0; e < 9; e++) g[e] = dR[9 * i + e];
+    rodrigues_bwd(t, g, d);
+    daa[3 * i] = d[0]; daa[3 * i + 1] = d[1]; daa[3 * i + 2] = d[2];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward, launch 1: one wave per frame -- rotations, joints, kinematic chain (smpl_layer.py:88-143)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict__ pose, const float *__restrict__ betas,
+                                                        const float *__restrict__ trans, const float *__restrict__ J_t,
+                                                        const float *__restrict__ J_s, SmplParents par,
+                                                        float *__restrict__ ws, float *__restrict__ jtr)
+{
+    __shared__ float sR[J_ * 9], sJ[J_ * 3], sG[J_ * 12];
+    const int b = blockIdx.x, j = threadIdx.x;
+    float *w = ws + (size_t)b * WS_FRAME;
+    if (j < J_) {
+        float t[3] = {pose[(b * J_ + j) * 3], pose[(b * J_ + j) * 3 + 1], pose[(b * J_ + j) * 3 + 2]}, R[9];
+        rodrigues_fwd(t, R, nullptr);
+#pragma unroll
+        for (int e = 0; e < 9; e++) { sR[j * 9 + e] = R[e]; w[WS_R + j * 9 + e] = R[e]; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float a = J_t[j * 3 + c];
+#pragma unroll
+            for (int l = 0; l < NB_; l++) a += J_s[(j * 3 + c) * NB_ + l] * betas[b * NB_ + l];
+            sJ[j * 3 + c] = a; w[WS_J + j * 3 + c] = a;
+        }
+    }
+    __syncthreads();
+    if (j == 0) {
+        // G_0 = [R_0 | J_0];  G_i = G_parent . [R_i | J_i - J_parent]
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sG[r * 4 + c] = sR[r * 3 + c]; sG[r * 4 + 3] = sJ[r]; }
+        for (int i = 1; i < J_; i++) {
+            const int p = par.p[i];
+            const float *Gp = sG + 12 * p, *Ri = sR + 9 * i;
+            const float d0 = sJ[3 * i] - sJ[3 * p], d1 = sJ[3 * i + 1] - sJ[3 * p + 1], d2 = sJ[3 * i + 2] - sJ[3 * p + 2];
+            float *Gi = sG + 12 * i;
+            for (int r = 0; r < 3; r++) {
+                const float g0 = Gp[r * 4], g1 = Gp[r * 4 + 1], g2 = Gp[r * 4 + 2];
+                Gi[r * 4 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
+                Gi[r * 4 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
+                Gi[r * 4 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
+                Gi[r * 4 + 3] = g0 * d0 + g1 * d1 + g2 * d2 + Gp[r * 4 + 3];
+            }
+        }
+    }
+    __syncthreads();
+    if (j < J_) {
+        // A_j = G_j - [0 | G_rot J_j]   (th_results2, smpl_layer.py:133-143);  jtr = G_t + trans (:154,172)
+        const float *G = sG + 12 * j;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float gt = G[r * 4 + 3];
+            w[WS_G + j * 12 + r * 4 + 0] = G[r * 4]; w[WS_G + j * 12 + r * 4 + 1] = G[r * 4 + 1];
+            w[WS_G + j * 12 + r * 4 + 2] = G[r * 4 + 2]; w[WS_G + j * 12 + r * 4 + 3] = gt;
+            w[WS_A + j * 12 + r * 4 + 0] = G[r * 4]; w[WS_A + j * 12 + r * 4 + 1] = G[r * 4 + 1]; w[WS_A + j * 12 + r * 4 + 2] = G[r * 4 + 2];
+            w[WS_A + j * 12 + r * 4 + 3] = gt - (G[r * 4] * sJ[3 * j] + G[r * 4 + 1] * sJ[3 * j + 1] + G[r * 4 + 2] * sJ[3 * j + 2]);
+            if (jtr) jtr[(b * J_ + j) * 3 + r] = gt + trans[3 * b + r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward, launch 2: thread == vertex, FB frames per workgroup.  blend shapes + LBS fused
+// (smpl_layer.py:103-112,145-173).  P is streamed once per FB frames, coalesced.
+// ---------------------------------------------------------------------------------------------------
+template <int FB>
+__global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ P_kcv, const float *__restrict__ S_lcv,
+                                                          const float *__restrict__ T_cv, const float *__restrict__ W_jv,
+                                                          const float *__restrict__ betas, const float *__restrict__ trans,
+                                                          const float *__restrict__ ws, int B,
+                                                          float *__restrict__ verts, float *__restrict__ v_posed)
+{
+    __shared__ __attribute__((aligned(16))) float pmT[NP_ * FB];
+    __shared__ __attribute__((aligned(16))) float sA[FB * 624];
+    __shared__ float sBeta[FB * NB_], sTr[FB * 3];
+    const int tid = threadIdx.x, b0 = blockIdx.y * FB, v = blockIdx.x * 256 + tid;
+    for (int i = tid; i < NP_ * FB; i += 256) {
+        const int k = i / FB, f = i % FB, b = min(b0 + f, B - 1), e = k % 9;
+        pmT[i] = ws[(size_t)b * WS_FRAME + WS_R + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+    for (int i = tid; i < FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[i] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
+    if (tid < FB * NB_) { const int f = tid / NB_, b = min(b0 + f, B - 1); sBeta[tid] = betas[b * NB_ + tid % NB_]; }
+    if (tid < FB * 3) { const int f = tid / 3, b = min(b0 + f, B - 1); sTr[tid] = trans[b * 3 + tid % 3]; }
+    __syncthreads();
+
+    float acc[FB][3];
+    {
+        const float t0 = T_cv[v], t1 = T_cv[VP_ + v], t2 = T_cv[2 * VP_ + v];
+#pragma unroll
+        for (int f = 0; f < FB; f++) { acc[f][0] = t0; acc[f][1] = t1; acc[f][2] = t2; }
+    }
+#pragma unroll
+    for (int l = 0; l < NB_; l++) {
+        const float s0 = S_lcv[(l * 3 + 0) * VP_ + v], s1 = S_lcv[(l * 3 + 1) * VP_ + v], s2 = S_lcv[(l * 3 + 2) * VP_ + v];
+#pragma unroll
+        for (int f = 0; f < FB; f++) { const float bl = sBeta[f * NB_ + l]; acc[f][0] += s0 * bl; acc[f][1] += s1 * bl; acc[f][2] += s2 * bl; }
+    }
+#pragma unroll 4
+    for (int k = 0; k < NP_; k++) {
+        const float p0 = P_kcv[(size_t)(k * 3 + 0) * VP_ + v], p1 = P_kcv[(size_t)(k * 3 + 1) * VP_ + v], p2 = P_kcv[(size_t)(k * 3 + 2) * VP_ + v];
+#pragma unroll
+        for (int f = 0; f < FB; f++) { const float m = pmT[k * FB + f]; acc[f][0] += p0 * m; acc[f][1] += p1 * m; acc[f][2] += p2 * m; }
+    }
+    float w[J_];
+#pragma unroll
+    for (int j = 0; j < J_; j++) w[j] = W_jv[j * VP_ + v];
+#pragma unroll
+    for (int f = 0; f < FB; f++) {
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; e++) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < J_; j++) {
+#pragma unroll
+            for (int e = 0; e < 12; e++) T[e] += w[j] * sA[f * 624 + j * 12 + e];
+        }
+        const int b = b0 + f;
+        if (b < B && v < V_) {
+            const size_t o = ((size_t)b * V_ + v) * 3;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                verts[o + r] = T[r * 4] * acc[f][0] + T[r * 4 + 1] * acc[f][1] + T[r * 4 + 2] * acc[f][2] + T[r * 4 + 3] + sTr[f * 3 + r];
+                v_posed[o + r] = acc[f][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, launch 1: per (vertex tile, FB frames) partial sums of dA (624), dtrans (3), dpose_map (459), dbetas (10)
+// ---------------------------------------------------------------------------------------------------
+#define WLD 257 /* padded row of the weight tile in LDS: bank = (j + v) % 32 */
+template <int FB>
+__global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ P_vck, const float *__restrict__ S_vcl,
+                                                             const float *__restrict__ W_jv, const float *__restrict__ ws,
+                                                             const float *__restrict__ v_posed, const float *__restrict__ dverts,
+                                                             int B, float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sW = lds;                         // [52][WLD]
+    float *sdT = sW + J_ * WLD;              // [256][13]
+    float *sdvp = sdT + 256 * 13;            // [768][FB]
+    float *sA = sdvp + 768 * FB;             // [FB][624]
+    const int tid = threadIdx.x, tile = blockIdx.x, b0 = blockIdx.y * FB, v0 = tile * 256, v = v0 + tid;
+    for (int i = tid; i < J_ * 256; i += 256) { const int j = i >> 8, vv = i & 255; sW[j * WLD + vv] = W_jv[j * VP_ + v0 + vv]; }
+    for (int i = tid; i < FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[i] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
+    __syncthreads();
+    for (int f = 0; f < FB; f++) {
+        const int b = b0 + f;
+        // phase 1: thread == vertex
+        float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
+        if (b < B && v < V_) {
+            const size_t o = ((size_t)b * V_ + v) * 3;
+            dv[0] = dverts[o]; dv[1] = dverts[o + 1]; dv[2] = dverts[o + 2];
+            vp[0] = v_posed[o]; vp[1] = v_posed[o + 1]; vp[2] = v_posed[o + 2];
+        }
+        float T[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) T[e] = 0.f;
+        for (int j = 0; j < J_; j++) {
+            const float wj = sW[j * WLD + tid];
+            const float *A = sA + f * 624 + j * 12;
+#pragma unroll
+            for (int r = 0; r < 3; r++) { T[r * 3] += wj * A[r * 4]; T[r * 3 + 1] += wj * A[r * 4 + 1]; T[r * 3 + 2] += wj * A[r * 4 + 2]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            sdT[tid * 13 + r * 4 + 0] = dv[r] * vp[0]; sdT[tid * 13 + r * 4 + 1] = dv[r] * vp[1];
+            sdT[tid * 13 + r * 4 + 2] = dv[r] * vp[2]; sdT[tid * 13 + r * 4 + 3] = dv[r];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) sdvp[(tid * 3 + c) * FB + f] = T[c] * dv[0] + T[3 + c] * dv[1] + T[6 + c] * dv[2];
+        __syncthreads();
+        // phase 2: thread == output element of dA (j,e) or dtrans
+        if (b < B) {
+            float *dst = part + ((size_t)tile * B + b) * PT_N;
+            for (int o = tid; o < 627; o += 256) {
+                float s = 0.f;
+                if (o < 624) {
+                    const int j = o / 12, e = o % 12;
+                    const float *wr = sW + j * WLD;
+#pragma unroll 8
+                    for (int vv = 0; vv < 256; vv++) s += wr[vv] * sdT[vv * 13 + e];
+                } else {
+                    const int e = (o - 624) * 4 + 3;
+#pragma unroll 8
+                    for (int vv = 0; vv < 256; vv++) s += sdT[vv * 13 + e];
+                }
+                dst[o] = s;
+            }
+        }
+        __syncthreads();
+    }
+    // phase 3: thread == pose-map / beta column, reduction over the tile's 768 (vertex, coord) rows
+    for (int k = tid; k < 469; k += 256) {
+        float acc[FB];
+#pragma unroll
+        for (int f = 0; f < FB; f++) acc[f] = 0.f;
+        const int nrow = min(768, V_ * 3 - v0 * 3);
+        if (k < NP_) {
+            const float *src = P_vck + (size_t)v0 * 3 * NP_ + k;
+            for (int r = 0; r < nrow; r++) {
+                const float p = src[(size_t)r * NP_];
+#pragma unroll
+                for (int f = 0; f < FB; f++) acc[f] += p * sdvp[r * FB + f];
+            }
+        } else {
+            const float *src = S_vcl + (size_t)v0 * 3 * NB_ + (k - NP_);
+            for (int r = 0; r < nrow; r++) {
+                const float p = src[(size_t)r * NB_];
+#pragma unroll
+                for (int f = 0; f < FB; f++) acc[f] += p * sdvp[r * FB + f];
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FB; f++) if (b0 + f < B) part[((size_t)tile * B + b0 + f) * PT_N + PT_DPM + k] = acc[f];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, launch 2: per frame -- reduce the 27 tile partials, VJP of A, chain, pose map, rodrigues, joints
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__restrict__ pose, const float *__restrict__ J_s,
+                                                              SmplParents par, const float *__restrict__ ws,
+                                                              const float *__restrict__ part, const float *__restrict__ djtr,
+                                                              int B, float *__restrict__ dpose, float *__restrict__ dbetas,
+                                                              float *__restrict__ dtrans)
+{
+    __shared__ float red[PT_N];
+    __shared__ float sdG[J_ * 12], sdJ[J_ * 3], sdR[J_ * 9];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *w = ws + (size_t)b * WS_FRAME;
+    for (int i = tid; i < PT_N; i += 256) {
+        float s = 0.f;
+        for (int t = 0; t < NVT_; t++) s += part[((size_t)t * B + b) * PT_N + i];
+        red[i] = s;
+    }
+    __syncthreads();
+    if (tid < J_) {
+        const int j = tid;
+        const float *G = w + WS_G + 12 * j; const float *Jr = w + WS_J;
+        float dj[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float dat = red[PT_DA + 12 * j + r * 4 + 3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { sdG[12 * j + r * 4 + c] = red[PT_DA + 12 * j + r * 4 + c] - dat * Jr[3 * j + c]; dj[c] -= G[r * 4 + c] * dat; }
+            sdG[12 * j + r * 4 + 3] = dat + (djtr ? djtr[(b * J_ + j) * 3 + r] : 0.f);
+        }
+        sdJ[3 * j] = dj[0]; sdJ[3 * j + 1] = dj[1]; sdJ[3 * j + 2] = dj[2];
+#pragma unroll
+        for (int e = 0; e < 9; e++) sdR[9 * j + e] = 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float *Jr = w + WS_J;
+        for (int j = J_ - 1; j >= 1; j--) {
+            const int p = par.p[j];
+            const float *Gp = w + WS_G + 12 * p, *Rj = w + WS_R + 9 * j;
+            const float rel[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
+            const float *dGj = sdG + 12 * j; float *dGp = sdG + 12 * p;
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++)
+                    dGp[r * 4 + c] += dGj[r * 4] * Rj[3 * c] + dGj[r * 4 + 1] * Rj[3 * c + 1] + dGj[r * 4 + 2] * Rj[3 * c + 2] + dGj[r * 4 + 3] * rel[c];
+                dGp[r * 4 + 3] += dGj[r * 4 + 3];
+            }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+                sdR[9 * j + 3 * r + c] += Gp[r] * dGj[c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
+            for (int c = 0; c < 3; c++) {
+                const float s = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
+                sdJ[3 * j + c] += s; sdJ[3 * p + c] -= s;
+            }
+        }
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sdR[3 * r + c] += sdG[r * 4 + c]; sdJ[r] += sdG[r * 4 + 3]; }
+    }
+    __syncthreads();
+    if (tid < J_) {
+        const int j = tid;
+        float g[9], t[3] = {pose[(b * J_ + j) * 3], pose[(b * J_ + j) * 3 + 1], pose[(b * J_ + j) * 3 + 2]}, d[3];
+#pragma unroll
+        for (int e = 0; e < 9; e++) g[e] = sdR[9 * j + e] + (j >= 1 ? red[PT_DPM + (j - 1) * 9 + e] : 0.f);
+        rodrigues_bwd(t, g, d);
+        dpose[(b * J_ + j) * 3] = d[0]; dpose[(b * J_ + j) * 3 + 1] = d[1]; dpose[(b * J_ + j) * 3 + 2] = d[2];
+    } else if (tid >= 64 && tid < 64 + NB_) {
+        const int l = tid - 64;
+        float s = red[PT_DB + l];
+        for (int i = 0; i < J_ * 3; i++) s += J_s[i * NB_ + l] * sdJ[i];
+        dbetas[b * NB_ + l] = s;
+    } else if (tid >= 128 && tid < 131) {
+        const int c = tid - 128;
+        float s = red[PT_DTR + c];
+        if (djtr) for (int j = 0; j < J_; j++) s += djtr[(b * J_ + j) * 3 + c];
+        dtrans[b * 3 + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const float *shapedirs, const float *posedirs,
+                               const float *J_regressor, const float *weights, const int *parents, void *stream)
+{
+    VT_REQUIRE(out && v_template && shapedirs && posedirs && J_regressor && weights && parents, "vt_smplh_create: null argument");
+    hipStream_t st = vt_stream(stream);
+    vt_smplh *h = new vt_smplh();
+    for (int j = 0; j < J_; j++) h->par.p[j] = (j == 0) ? 0 : parents[j];
+    for (int j = 1; j < J_; j++) VT_REQUIRE(h->par.p[j] >= 0 && h->par.p[j] < j, "vt_smplh_create: parents[%d]=%d must be in [0,%d)", j, parents[j], j);
+    float *P_kcv = new float[(size_t)NP_ * 3 * VP_](), *S_lcv = new float[(size_t)NB_ * 3 * VP_](), *T_cv = new float[3 * VP_](),
+          *W_jv = new float[(size_t)J_ * VP_](), *J_t = new float[J_ * 3], *J_s = new float[J_ * 3 * NB_];
+    for (int v = 0; v < V_; v++) for (int c = 0; c < 3; c++) {
+        T_cv[c * VP_ + v] = v_template[v * 3 + c];
+        for (int l = 0; l < NB_; l++) S_lcv[(size_t)(l * 3 + c) * VP_ + v] = shapedirs[((size_t)v * 3 + c) * NB_ + l];
+        for (int k = 0; k < NP_; k++) P_kcv[(size_t)(k * 3 + c) * VP_ + v] = posedirs[((size_t)v * 3 + c) * NP_ + k];
+    }
+    for (int v = 0; v < V_; v++) for (int j = 0; j < J_; j++) W_jv[(size_t)j * VP_ + v] = weights[(size_t)v * J_ + j];
+    for (int j = 0; j < J_; j++) for (int c = 0; c < 3; c++) {
+        double a = 0; double s[NB_] = {0};
+        for (int v = 0; v < V_; v++) {
+            const double r = J_regressor[(size_t)j * V_ + v];
+            if (r == 0.0) continue;
+            a += r * v_template[v * 3 + c];
+            for (int l = 0; l < NB_; l++) s[l] += r * shapedirs[((size_t)v * 3 + c) * NB_ + l];
+        }
+        J_t[j * 3 + c] = (float)a;
+        for (int l = 0; l < NB_; l++) J_s[(j * 3 + c) * NB_ + l] = (float)s[l];
+    }
+    int rc = VT_OK;
+    if ((rc = vt_upload(&h->P_kcv, P_kcv, (size_t)NP_ * 3 * VP_, st)) || (rc = vt_upload(&h->P_vck, posedirs, (size_t)V_ * 3 * NP_, st)) ||
+        (rc = vt_upload(&h->S_lcv, S_lcv, (size_t)NB_ * 3 * VP_, st)) || (rc = vt_upload(&h->S_vcl, shapedirs, (size_t)V_ * 3 * NB_, st)) ||
+        (rc = vt_upload(&h->T_cv, T_cv, (size_t)3 * VP_, st)) || (rc = vt_upload(&h->W_jv, W_jv, (size_t)J_ * VP_, st)) ||
+        (rc = vt_upload(&h->J_t, J_t, (size_t)J_ * 3, st)) || (rc = vt_upload(&h->J_s, J_s, (size_t)J_ * 3 * NB_, st))) {
+        return rc;
+    }
+    VT_HIP(hipStreamSynchronize(st));  // host staging buffers are freed below
+    delete[] P_kcv; delete[] S_lcv; delete[] T_cv; delete[] W_jv; delete[] J_t; delete[] J_s;
+    *out = h;
+    return VT_OK;
+}
+
+extern "C" void vt_smplh_destroy(vt_smplh *h)
+{
+    if (!h) return;
+    hipFree(h->P_kcv); hipFree(h->P_vck); hipFree(h->S_lcv); hipFree(h->S_vcl); hipFree(h->T_cv); hipFree(h->W_jv); hipFree(h->J_t); hipFree(h->J_s);
+    delete h;
+}
+
+extern "C" long vt_smplh_workspace_floats(int B) { return (long)B * WS_FRAME; }
+extern "C" long vt_smplh_bwd_scratch_floats(int B) { return (long)NVT_ * B * PT_N; }
+
+#define FWD_FB 8
+#define BWD_FB 4
+
+extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const float *betas, const float *trans, int B,
+                                float *verts, float *jtr, float *v_posed, float *ws, void *stream)
+{
+    VT_REQUIRE(h && pose && betas && trans && verts && v_posed && ws && B > 0, "vt_smplh_forward: null argument or B <= 0");
+    hipStream_t st = vt_stream(stream);
+    hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smplh_verts_kernel<FWD_FB>, dim3(NVT_, (B + FWD_FB - 1) / FWD_FB), dim3(256), 0, st, h->P_kcv, h->S_lcv, h->T_cv,
+                       h->W_jv, betas, trans, ws, B, verts, v_posed);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const float *betas, int B, const float *dverts,
+                                 const float *djtr, const float *v_posed, const float *ws, float *scratch,
+                                 float *dpose, float *dbetas, float *dtrans, void *stream)
+{
+    (void)betas;
+    VT_REQUIRE(h && pose && dverts && v_posed && ws && scratch && dpose && dbetas && dtrans && B > 0, "vt_smplh_backward: null argument or B <= 0");
+    hipStream_t st = vt_stream(stream);
+    const size_t lds = sizeof(float) * (J_ * WLD + 256 * 13 + 768 * BWD_FB + BWD_FB * 624);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_bwd_tile_kernel<BWD_FB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->P_vck, h->S_vcl, h->W_jv, ws,
+                       v_posed, dverts, B, scratch);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, djtr, B, dpose, dbetas, dtrans);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+extern "C" int vt_rodrigues_forward(const float *aa, int n, float *R, void *stream)
+{
+    VT_REQUIRE(aa && R && n > 0, "vt_rodrigues_forward: bad argument");
+    hipLaunchKernelGGL(rodrigues_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, vt_stream(stream), aa, n, R);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+extern "C" int vt_rodrigues_backward(const float *aa, int n, const float *dR, float *daa, void *stream)
+{
+    VT_REQUIRE(aa && dR && daa && n > 0, "vt_rodrigues_backward: bad argument");
+    hipLaunchKernelGGL(rodrigues_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, vt_stream(stream), aa, n, dR, daa);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
