@@ -43,8 +43,8 @@ def test_mfma_operand_layout():
     from vistracker_amd import _lib as L
     rng = np.random.default_rng(0)
     A = rng.normal(size=(16, 4)).astype(np.float32); Bm = rng.normal(size=(4, 16)).astype(np.float32)
-    out = torch.zeros(16, 16, device="cuda")
-    L.check(L.lib().vt_selftest_mfma(L.dptr(cu(A)), L.dptr(cu(Bm)), L.dptr(out), L.stream_ptr()))
+    out = torch.zeros(16, 16, device="cuda"); At, Bt = cu(A), cu(Bm)   # keep the temporaries alive across the launch
+    L.check(L.lib().vt_selftest_mfma(L.dptr(At), L.dptr(Bt), L.dptr(out), L.stream_ptr()))
     assert np.abs(npy(out) - A @ Bm).max() < 1e-5
 
 
@@ -171,14 +171,15 @@ def test_query_fused_objectives_vs_oracle(hip, synth):
 
     maps = hip["ops"].FeatureMaps.from_nchw(mp)
     terms = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, N, 3, device="cuda")
-    L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(cu(pts)), L.dptr(cu(cc)), L.dptr(cu(bc)), B, N,
-                                        L.dptr(cu(labels)), w_dfh, w_part, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+    pts_t, cc_t, bc_t, lab_t, occ_t = cu(pts), cu(cc), cu(bc), cu(labels), cu(occ)
+    L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,
+                                        L.dptr(lab_t), w_dfh, w_part, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
     t = npy(terms)
     assert abs(t[0] - t_dfh) < 1e-5 * abs(t_dfh) + 1e-7 and abs(t[1] - t_part) < 1e-4 * abs(t_part)
     assert rel(npy(dp), dpts_h) < 3e-4
     terms.zero_()
-    L.check(L.lib().vt_query_object_loss(hip["net"].h, C.byref(maps.c), L.dptr(cu(pts)), L.dptr(cu(cc)), L.dptr(cu(bc)), B, N,
-                                         L.dptr(cu(occ)), w_obj, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+    L.check(L.lib().vt_query_object_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,
+                                         L.dptr(occ_t), w_obj, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
     assert abs(npy(terms)[0] - t_obj) < 1e-5 * abs(t_obj) + 1e-7
     assert rel(npy(dp), dpts_o) < 3e-4
 
@@ -286,13 +287,14 @@ def test_kpts_and_sqdiff(hip):
         ref = e.sum() / (B * K * 2) if mode == 0 else e.mean()
         (ref * 0.7).backward()
         term = torch.zeros(1, dtype=torch.float64, device="cuda"); dJ = torch.empty(B, K, 3, device="cuda")
-        L.check(L.lib().vt_kpts_loss(L.dptr(cu(J)), L.dptr(cu(k2)), L.dptr(cu(cc)), B, K, mode, cam.ctypes.data, 512.0, 0.7,
+        J_t, k2_t, cc_t = cu(J), cu(k2), cu(cc)
+        L.check(L.lib().vt_kpts_loss(L.dptr(J_t), L.dptr(k2_t), L.dptr(cc_t), B, K, mode, cam.ctypes.data, 512.0, 0.7,
                                      L.dptr(term), L.dptr(dJ), L.stream_ptr()))
         assert abs(term.item() - ref.item()) < 1e-5 * abs(ref.item())
         assert rel(npy(dJ), Jt.grad.numpy()) < 1e-4
     a = rng.normal(0, 1, (B, 156)).astype(np.float32); b = rng.normal(0, 1, (B, 69)).astype(np.float32)
-    term = torch.zeros(1, dtype=torch.float64, device="cuda"); at = cu(a); da = torch.zeros_like(at)
-    L.check(L.lib().vt_sqdiff_loss(at[:, 3:].data_ptr(), 156, L.dptr(cu(b)), 69, B, 69, float(B), 2.0, L.dptr(term), da[:, 3:].data_ptr(), L.stream_ptr()))
+    term = torch.zeros(1, dtype=torch.float64, device="cuda"); at = cu(a); da = torch.zeros_like(at); bt = cu(b)
+    L.check(L.lib().vt_sqdiff_loss(at[:, 3:].data_ptr(), 156, L.dptr(bt), 69, B, 69, float(B), 2.0, L.dptr(term), da[:, 3:].data_ptr(), L.stream_ptr()))
     d = a[:, 3:72].astype(np.float64) - b
     assert abs(term.item() - (d ** 2).sum() / B) < 1e-5 * (d ** 2).sum() / B
     assert rel(npy(da)[:, 3:72], 2 * d / B * 2.0) < 1e-5 and np.abs(npy(da)[:, 72:]).max() == 0
