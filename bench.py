@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of the VisTracker SMPL-H + object fit (recon_fit_trivis_full: optimize_smpl + optimize_smpl_object)
+on MI355X.
+
+A "step" is one pass of the hot path over one batch of B=96 consecutive frames of a synthetic 1500-frame sequence
+(reference batch size, recon/recon_fit_triplane.py:257): the full SMPL stage and the full object stage with the
+reference's schedules, loss weights and early-stop rules.  Feature maps (71.3 MB/frame fp32) are
+resident in HBM when the timed region starts.  With N GPUs every rank fits its own K batches (batch-aligned frame
+sharding, no collective inside the fit; one all_gather of the fitted parameters at the end) -> weak scaling; `value` is
+the whole-job frames/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 96
+N_OBJ = 3000
+# algorithmic FLOPs per query point: SURVEY.md 8(d) -- 1.117 MFLOP/pt forward for the 5 decoders = 0.2234 MFLOP per head;
+# the SMPL-stage kernel needs 2 heads (df, parts), forward + backward-to-coordinates: 2 heads x 2 directions
+FLOP_PER_POINT_HUMAN = 4 * ((611 * 128 + 2 * 128 * 128 + 128 * 2) + (611 * 128 + 2 * 128 * 128 + 128 * 14))
+FLOP_PER_POINT_OBJECT = 4 * (611 * 128 + 2 * 128 * 128 + 128 * 2)
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0):
+    """Synthetic inputs of one 96-frame batch, all on the device."""
+    import torch.nn.functional as F
+    from vistracker_amd import ops
+    from vistracker_amd.fitting import SilSetup
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    B = BATCH
+    seq = syn.sequence_params(B, seed=seed, grab_hand_mean=np.concatenate([ctx.pri_np["lhand_mean"], ctx.pri_np["rhand_mean"]]))
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    gt_pose, gt_betas, gt_trans = t(seq["pose"]), t(seq["betas"]), t(seq["trans"])
+    cc = t(np.tile([[1018.952, 779.486]], (B, 1)) + rng.normal(0, 20, (B, 2)))
+    # keypoints: crop-space projection of the GT body25 + 1 px noise (recon_fit_base.py:781-802)
+    with torch.no_grad():
+        verts, _, _ = ops.smplh_forward(ctx.smpl, gt_pose, gt_betas, gt_trans)
+        J = ops.landmarks(ctx.b25, verts)
+    cam = ctx.cam
+    px = (cam[4] / 2 + cam[0] * J[..., 0] / J[..., 2] + cam[2] - cc[:, :1]) * (512.0 / cam[4])
+    py = (cam[4] / 2 + cam[1] * J[..., 1] / J[..., 2] + cam[3] - cc[:, 1:]) * (512.0 / cam[4])
+    kp = torch.stack([px + torch.randn(B, 25, device=dev, generator=g), py + torch.randn(B, 25, device=dev, generator=g),
+                      torch.rand(B, 25, device=dev, generator=g) * 0.7 + 0.3], -1).contiguous()
+    pose = gt_pose.clone(); pose[:, :66] += 0.06 * torch.randn(B, 66, device=dev, generator=g)
+    trans = gt_trans + 0.04 * torch.randn(B, 3, device=dev, generator=g)
+    betas = gt_betas.clone()
+    body_center = trans.clone()
+    # feature maps: smooth random fields of the true shapes, channel-last
+    maps = {}
+    for name, c, res, _ in syn.MAP_SPECS:
+        r = max(4, int(round(res * res_scale)))
+        lo = torch.randn(B, c, max(2, r // 8), max(2, r // 8), device=dev, generator=g)
+        maps[name] = F.interpolate(lo, size=(r, r), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    fm = ops.FeatureMaps(maps)
+    # object: GT pose + perturbation; silhouette reference rendered from the GT pose, random person occluder
+    obj_R_gt, obj_t_gt = t(seq["obj_R"]), t(seq["obj_t"])
+    obj_R = (obj_R_gt + 0.03 * torch.randn(B, 3, 3, device=dev, generator=g)).contiguous()
+    obj_t = (obj_t_gt + 0.05 * torch.randn(B, 3, device=dev, generator=g)).contiguous()
+    obj_s = torch.ones(B, device=dev)
+    occ = t(seq["occ_ratios"])
+    u0 = cam[0] * obj_t_gt[:, 0] / obj_t_gt[:, 2] + cam[2]; v0 = cam[1] * obj_t_gt[:, 1] / obj_t_gt[:, 2] + cam[3]
+    bb = 1.3 * cam[0] * 1.0 / obj_t_gt[:, 2]
+    K = torch.zeros(B, 9, device=dev)
+    K[:, 0] = cam[0] / bb; K[:, 2] = (cam[2] - (u0 - bb / 2)) / bb; K[:, 4] = cam[1] / bb; K[:, 5] = (cam[3] - (v0 - bb / 2)) / bb; K[:, 8] = 1
+    with torch.no_grad():
+        Vgt = ops.rigid_transform(ctx.obj_verts, ops.so3_project(obj_R_gt), obj_t_gt, obj_s)
+        ref = ops.silhouette(Vgt, ctx.obj_faces, K, 256)
+    keep = torch.ones_like(ref); keep[:, 96:160, :80] = 0
+    ref = ref * keep
+    return dict(pose=pose, betas=betas, trans=trans, cc=cc, bc=body_center, kp=kp, maps=fm, obj_R=obj_R, obj_t=obj_t, obj_s=obj_s,
+                occ=occ, sil=SilSetup(K, keep, ref, 256))
+
+
+def fit_batch(ctx, torch, d, prof=None):
+    """The hot path over one batch: SMPL stage then object stage (recon/recon_fit_triplane.py:70-106)."""
+    from vistracker_amd import ops
+    r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof)
+    with torch.no_grad():
+        verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
+    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof)
+    return r1, r2
+
+
+def cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, oracle/) timed on this box's host cores on a bounded sample:
+    Bc frames, a few Adam steps per stage at full V=6890 / N=3000 / full-resolution maps; scaled by the step counts the
+    GPU run executed."""
+    from oracle import oracle as O
+    Bc = 4
+    rng = np.random.default_rng(0)
+    seq = syn.sequence_params(Bc, seed=3, grab_hand_mean=np.concatenate([pri["lhand_mean"], pri["rhand_mean"]]))
+    maps = syn.feature_maps(Bc, 5, res_scale=1.0, smooth=8)
+    net = O.SifNet(dec, maps); m = O.SmplModel(model); b25 = O.Landmarks(regs["body25"])
+    pose, betas, trans = seq["pose"].copy(), seq["betas"].copy(), seq["trans"].copy()
+    cc = np.tile(np.array([[1018.952, 779.486]], np.float32), (Bc, 1)); bc = trans.copy()
+    kp = np.concatenate([rng.uniform(100, 400, (Bc, 25, 2)), rng.uniform(0.3, 1, (Bc, 25, 1))], -1).astype(np.float32)
+    pose_init = pose[:, 3:72].copy()
+    opt = O.Adam([trans, pose, betas], 0.006)
+    t0 = time.time(); n1 = 0
+    while True:
+        _, _, dp, db, dt = O.smplfit_loss_and_grad(m, b25, pri, net, labels, pose, betas, trans, cc, bc, kp, pose_init, "kpts", 1.0)
+        opt.step([dt, dp, db]); n1 += 1
+        if time.time() - t0 > budget_s / 2 or n1 >= 20:
+            break
+    t_smpl = (time.time() - t0) / n1
+    ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, N_OBJ, seed=6)
+    R, tt = seq["obj_R"].copy(), seq["obj_t"].copy(); sc = np.ones(Bc, np.float32)
+    opt = O.Adam([R, tt], [0.002, 0.006])
+    t0 = time.time(); n2 = 0
+    while True:
+        _, _, dM, dtt = O.objfit_loss_and_grad(net, opts, R, tt, sc, rng.uniform(0, 1, (Bc, 3, 3)).astype(np.float32), cc, bc,
+                                               seq["occ_ratios"], trans.copy(), "object only", 1.0)
+        opt.step([dM, dtt]); n2 += 1
+        if time.time() - t0 > budget_s / 2 or n2 >= 40:
+            break
+    t_obj = (time.time() - t0) / n2
+    per_frame = (t_smpl * smpl_steps + t_obj * obj_steps) / Bc
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"oracle (oracle/vt_oracle.c, OpenMP) on {Bc} frames: {n1} SMPL-stage steps ({t_smpl:.3f} s/step, V=6890 query) + {n2} "
+                      f"object-stage steps ({t_obj:.3f} s/step, N={N_OBJ}); scaled to the {smpl_steps}+{obj_steps} Adam steps/batch the GPU run executed"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vistracker_amd import synthetic as syn
+    from vistracker_amd.fitting import FitContext
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    model = syn.smplh_model(0); regs = syn.landmark_regressors(model, 1); pri = syn.priors(2); dec = syn.sifnet_decoders(3)
+    labels = syn.part_labels(model); ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, N_OBJ, seed=6)
+    ctx = FitContext(model, regs, pri, dec, labels, ov, of, opts, device=dev)
+    ctx.pri_np = pri
+
+    def run(idx, prof=None):
+        d = make_batch(ctx, syn, torch, seed=1000 * rank + idx, dev=dev, res_scale=args.res_scale)
+        torch.cuda.synchronize()
+        return d
+
+    for wi in range(args.warmup):
+        d = run(100 + wi); fit_batch(ctx, torch, d); del d
+    batches = [run(i) for i in range(args.steps)]          # inputs resident in HBM before the timed region
+    prof = {"human": [], "object": []}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    results = [fit_batch(ctx, torch, d, prof) for d in batches]
+    if world > 1:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch)
+        packed = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(BATCH, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches])
+        out = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(out, packed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+
+    if rank == 0:
+        frames = world * args.steps * BATCH
+        smpl_steps = float(np.mean([r[0].steps for r in results])); obj_steps = float(np.mean([r[1].steps for r in results]))
+        th = np.array([a.elapsed_time(b) for a, b in prof["human"]]) * 1e-3 if prof["human"] else np.zeros(1)
+        to = np.array([a.elapsed_time(b) for a, b in prof["object"]]) * 1e-3 if prof["object"] else np.zeros(1)
+        flops_h = FLOP_PER_POINT_HUMAN * BATCH * 6890
+        ach = flops_h / th.mean() / 1e12 if th.mean() > 0 else 0.0
+        line = {
+            "metric": "frames/sec joint SMPL+object fit", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "recon_fit_trivis_full joint opt (optimize_smpl + optimize_smpl_object), batches of 96 frames of a synthetic "
+                                   "1500-frame sequence, SMPL-H V=6890 + 1 rigid object (2500 faces, 3000 surface points), feature maps resident "
+                                   f"(res_scale={args.res_scale})",
+                       "batch_frames": BATCH, "adam_steps_smpl_stage": smpl_steps, "adam_steps_object_stage": obj_steps,
+                       "early_stop": "reference rule, evaluated on device", "sharding": f"{world} ranks x {args.steps} batches, no collective in the fit"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
+                         "avg_launch_ms": 1e3 * float(th.mean()), "launches": int(len(th)), "flop_per_launch": flops_h,
+                         "object_kernel_avg_ms": 1e3 * float(to.mean()),
+                         "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

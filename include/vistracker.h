@@ -167,6 +167,9 @@ int vt_rigid_backward(const float *X0, int shared_x0, const float *s, int B, int
  * v (B,D).  *term (device scalar) += value;  dv (B,D) += gscale * gradient (dv may be NULL).
  * ------------------------------------------------------------------------------------------------- */
 int vt_accel_loss(const float *v, int B, int D, const float *elem_w, float gscale, double *term, float *dv, void *stream);
+/* same on the first D columns of a row-strided matrix (v, dv have `stride` floats per frame): pose accelerations */
+int vt_accel_loss_strided(const float *v, int B, int D, int stride, const float *elem_w, float gscale, double *term,
+                          float *dv, void *stream);
 int vt_velocity_loss(const float *v, int B, int D, float gscale, double *term, float *dv, void *stream);
 
 /* 2D keypoint terms.  mode 0: BaseFitter.compute_loss 'kpts' (preprocess/fit_SMPLH_kpts.py:280-310):
@@ -215,6 +218,11 @@ int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, co
  * ------------------------------------------------------------------------------------------------- */
 int vt_adam_step(float *p, const float *g, float *m, float *v, long n, int step, float lr, float beta1, float beta2,
                  float eps, const int *stop_flag, void *stream);
+
+/* the same update on the first `cols` columns of row-strided p/g (m, v are (rows, cols) contiguous): lets one pose
+ * tensor (B,156) be optimised on its [0:66) slice, i.e. global_pose + body_pose of SMPLPyTorchWrapperBatchSplitParams */
+int vt_adam_step_2d(float *p, long p_stride, const float *g, long g_stride, float *m, float *v, int rows, int cols,
+                    int step, float lr, float beta1, float beta2, float eps, const int *stop_flag, void *stream);
 
 /* Early-stop rule of the fit loops evaluated on the device (recon_fit_behave.py:447-455,
  * recon_fit_trivis_full.py:372-373, fit_SMPLH_kpts.py:161):

@@ -55,6 +55,7 @@ SIGNATURES = {
     "vt_rigid_forward": (ci, [fp, ci, fp, fp, fp, ci, ci, fp, vp]),
     "vt_rigid_backward": (ci, [fp, ci, fp, ci, ci, fp, fp, fp, ci, vp]),
     "vt_accel_loss": (ci, [fp, ci, ci, fp, cf, fp, fp, vp]),
+    "vt_accel_loss_strided": (ci, [fp, ci, ci, ci, fp, cf, fp, fp, vp]),
     "vt_velocity_loss": (ci, [fp, ci, ci, cf, fp, fp, vp]),
     "vt_kpts_loss": (ci, [fp, fp, fp, ci, ci, ci, vp, cf, cf, fp, fp, vp]),
     "vt_sqdiff_loss": (ci, [fp, ci, fp, ci, ci, ci, cf, cf, fp, fp, vp]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "vt_sil_backward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, cf, fp, fp, vp]),
     "vt_sil_mask_loss": (ci, [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp]),
     "vt_adam_step": (ci, [fp, fp, fp, fp, cl, ci, cf, cf, cf, cf, fp, vp]),
+    "vt_adam_step_2d": (ci, [fp, cl, fp, cl, fp, fp, ci, ci, ci, cf, cf, cf, cf, fp, vp]),
     "vt_loss_reduce_and_stop": (ci, [fp, vp, ci, cf, ci, fp, fp, fp, ci, vp]),
     "vt_fill": (ci, [fp, cl, cf, vp]),
     "vt_selftest_mfma": (ci, [fp, fp, fp, vp]),

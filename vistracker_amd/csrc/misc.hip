@@ -359,13 +359,14 @@ extern "C" int vt_rigid_backward(const float *X0, int shared_x0, const float *s,
 // temporal stencils: thread == one column of v (B,D), walks the frames with a sliding window so that every
 // gradient element is written exactly once (no atomics):  a_b = 2 v_b - v_{b-1} - v_{b+1}
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict__ v, int B, int D, const float *__restrict__ elem_w,
+__global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict__ v, int B, int Dcols, int D, const float *__restrict__ elem_w,
                                                          float gs, double *term, float *__restrict__ dv)
 {
+    // D = row stride (floats per frame), Dcols = columns that take part
     __shared__ double red[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (i < D) {
+    if (i < Dcols) {
         const float w = elem_w ? elem_w[i] : 1.f;
         float vm = v[i], v0 = v[(size_t)D + i], vp = v[(size_t)2 * D + i];
         float a_prev = 0.f, a_cur = 2.f * v0 - vm - vp, a_next;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict
             a_prev = a_cur; a_cur = a_next; vm = v0; v0 = vp; vp = vpp;
         }
     }
-    term_add(acc / ((double)(B - 2) * D), term, red);
+    term_add(acc / ((double)(B - 2) * Dcols), term, red);
 }
 
 __global__ __launch_bounds__(256) void velocity_loss_kernel(const float *__restrict__ v, int B, int D, float gs, double *term, float *__restrict__ dv)
@@ -408,7 +409,15 @@ extern "C" int vt_accel_loss(const float *v, int B, int D, const float *elem_w, 
     VT_REQUIRE(v && B >= 3 && D > 0, "vt_accel_loss: needs B >= 3 (the reference returns NaN for empty stencils)");
     // d/dv of mean(w a^2): 2 w a / cnt per stencil element; a's own coefficient 2 is folded in the kernel
     const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
-    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, elem_w, gs, term, dv);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, D, elem_w, gs, term, dv);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_accel_loss_strided(const float *v, int B, int D, int stride, const float *elem_w, float gscale, double *term, float *dv, void *stream)
+{
+    VT_REQUIRE(v && B >= 3 && D > 0 && stride >= D, "vt_accel_loss_strided: needs B >= 3 and stride >= D");
+    const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, stride, elem_w, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -507,6 +516,31 @@ extern "C" int vt_adam_step(float *p, const float *g, float *m, float *v, long n
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, vt_stream(stream), p, g, m, v, n, (float)(lr / bc1),
                        (float)sqrt(bc2), beta1, beta2, eps, stop_flag);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+__global__ void adam2d_kernel(float *p, long ps, const float *g, long gs, float *m, float *v, int rows, int cols, float step_size, float bc2s,
+                              float beta1, float beta2, float eps, const int *stop_flag)
+{
+    if (stop_flag && *stop_flag) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i / cols, c = i % cols;
+    const float gi = g[(size_t)r * gs + c];
+    const float mi = m[i] * beta1 + (1.f - beta1) * gi;
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[(size_t)r * ps + c] = p[(size_t)r * ps + c] - step_size * (mi / denom);
+}
+extern "C" int vt_adam_step_2d(float *p, long p_stride, const float *g, long g_stride, float *m, float *v, int rows, int cols, int step, float lr,
+                               float beta1, float beta2, float eps, const int *stop_flag, void *stream)
+{
+    VT_REQUIRE(p && g && m && v && rows > 0 && cols > 0 && step >= 1 && p_stride >= cols && g_stride >= cols, "vt_adam_step_2d: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam2d_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, vt_stream(stream), p, p_stride, g, g_stride, m, v, rows, cols,
+                       (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, stop_flag);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

@@ -1,0 +1,395 @@
+"""Fused fit loops of the hot path: every Adam step is a fixed sequence of C-ABI launches on the current HIP stream --
+no autograd tape, no host synchronisation inside the 10-step inner loop, early stop decided on the device.
+
+Mirrors, with the reference's schedules / weights / stop rules:
+  * ``ReconFitterBehave.optimize_smpl`` + ``forward_smpl``        (recon/recon_fit_behave.py:393-513)
+  * ``ReconFitterTriVisFull.optimize_smpl_object`` + ``forward_step`` (recon/recon_fit_trivis_full.py:193-377)
+  * ``BaseFitter.fit_one_batch`` + ``SMPLHFitter30fps.compute_loss``   (preprocess/fit_SMPLH_kpts.py:114-180,
+    preprocess/fit_SMPLH_30fps.py:153-200)
+Work the reference does but whose result is never used is skipped: the SMPL forward of the frozen body in
+the object stage, the unused decoder heads, the object query in phase 'sil', the weight-0 'ocent' term, the constant hand
+prior gradient.  Loss VALUES keep every term the reference sums (the early-stop rule depends on them).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+# c * cst / (1 + decay) -- ReconFitterTriVisFull.get_loss_weights (recon_fit_trivis_full.py:124-153)
+FIT_WEIGHTS = {"pose": 1e-5, "hand": 1e-5, "j2d": 0.09, "object": 900.0, "part": 0.0025, "contact": 900.0, "scale": 100.0,
+               "df_h": 100.0, "mask": 0.0009, "ocent": 0.0, "pinit": 25.0, "rot": 100.0, "trans": 100.0,
+               "stemp": 10000.0, "otemp": 225.0, "ovtemp": 2500.0}
+# SMPLHFitter30fps.get_loss_weights (fit_SMPLH_30fps.py:55-66); BaseFitter uses pinit 100 (fit_SMPLH_kpts.py:57-65)
+SMPLT_WEIGHTS = {"pose": 1e-5, "hand": 1e-5, "kpts": 0.09, "temp": 900.0, "ptemp": 25.0, "pinit": 900.0}
+# joint_weights of compute_Jaccel_loss (fit_SMPLH_30fps.py:26-51)
+JOINT_WEIGHTS_66 = np.repeat(np.array([1, 10, 10, 10, 5, 5, 10, 1, 1, 10, 1, 1, 5, 5, 5, 5, 5, 5, 1, 1, 1, 1], np.float32), 3)
+JOINT_WEIGHTS_66[37:39] = 10.0
+
+
+def _lib():
+    return L.lib()
+
+
+def _chk(rc):
+    L.check(rc)
+
+
+def _ev_begin(prof):
+    """HIP event before a kernel of interest (bench.py roofline); launches go to torch's current stream, so torch events see them."""
+    if prof is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True); e.record()
+    return e
+
+
+def _ev_end(prof, key, e0):
+    if prof is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+    prof[key].append((e0, e1))
+
+
+class Terms:
+    """fp64 loss-term accumulators on the device, addressed by name."""
+
+    def __init__(self, names, device):
+        self.names = list(names)
+        self.buf = torch.zeros(len(self.names), dtype=torch.float64, device=device)
+        self.idx = {n: i for i, n in enumerate(self.names)}
+
+    def ptr(self, name):
+        return self.buf.data_ptr() + 8 * self.idx[name]
+
+    def zero(self, first=0, count=None):
+        count = len(self.names) - first if count is None else count
+        _chk(_lib().vt_fill_f64(self.buf.data_ptr() + 8 * first, count, 0.0, L.stream_ptr()))
+
+    def weights(self, table, decay, extra=None):
+        w = np.zeros(16, np.float32)
+        for n, i in self.idx.items():
+            w[i] = table[n] / (1.0 + decay) * (1.0 if extra is None else extra.get(n, 1.0))
+        return w
+
+
+class AdamState:
+    """torch.optim.Adam over column slices of parameter tensors (one launch per slice)."""
+
+    def __init__(self, slices, stop_flag):
+        # slices: list of (tensor (B, C) contiguous, ncols, grad tensor (B, Cg) contiguous, lr)
+        self.slices = slices
+        self.m = [torch.zeros(p.shape[0], n, device=p.device) for p, n, g, lr in slices]
+        self.v = [torch.zeros(p.shape[0], n, device=p.device) for p, n, g, lr in slices]
+        self.t = 0
+        self.stop_flag = stop_flag
+
+    def step(self):
+        self.t += 1
+        for (p, n, g, lr), m, v in zip(self.slices, self.m, self.v):
+            _chk(_lib().vt_adam_step_2d(p.data_ptr(), p.shape[1], g.data_ptr(), g.shape[1], m.data_ptr(), v.data_ptr(), p.shape[0], n,
+                                        self.t, lr, 0.9, 0.999, 1e-8, self.stop_flag.data_ptr(), L.stream_ptr()))
+
+
+@dataclass
+class FitResult:
+    steps: int = 0
+    outer_iters: int = 0
+    stopped_early: bool = False
+    losses: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+
+
+class FitContext:
+    """Device-resident constants shared by all batches of a sequence: SMPL-H model, body25 regressor, priors,
+    SIF-Net decoders, part labels, object template / surface samples."""
+
+    def __init__(self, smpl_model, regressors, priors, decoders, part_labels, obj_verts, obj_faces, obj_points,
+                 cam=ops.DEFAULT_CAM, device="cuda:0"):
+        self.device = torch.device(device)
+        dev = self.device
+        self.smpl = ops.SmplhHandle(smpl_model, dev)
+        self.b25 = ops.LandmarkHandle(regressors["body25"], dev)
+        self.net = ops.SifNetHandle(decoders, cam, dev)
+        self.cam = np.ascontiguousarray(cam, np.float32)
+        t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        self.pri = {k: t(v) for k, v in priors.items()}
+        self.labels = t(part_labels, torch.int32)
+        self.obj_verts = t(obj_verts); self.obj_faces = t(obj_faces, torch.int32); self.obj_points = t(obj_points)
+        self.jw66 = t(JOINT_WEIGHTS_66)
+
+    # ---- shared pieces ----------------------------------------------------------------------------------
+    def smpl_forward(self, pose, betas, trans, verts, jtr, vposed, ws):
+        _chk(_lib().vt_smplh_forward(self.smpl.h, pose.data_ptr(), betas.data_ptr(), trans.data_ptr(), pose.shape[0], verts.data_ptr(),
+                                     jtr.data_ptr(), vposed.data_ptr(), ws.data_ptr(), L.stream_ptr()))
+
+    def smpl_backward(self, pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans):
+        _chk(_lib().vt_smplh_backward(self.smpl.h, pose.data_ptr(), betas.data_ptr(), pose.shape[0], dverts.data_ptr(), None, vposed.data_ptr(),
+                                      ws.data_ptr(), scratch.data_ptr(), dpose.data_ptr(), dbetas.data_ptr(), dtrans.data_ptr(), L.stream_ptr()))
+
+    def hand_prior_value(self, pose, terms, name, scratch_b):
+        """HandPrior value (constant: hand pose is never optimised).  Quirk kept: sum over frames and hands / 45
+        (th_hand_prior.py:57-72 broadcasts to (1,2B,45) and torch.mean divides by 45)."""
+        B = pose.shape[0]
+        for off, m, p in ((66, "lhand_mean", "lhand_prec"), (111, "rhand_mean", "rhand_prec")):
+            _chk(_lib().vt_mahalanobis(pose.data_ptr(), B, 156, off, 45, self.pri[m].data_ptr(), self.pri[p].data_ptr(), scratch_b.data_ptr(), None, 0.0, L.stream_ptr()))
+            _chk(_lib().vt_sum_to_term(scratch_b.data_ptr(), B, 1.0 / 45.0, terms.ptr(name), L.stream_ptr()))
+
+    def body_prior(self, pose, dpose, w, terms, name, scratch_b):
+        B = pose.shape[0]
+        _chk(_lib().vt_mahalanobis(pose.data_ptr(), B, 156, 3, 63, self.pri["body_mean"].data_ptr(), self.pri["body_prec"].data_ptr(),
+                                   scratch_b.data_ptr(), dpose.data_ptr(), w / B, L.stream_ptr()))
+        _chk(_lib().vt_sum_to_term(scratch_b.data_ptr(), B, 1.0 / B, terms.ptr(name), L.stream_ptr()))
+
+    # ---- SMPL-T pre-fit (fit_SMPLH_kpts.py:114-180) ------------------------------------------------------
+    def fit_smplt(self, pose, betas, trans, kpts, max_iter=100, iter_for_global=8, temporal=True, pinit_w=900.0,
+                  lr_global=0.01, lr_all=0.001, it_range=None, check_every=1):
+        """In-place Adam fit of pose (B,156), betas (B,10), trans (B,3) to 2D keypoints kpts (B,25,3).
+        ``it_range`` = (start, end) restricts the outer iterations (used by the trajectory parity tests)."""
+        dev = pose.device; B = pose.shape[0]
+        names = ["kpts", "temp", "ptemp", "pose", "pinit", "hand"]
+        terms = Terms(names, dev)
+        table = dict(SMPLT_WEIGHTS); table["pinit"] = pinit_w
+        verts = torch.empty(B, 6890, 3, device=dev); jtr = torch.empty(B, 52, 3, device=dev); vposed = torch.empty_like(verts)
+        ws = torch.empty(_lib().vt_smplh_workspace_floats(B), device=dev); scratch = torch.empty(_lib().vt_smplh_bwd_scratch_floats(B), device=dev)
+        dverts = torch.empty_like(verts); J = torch.empty(B, 25, 3, device=dev); dJ = torch.empty_like(J)
+        dpose = torch.empty(B, 156, device=dev); dbetas = torch.empty(B, 10, device=dev); dtrans = torch.empty(B, 3, device=dev)
+        vb = torch.empty(B, device=dev)
+        pose_init = pose.clone()
+        stop = torch.zeros(1, dtype=torch.int32, device=dev); state = torch.zeros(2, device=dev)   # prev_loss = 0 (fit_SMPLH_kpts.py:136)
+        self.hand_prior_value(pose, terms, "hand", vb)
+        start, end = it_range if it_range is not None else (0, max_iter)
+        hist = torch.full(((end - start) * 10,), float("nan"), device=dev)
+        temporal = temporal and B >= 3
+        adam = None
+        res = FitResult()
+        for it in range(start, end):
+            if adam is None or it == iter_for_global:
+                if it < iter_for_global:      # init_globalpose_optimizer: trans, global_pose, top_betas
+                    adam = AdamState([(trans, 3, dtrans, lr_global), (pose, 3, dpose, lr_global), (betas, 2, dbetas, lr_global)], stop)
+                else:                         # init_allpose_optimizer: trans, global, body, top_betas, other_betas
+                    adam = AdamState([(trans, 3, dtrans, lr_all), (pose, 66, dpose, lr_all), (betas, 10, dbetas, lr_all)], stop)
+            decay = it // 3
+            w = terms.weights(table, decay)
+            for i in range(10):
+                terms.zero(0, 5)
+                self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+                _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
+                _chk(_lib().vt_kpts_loss(J.data_ptr(), kpts.data_ptr(), None, B, 25, 0, self.cam.ctypes.data, 0.0, float(w[0]), terms.ptr("kpts"), dJ.data_ptr(), L.stream_ptr()))
+                _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 0, L.stream_ptr()))
+                if temporal:
+                    _chk(_lib().vt_accel_loss(verts.data_ptr(), B, 6890 * 3, None, float(w[1]), terms.ptr("temp"), dverts.data_ptr(), L.stream_ptr()))
+                self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                if temporal:
+                    _chk(_lib().vt_accel_loss_strided(pose.data_ptr(), B, 66, 156, self.jw66.data_ptr(), float(w[2]), terms.ptr("ptemp"), dpose.data_ptr(), L.stream_ptr()))
+                self.body_prior(pose, dpose, float(w[3]), terms, "pose", vb)
+                _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 63, float(B * 63), float(w[4]),
+                                           terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
+                adam.step()
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(it > 0.3 * max_iter), state.data_ptr(),
+                                                    stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
+                res.steps += 1
+            res.outer_iters += 1
+            if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                res.stopped_early = True
+                break
+        res.losses = hist.cpu().numpy()
+        if res.stopped_early:
+            res.steps = int(np.isfinite(res.losses).sum())
+        return res
+
+    # ---- fit, SMPL stage (recon_fit_behave.py:393-513) ----------------------------------------------------
+    def optimize_smpl(self, maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter=100, iter_for_betas=1,
+                      iter_for_pose=1, iter_for_kpts=1, it_range=None, net_size=512.0, check_every=1, prof=None):
+        dev = pose.device; B = pose.shape[0]; V = 6890
+        names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
+        terms = Terms(names, dev)
+        verts = torch.empty(B, V, 3, device=dev); jtr = torch.empty(B, 52, 3, device=dev); vposed = torch.empty_like(verts)
+        ws = torch.empty(_lib().vt_smplh_workspace_floats(B), device=dev); scratch = torch.empty(_lib().vt_smplh_bwd_scratch_floats(B), device=dev)
+        dverts = torch.empty_like(verts); J = torch.empty(B, 25, 3, device=dev); dJ = torch.empty_like(J)
+        dpose = torch.empty(B, 156, device=dev); dbetas = torch.empty(B, 10, device=dev); dtrans = torch.empty(B, 3, device=dev)
+        vb = torch.empty(B, device=dev)
+        pose_init = pose.clone()
+        stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        state = torch.tensor([300.0, 300.0], device=dev)          # prev_loss = 300 (recon_fit_behave.py:408)
+        self.hand_prior_value(pose, terms, "hand", vb)
+        total = iter_for_betas + iter_for_kpts + iter_for_pose + max_iter
+        start, end = it_range if it_range is not None else (0, total)
+        hist = torch.full(((end - start) * 10,), float("nan"), device=dev)
+        arm_after = 0.25 * max_iter + iter_for_betas + iter_for_pose
+        adam = None; res = FitResult()
+        for it in range(start, end):
+            if it < iter_for_betas:
+                phase = "global"
+                if adam is None:
+                    adam = AdamState([(betas, 2, dbetas, 0.02), (trans, 3, dtrans, 0.02)], stop)
+            else:
+                phase = "kpts" if it >= iter_for_betas + iter_for_pose else "smpl all pose"
+                if adam is None or it == iter_for_betas:
+                    adam = AdamState([(trans, 3, dtrans, 0.006), (pose, 66, dpose, 0.006), (betas, 10, dbetas, 0.006)], stop)
+            decay = 1 if phase != "kpts" else it / 3
+            w = terms.weights(FIT_WEIGHTS, decay)
+            for i in range(10):
+                terms.zero(0, 6)
+                self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+                ev = _ev_begin(prof)
+                _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
+                                                self.labels.data_ptr(), float(w[0]), float(w[1]), dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
+                _ev_end(prof, "human", ev)
+                if phase == "kpts":
+                    _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
+                                             float(w[4]), terms.ptr("j2d"), dJ.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 1, L.stream_ptr()))
+                if B >= 4:
+                    _chk(_lib().vt_accel_loss(verts.data_ptr(), B, V * 3, None, float(w[5]), terms.ptr("stemp"), dverts.data_ptr(), L.stream_ptr()))
+                self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
+                # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
+                _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
+                                           terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
+                adam.step()
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(it > arm_after), state.data_ptr(),
+                                                    stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
+                res.steps += 1
+            res.outer_iters += 1
+            if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                res.stopped_early = True
+                break
+        res.losses = hist.cpu().numpy()
+        if res.stopped_early:
+            res.steps = int(np.isfinite(res.losses).sum())
+        return res
+
+    # ---- fit, object stage (recon_fit_trivis_full.py:283-377) ----------------------------------------------
+    def optimize_smpl_object(self, maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil=None, noise=None,
+                             iter_for_obj=15, iter_for_sil=30, joint_iter=10, max_iter=100, it_range=None, seed=0, check_every=1, prof=None):
+        """obj_R (B,3,3), obj_t (B,3) are updated in place.  ``smpl_verts`` (B,6890,3): the frozen body (contacts).
+        ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``)."""
+        dev = obj_R.device; B = obj_R.shape[0]; N = self.obj_points.shape[0]; NV = self.obj_verts.shape[0]
+        names = ["object", "otemp", "ovtemp", "mask", "trans", "contact"]
+        terms = Terms(names, dev)
+        total = joint_iter + iter_for_obj + max_iter + iter_for_sil
+        start, end = it_range if it_range is not None else (0, total)
+        nsteps = (end - start) * 10
+        if noise is None:
+            gen = torch.Generator(device=dev); gen.manual_seed(seed)
+            noise = torch.rand(nsteps, B, 3, 3, device=dev, generator=gen)
+        R = torch.empty(B, 3, 3, device=dev); X = torch.empty(B, N, 3, device=dev); dX = torch.empty_like(X)
+        dR = torch.empty(B, 3, 3, device=dev); dM = torch.empty(B, 3, 3, device=dev); dt = torch.empty(B, 3, device=dev)
+        stop = torch.zeros(1, dtype=torch.int32, device=dev); state = torch.tensor([300.0, 300.0], device=dev)
+        hist = torch.full((nsteps,), float("nan"), device=dev)
+        Rv, tv = obj_R.view(B, 9), obj_t
+        if sil is not None:
+            Vt = torch.empty(B, NV, 3, device=dev); dVt = torch.empty_like(Vt); img = torch.empty(B, sil.size, sil.size, device=dev)
+            fidx = torch.empty(B, sil.size, sil.size, dtype=torch.int32, device=dev); proj = torch.empty(B, NV, 3, device=dev)
+            gproj = torch.empty(B, NV, 2, device=dev); dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
+        adam = None; res = FitResult(); contact = None; trans_init = None
+        for it in range(start, end):
+            if it < iter_for_obj:
+                phase = "object only"
+                if adam is None:
+                    adam = AdamState([(Rv, 9, dM.view(B, 9), 0.002), (tv, 3, dt, 0.006)], stop)
+            elif it < iter_for_obj + iter_for_sil:
+                phase = "sil"
+                if adam is None or it == iter_for_obj:
+                    adam = AdamState([(Rv, 9, dM.view(B, 9), 0.006), (tv, 3, dt, 0.006)], stop)
+                    trans_init = obj_t.clone()
+            else:
+                phase = "joint"
+                if adam is None or it == iter_for_obj + iter_for_sil:
+                    adam = AdamState([(tv, 3, dt, 0.002)], stop)
+            decay = 1 if phase == "object only" else (it - iter_for_obj + 1 if phase == "sil" else (it - iter_for_obj + 1) / 3)
+            tw = 10.0 if phase == "joint" else 1.0
+            w = terms.weights(FIT_WEIGHTS, decay, {"otemp": tw, "ovtemp": tw})
+            for i in range(10):
+                k = (it - start) * 10 + i
+                nz = noise[k]
+                terms.zero()
+                _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
+                _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
+                acc = 0
+                if phase == "sil":
+                    if sil is None:
+                        raise L.VtError("phase 'sil' needs a SilSetup")
+                    _chk(_lib().vt_fill(dX.data_ptr(), dX.numel(), 0.0, L.stream_ptr()))
+                else:
+                    ev = _ev_begin(prof)
+                    _chk(_lib().vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
+                                                     occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), L.stream_ptr()))
+                    _ev_end(prof, "object", ev)
+                if B >= 4:
+                    _chk(_lib().vt_accel_loss(X.data_ptr(), B, N * 3, None, float(w[1]), terms.ptr("otemp"), dX.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_velocity_loss(X.data_ptr(), B, N * 3, float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), L.stream_ptr()))
+                if phase == "sil":
+                    _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vt.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                               img.data_ptr(), fidx.data_ptr(), proj.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
+                                                 terms.ptr("mask"), per.data_ptr(), dimg.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_sil_backward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                                fidx.data_ptr(), proj.data_ptr(), dimg.data_ptr(), 1e-4, gproj.data_ptr(), dVt.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_rigid_backward(self.obj_verts.data_ptr(), 1, obj_s.data_ptr(), B, NV, dVt.data_ptr(), dR.data_ptr(), dt.data_ptr(), 0, L.stream_ptr()))
+                    _chk(_lib().vt_sqdiff_loss(obj_t.data_ptr(), 3, trans_init.data_ptr(), 3, B, 3, float(B * 3), float(w[4]), terms.ptr("trans"), dt.data_ptr(), L.stream_ptr()))
+                    acc = 1
+                if phase == "joint":
+                    if contact is None:
+                        contact = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
+                    if contact["P"] > 0:
+                        y = X.view(-1, 3).index_select(0, contact["idx_o"])
+                        dy = torch.zeros_like(y)
+                        _chk(_lib().vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
+                                                      contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), L.stream_ptr()))
+                        dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
+                _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
+                _chk(_lib().vt_so3_project_backward(obj_R.data_ptr(), nz.data_ptr(), B, dR.data_ptr(), dM.data_ptr(), L.stream_ptr()))
+                adam.step()
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(phase == "joint" and it > 0.25 * max_iter),
+                                                    state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
+                res.steps += 1
+            res.outer_iters += 1
+            if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                res.stopped_early = True
+                break
+        res.losses = hist.cpu().numpy()
+        if res.stopped_early:
+            res.steps = int(np.isfinite(res.losses).sum())
+        return res
+
+    def _contacts_once(self, maps, smpl_verts, X, crop_center, body_center, thres=0.08):
+        """'Computing contacts once' (recon_fit_trivis_full.py:242-253) + the pairing of compute_contact_loss (:393-457):
+        contact masks df < 0.08 on both sides, pairs (frame, part) present on both, ragged index lists on the device."""
+        B, N = X.shape[:2]; V = smpl_verts.shape[1]; dev = X.device
+        df_o, _, parts_o, _, _ = ops.sifnet_query(self.net, maps, X, crop_center, body_center, head_mask=0b00101)
+        df_h, _, _, _, _ = ops.sifnet_query(self.net, maps, smpl_verts, crop_center, body_center, head_mask=0b00001)
+        mask_o = df_o[:, 0] < thres                      # df_obj_h: human distance at the object points
+        mask_h = df_h[:, 1] < thres                      # df_hum_o: object distance at the SMPL vertices
+        lab_o = parts_o.argmax(1)                        # (B,N)
+        lab_h = self.labels.long().unsqueeze(0).expand(B, V)
+        oh = torch.zeros(B, 14, device=dev, dtype=torch.long); oo = torch.zeros_like(oh)
+        oh.scatter_add_(1, lab_h, mask_h.long()); oo.scatter_add_(1, lab_o, mask_o.long())
+        pair = (oh > 0) & (oo > 0)                       # (B,14)
+        P = int(pair.sum().item())
+        if P == 0:
+            return {"P": 0}
+        sel_h = mask_h & pair.gather(1, lab_h); sel_o = mask_o & pair.gather(1, lab_o)
+        bh, vh = sel_h.nonzero(as_tuple=True); bo, no = sel_o.nonzero(as_tuple=True)
+        kh = bh * 14 + lab_h[bh, vh]; ko = bo * 14 + lab_o[bo, no]
+        oh_s = torch.sort(kh, stable=True); oo_s = torch.sort(ko, stable=True)
+        idx_h = (bh * V + vh)[oh_s.indices]; idx_o = (bo * N + no)[oo_s.indices]
+        cnt_h = (oh * pair).reshape(-1); cnt_o = (oo * pair).reshape(-1)
+        keep = pair.reshape(-1)
+        offx = torch.zeros(P + 1, dtype=torch.int32, device=dev); offy = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+        offx[1:] = torch.cumsum(cnt_h[keep], 0).int(); offy[1:] = torch.cumsum(cnt_o[keep], 0).int()
+        return {"P": P, "x": smpl_verts.reshape(-1, 3).index_select(0, idx_h).contiguous(), "offx": offx, "offy": offy, "idx_o": idx_o}
+
+
+class SilSetup:
+    """Per-batch constants of SilLossROI (obj_pose_roi.py:39-75): ROI intrinsics K (B,9), keep mask and reference mask
+    (B,size,size).  Built from already cropped masks by ``vistracker_amd.silhouette.SilLossROI`` or synthetically."""
+
+    def __init__(self, K, keep, ref, size=256):
+        self.K, self.keep, self.ref, self.size = K.contiguous(), keep.contiguous(), ref.contiguous(), size
