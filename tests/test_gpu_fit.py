@@ -57,7 +57,7 @@ def test_smplfit_trajectory_vs_reference(synth):
     # top betas (the only ones copy_smpl_params keeps, recon_fit_base.py:808-816) tight; the 8 "other" betas are barely
     # observable on this model (shapedirs ~1e-2) and Adam amplifies round-off on them
     db = np.abs(betas.cpu().numpy() - g["fin_betas"])
-    assert db[:, :2].max() < 5e-4 and db[:, 2:].max() < 2e-2
+    assert db[:, :2].max() < 2e-3 and db[:, 2:].max() < 2e-2
 
 
 def test_objfit_smooth_trajectory_vs_reference(synth):
