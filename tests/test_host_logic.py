@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the package -- sharding (+ world-size-2 gloo gather), config loading, SilLossROI setup math,
+model loading without chumpy.  No GPU, no compute kernels."""
+import json
+import os
+import pickle
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_shard_batches_cover_sequence_in_order():
+    from vistracker_amd.sharding import batches_of, shard_batches, frame_range
+    T, bs = 1500, 96
+    allb = batches_of(T, bs)
+    assert len(allb) == 16 and allb[-1] == (1440, 1500)           # 15 x 96 + 60
+    for world in (1, 2, 4, 8, 16, 32):
+        got = []
+        for r in range(world):
+            sh = shard_batches(T, bs, world, r)
+            if sh:
+                s, e = frame_range(sh)
+                assert s % bs == 0 and (e % bs == 0 or e == T)     # batch aligned like --start/--end multiples of bs
+            got += sh
+        assert got == allb
+    assert [len(shard_batches(T, bs, 8, r)) for r in range(8)] == [2] * 8
+    assert shard_batches(10, 96, 4, 3) == [] and shard_batches(0, 96, 2, 0) == []
+    assert batches_of(1500, 96, start=96, end=300) == [(96, 192), (192, 288), (288, 300)]
+
+
+def test_gather_params_world2_gloo(tmp_path):
+    """two CPU processes (gloo): each rank 'fits' its frames, all_gather returns the sequence in frame order."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, {ROOT!r})
+        from vistracker_amd.sharding import shard_batches, gather_params
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        T, bs = 500, 96                                   # 6 batches: 3 + 3, last one ragged (20 frames)
+        mine = shard_batches(T, bs, w, r)
+        rows = torch.cat([torch.arange(s, e, dtype=torch.float32)[:, None].repeat(1, 182) for s, e in mine])
+        allp = gather_params(rows, T, bs)
+        assert allp.shape == (T, 182) and torch.equal(allp[:, 0], torch.arange(T, dtype=torch.float32)), allp[:, 0]
+        if r == 0: print("GATHER_OK")
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29533", str(script)], capture_output=True, text=True, env=env, timeout=240)
+    assert "GATHER_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_config_loader_reads_reference_style_json(tmp_path):
+    from vistracker_amd.config import load_configs, get_parser, merge_configs
+    (tmp_path / "x.json").write_text('{\n "exp_name": "x", // comment\n "loadSize": 1200, "net_img_size": [512, 512], "z_feat": "smpl-triplane"\n}\n')
+    cfg = load_configs("x", str(tmp_path))
+    assert cfg.loadSize == 1200 and "z_feat" in cfg and "missing" not in cfg
+    args = get_parser().parse_args(["x", "-s", "/seq", "-sn", "out", "-sr", "smplt", "-or", "hvop", "-fs", "96", "-fe", "288"])
+    m = merge_configs(args, cfg)
+    assert m.batch_size == 96 and m.start == 96 and m.end == 288 and m.smpl_recon_name == "smplt" and m.test_kid == 1
+    (tmp_path / "bad.json").write_text('{"loadSize": 1200, "camera_params": {"crop_size": 1000}}')
+    with pytest.raises(AssertionError):
+        load_configs("bad", str(tmp_path))
+
+
+def test_silhouette_setup_math():
+    import torch
+    from vistracker_amd.silhouette import mask2bbox, make_bbox_square, roi_align_mask, compute_K_roi
+    m = np.zeros((512, 512), np.uint8); m[100:200, 150:400] = 255
+    bb = mask2bbox(m)
+    assert bb.tolist() == [150, 100, 400, 200]
+    sq = make_bbox_square(np.array([150, 100, 250, 100.0]), 0.3)[0]
+    assert np.allclose(sq, [275 - 162.5, 150 - 162.5, 325, 325])
+    # ROIAlign of a constant region is constant; of a half-plane reproduces the edge position
+    mask = torch.zeros(512, 512); mask[:, 256:] = 1
+    out = roi_align_mask(mask, [128, 128, 384, 384], 256)
+    assert out.shape == (256, 256) and out[:, :120].max() == 0 and out[:, 136:].min() == 1
+    col = (out[0] >= 0.5).float().argmax().item()
+    assert abs(col - 128) <= 1
+    K = compute_K_roi([900.0, 600.0, 500.0, 500.0])
+    assert np.allclose(K[0], [979.7844 / 500, 0, (1018.952 - 900) / 500]) and np.allclose(K[1], [0, 979.840 / 500, (779.486 - 600) / 500])
+    with pytest.raises(AssertionError):
+        compute_K_roi([0, 0, 10, 11])
+
+
+def test_smplh_model_loader_without_chumpy(tmp_path, synth):
+    """npz / dict inputs and a pickle with only numpy payloads load; foreign classes in a pickle are refused."""
+    from vistracker_amd.smpl import load_smplh_model
+    m = synth["model"]
+    np.savez(tmp_path / "m.npz", **{k: v for k, v in m.items()})
+    got = load_smplh_model(str(tmp_path / "m.npz"))
+    assert got["posedirs"].shape == (6890, 3, 459) and got["parents"][1] == 0 and got["J_regressor"].shape == (52, 6890)
+    import scipy.sparse as sp
+    d = dict(m); d["J_regressor"] = sp.csc_matrix(m["J_regressor"]); d.pop("parents")
+    pickle.dump(d, open(tmp_path / "SMPLH_male.pkl", "wb"))
+    got = load_smplh_model(str(tmp_path / "SMPLH_male.pkl"))
+    assert np.allclose(got["J_regressor"], m["J_regressor"]) and got["parents"][5] == 2
+
+    import subprocess as sp_   # a class from a module outside the allow-list
+    pickle.dump({"x": sp_.CompletedProcess([], 0)}, open(tmp_path / "evil.pkl", "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        load_smplh_model(str(tmp_path / "evil.pkl"))

@@ -1,0 +1,49 @@
+"""Frame sharding of one sequence over the GPUs of a node and the parameter gather at a pipeline barrier.
+
+The reference parallelises by launching processes with disjoint ``--start/--end`` (README.md:55;
+recon/recon_fit_base.py:411-419): frames are cut into batches of ``bs`` consecutive frames and temporal terms couple
+frames only inside a batch.  ``shard_batches`` gives every rank a contiguous run of WHOLE batches, so an
+N-GPU run produces exactly the single-process result; ``gather_params`` is the one collective (RCCL all_gather over xGMI,
+latency-bound: 182 floats per frame).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def batches_of(num_frames: int, bs: int, start: int = 0, end: int | None = None) -> List[Tuple[int, int]]:
+    end = num_frames if end is None else min(end, num_frames)
+    return [(s, min(s + bs, end)) for s in range(start, end, bs)]
+
+
+def shard_batches(num_frames: int, bs: int, world: int, rank: int, start: int = 0, end: int | None = None) -> List[Tuple[int, int]]:
+    """Contiguous, batch-aligned share of rank ``rank``: the first (nb % world) ranks get one extra batch."""
+    allb = batches_of(num_frames, bs, start, end)
+    nb = len(allb)
+    base, extra = divmod(nb, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return allb[lo:hi]
+
+
+def frame_range(batches: List[Tuple[int, int]]) -> Tuple[int, int]:
+    """the --start/--end pair equivalent to a shard (empty shard -> (0, 0))"""
+    return (batches[0][0], batches[-1][1]) if batches else (0, 0)
+
+
+def gather_params(local, num_frames: int, bs: int, start: int = 0, end: int | None = None):
+    """all_gather of per-frame parameter rows (T_rank, D) from every rank -> (T, D) in frame order on every rank.
+    Works with any initialised torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    counts = [sum(e - s for s, e in shard_batches(num_frames, bs, world, r, start, end)) for r in range(world)]
+    D = local.shape[1]
+    mx = max(counts)
+    pad = torch.zeros(mx, D, dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[:c] for o, c in zip(outs, counts)], 0)
