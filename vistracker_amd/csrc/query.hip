@@ -25,15 +25,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define KTOT 612            /* 608 map channels + x,y,z-2.2 + 1 zero pad (internal channel order) */
 #define NCHUNK 19
-#define FS 34               /* LDS stride of a 32-channel chunk row   [pt][32 + 2]  */
-#define HS 130              /* LDS stride of a hidden activation row  [pt][128 + 2] */
-#define GS 18               /* LDS stride of an output-gradient row   [pt][16 + 2]  */
+#define FS 36               /* LDS stride of a 32-channel chunk row   [pt][32 + 4]:  36 j mod 64 distinct -> conflict-free ds_read_b64 */
+#define HS 132              /* LDS stride of a hidden activation row  [pt][128 + 4]: 132 j mod 64 = 4 j                                  */
+#define GS 20               /* LDS stride of an output-gradient row   [pt][16 + 4]                                                       */
 #define OUT_DIST 5.0f       /* chore.py:93 */
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3 };
 
+// Weight fragments.  All GEMMs walk K in "pair steps": lane (q = lane>>4, j = lane&15) owns k = 8 s + 2 q + e, e in {0,1}, so
+// its two A values are one ds_read_b64 and its B values for both k's and both N-tiles of the wave are one 16-B global load.
+//   wNp  : [K/2][4 waves][16 j][2 e][2 nt]   element = W[k = 2 kp + e][n = (2 wave + nt) 16 + j]        (layers 1-3 fwd and bwd, layer-4 bwd)
+//   w1c  : [64 kp][20 chunks][16 j][2 e][2 nt] element = W1(out,in)[u = 2 kp + e][c = chunk 32 + nt 16 + j]   (layer-1 backward)
+//   w4p  : [64 kp][16 j][2 e]                element = W4(in,out)[k = 2 kp + e][o = j]
 struct HeadW {
-    const float *w1io, *w1oi, *b1, *w2io, *w2oi, *b2, *w3io, *w3oi, *b3, *w4io, *w4oi, *b4;
+    const float *w1p, *w1c, *w1xio, *w1xoi, *b1, *w2p, *w2tp, *b2, *w3p, *w3tp, *b3, *w4p, *w4tp, *b4;
     int kout, id;
 };
 
@@ -68,15 +73,16 @@ __device__ __forceinline__ void chunk_info(int i, int &mi, int &co)
     else { mi = 5 + (i - 13) / 2; co = 32 * ((i - 13) & 1); }
 }
 
-// stage one 32-channel chunk for the 64 points of the tile: blended features (GRAD = false -> bufA) or the tap
-// differences d feat / d u, d feat / d v scaled by (res-1)/2 (GRAD = true -> bufA = d/du, bufB = d/dv)
-template <bool GRAD>
-__device__ __forceinline__ void gather_chunk(const QArgs &a, int b, int mi, int co, const float *sUV, float *bufA, float *bufB, int tid)
+// The four bilinear taps of one 32-channel chunk for two points per thread, held in registers while the loads are in flight.
+struct Taps { float4 t[2][4]; float wx1[2], wy1[2]; float sc; };
+
+// issue the tap loads of chunk (mi, co): thread = (point pp / pp+32, 16-B piece `sub` of the 128-B tap row)
+__device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const float *sUV, int tid, Taps &r)
 {
     const float *__restrict__ map = a.maps[mi];
     const int R = a.res[mi], C = map_channels(mi), pr = map_proj(mi);
     const int sub = tid & 7, pp = tid >> 3;
-    const float sc = 0.5f * (float)(R - 1);
+    r.sc = 0.5f * (float)(R - 1);
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int pt = pp + 32 * pass;
@@ -86,26 +92,45 @@ __device__ __forceinline__ void gather_chunk(const QArgs &a, int b, int mi, int 
         ix = fminf(fmaxf(ix, -2.0f), (float)(R + 1)); iy = fminf(fmaxf(iy, -2.0f), (float)(R + 1));
         const float fxl = floorf(ix), fyl = floorf(iy);
         const int x0 = (int)fxl, y0 = (int)fyl, x1 = x0 + 1, y1 = y0 + 1;
-        const float wx1 = ix - fxl, wx0 = (fxl + 1.0f) - ix, wy1 = iy - fyl, wy0 = (fyl + 1.0f) - iy;
+        r.wx1[pass] = ix - fxl; r.wy1[pass] = iy - fyl;
         const bool bx0 = x0 >= 0 && x0 < R, bx1 = x1 >= 0 && x1 < R, by0 = y0 >= 0 && y0 < R, by1 = y1 >= 0 && y1 < R;
         const size_t rowb = (size_t)b * R;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 nw = (bx0 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x0) * C + co + sub * 4) : z4;
-        const float4 ne = (bx1 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x1) * C + co + sub * 4) : z4;
-        const float4 sw = (bx0 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x0) * C + co + sub * 4) : z4;
-        const float4 se = (bx1 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x1) * C + co + sub * 4) : z4;
-        float2 *dA = reinterpret_cast<float2 *>(bufA + pt * FS + sub * 4);
-        if (!GRAD) {
-            const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
-            dA[0] = make_float2(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11);
-            dA[1] = make_float2(nw.z * w00 + ne.z * w10 + sw.z * w01 + se.z * w11, nw.w * w00 + ne.w * w10 + sw.w * w01 + se.w * w11);
-        } else {
-            float2 *dB = reinterpret_cast<float2 *>(bufB + pt * FS + sub * 4);
-            dA[0] = make_float2(((ne.x - nw.x) * wy0 + (se.x - sw.x) * wy1) * sc, ((ne.y - nw.y) * wy0 + (se.y - sw.y) * wy1) * sc);
-            dA[1] = make_float2(((ne.z - nw.z) * wy0 + (se.z - sw.z) * wy1) * sc, ((ne.w - nw.w) * wy0 + (se.w - sw.w) * wy1) * sc);
-            dB[0] = make_float2(((sw.x - nw.x) * wx0 + (se.x - ne.x) * wx1) * sc, ((sw.y - nw.y) * wx0 + (se.y - ne.y) * wx1) * sc);
-            dB[1] = make_float2(((sw.z - nw.z) * wx0 + (se.z - ne.z) * wx1) * sc, ((sw.w - nw.w) * wx0 + (se.w - ne.w) * wx1) * sc);
-        }
+        r.t[pass][0] = (bx0 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x0) * C + co + sub * 4) : z4;
+        r.t[pass][1] = (bx1 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x1) * C + co + sub * 4) : z4;
+        r.t[pass][2] = (bx0 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x0) * C + co + sub * 4) : z4;
+        r.t[pass][3] = (bx1 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x1) * C + co + sub * 4) : z4;
+    }
+}
+// blend the taps to features and store [pt][FS] (forward) ...
+__device__ __forceinline__ void taps_store_feat(const Taps &r, float *buf, int tid)
+{
+    const int sub = tid & 7, pp = tid >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+        const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        *reinterpret_cast<float4 *>(buf + (pp + 32 * pass) * FS + sub * 4) =
+            make_float4(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11,
+                        nw.z * w00 + ne.z * w10 + sw.z * w01 + se.z * w11, nw.w * w00 + ne.w * w10 + sw.w * w01 + se.w * w11);
+    }
+}
+// ... or the tap differences d feat / d u, d feat / d v scaled by (res-1)/2 (backward)
+__device__ __forceinline__ void taps_store_grad(const Taps &r, float *bufU, float *bufV, int tid)
+{
+    const int sub = tid & 7, pp = tid >> 3;
+    const float sc = r.sc;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * FS + sub * 4) =
+            make_float4(((ne.x - nw.x) * wy0 + (se.x - sw.x) * wy1) * sc, ((ne.y - nw.y) * wy0 + (se.y - sw.y) * wy1) * sc,
+                        ((ne.z - nw.z) * wy0 + (se.z - sw.z) * wy1) * sc, ((ne.w - nw.w) * wy0 + (se.w - sw.w) * wy1) * sc);
+        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * FS + sub * 4) =
+            make_float4(((sw.x - nw.x) * wx0 + (se.x - ne.x) * wx1) * sc, ((sw.y - nw.y) * wx0 + (se.y - ne.y) * wx1) * sc,
+                        ((sw.z - nw.z) * wx0 + (se.z - ne.z) * wx1) * sc, ((sw.w - nw.w) * wx0 + (se.w - ne.w) * wx1) * sc);
     }
 }
 
@@ -156,30 +181,37 @@ __device__ __forceinline__ void store_hbuf(const Acc8 &c, float *H, int wave, in
 #pragma unroll
             for (int r = 0; r < 4; r++) H[(mt * 16 + (lane >> 4) * 4 + r) * HS + (2 * wave + nt) * 16 + (lane & 15)] = c.v[mt][nt][r];
 }
-// out[64 x 128 slice of this wave] = H[64 x 128] (A, LDS) x W[128 x 128] (B rows contiguous, global), K = 128
-__device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__restrict__ W, int wave, int lane)
+// one pair step of the wave tile: A pairs of the 4 M-tiles (LDS, row stride `stride`), B float4 = {e0nt0, e0nt1, e1nt0, e1nt1}
+__device__ __forceinline__ void pair_step(Acc8 &c, const float *Abase, int stride, int s, int q, int j, const float4 bb)
+{
+    float2 av[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) av[mt] = *reinterpret_cast<const float2 *>(Abase + (mt * 16 + j) * stride + 8 * s + 2 * q);
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt].x, bb.x, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt].x, bb.y, c.v[mt][1]); }
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt].y, bb.z, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt].y, bb.w, c.v[mt][1]); }
+}
+// out[64 x (32 cols of this wave)] = H[64 x 128] (A, LDS) x W[128 x 128] (B, pair-step fragments from L2), K = 128
+__device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__restrict__ Wp, int wave, int lane)
 {
     acc_zero(c);
     const int q = lane >> 4, j = lane & 15;
+    const float4 *__restrict__ w = reinterpret_cast<const float4 *>(Wp) + (q * 4 + wave) * 16 + j;
 #pragma unroll 4
-    for (int ks = 0; ks < 32; ks++) {
-        const float b0 = W[(ks * 4 + q) * 128 + (2 * wave) * 16 + j], b1 = W[(ks * 4 + q) * 128 + (2 * wave + 1) * 16 + j];
-        float av[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) av[mt] = H[(mt * 16 + j) * HS + ks * 4 + q];
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt], b0, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt], b1, c.v[mt][1]); }
-    }
+    for (int s = 0; s < 16; s++) pair_step(c, H, HS, s, q, j, w[(size_t)s * 4 * 64]);
 }
 
 template <int G, int MODE>
-__global__ __launch_bounds__(256) void query_kernel(const QArgs a)
+__global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Hb = lds;                        // G x [64][HS]   hidden activations / d(hidden-1) per head
-    float *Fch = Hb + G * 64 * HS;          // [64][FS]       feature chunk (fwd) / d feat / du (bwd)
-    float *Gvb = Fch + 64 * FS;             // [64][FS]       d feat / dv (bwd)
-    float *Go = Gvb + 64 * FS;              // [64][GS]       output gradient
+    // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden activations per head -> tap-difference double
+    // buffers (layer-1 backward, after the d(hidden-1) fragments moved to registers).
+    constexpr int R0 = (G * 64 * HS > 4 * 64 * FS) ? G * 64 * HS : 4 * 64 * FS;
+    float *Hb = lds;                        // G x [64][HS]
+    float *Cb = lds;                        // 2 x [64][FS] (fwd)   |   2 x { [64][FS] du, [64][FS] dv } (bwd)
+    float *Go = lds + R0;                   // [64][GS]       output gradient
     float *sPt = Go + 64 * GS;              // [64][3]
     float *sUV = sPt + 64 * 3;              // [4][64][2]
     int *sIn = reinterpret_cast<int *>(sUV + 4 * 64 * 2);  // [64]
@@ -206,50 +238,50 @@ __global__ __launch_bounds__(256) void query_kernel(const QArgs a)
     }
     __syncthreads();
 
-    // ---- layer 1: stream the 19 chunks, all heads of the group at once
+    // ---- layer 1: stream the 19 chunks (all heads of the group at once); the tap loads of chunk i+1 are in flight
+    //      while the MFMAs of chunk i run (one barrier per chunk thanks to the double buffer)
     Acc8 acc1[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc_zero(acc1[g]);
+    Taps tp;
+    { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
     for (int ci = 0; ci < NCHUNK; ci++) {
-        int mi, co; chunk_info(ci, mi, co);
-        // weight fragments of this chunk first (L2 latency overlaps the gather)
-        float bw[G][8][2];
+        float *buf = Cb + (ci & 1) * 64 * FS;
+        taps_store_feat(tp, buf, tid);
+        float4 bw[G][4];
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                const float *w = a.hw[g].w1io + (size_t)(ci * 32 + ks * 4 + q) * 128 + (2 * wave) * 16 + j;
-                bw[g][ks][0] = w[0]; bw[g][ks][1] = w[16];
+            for (int s = 0; s < 4; s++) bw[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)(ci * 16 + s * 4 + q) * 4 + wave) * 16 + j];
+        __syncthreads();
+        if (ci + 1 < NCHUNK) { int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            float2 av[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) av[mt] = *reinterpret_cast<const float2 *>(buf + (mt * 16 + j) * FS + 8 * s + 2 * q);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt].x, bw[g][s].x, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt].x, bw[g][s].y, acc1[g].v[mt][1]); }
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt].y, bw[g][s].z, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt].y, bw[g][s].w, acc1[g].v[mt][1]); }
             }
-        gather_chunk<false>(a, b, mi, co, sUV, Fch, nullptr, tid);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            float av[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) av[mt] = Fch[(mt * 16 + j) * FS + ks * 4 + q];
-#pragma unroll
-            for (int g = 0; g < G; g++)
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) {
-                    acc1[g].v[mt][0] = MFMA16(av[mt], bw[g][ks][0], acc1[g].v[mt][0]);
-                    acc1[g].v[mt][1] = MFMA16(av[mt], bw[g][ks][1], acc1[g].v[mt][1]);
-                }
         }
-        __syncthreads();
     }
-    {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (+ zero pad 611)
+    {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (+ zero pad 611), one plain k-step (k = q)
         float av[4];
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) av[mt] = q < 3 ? sPt[(mt * 16 + j) * 3 + q] - (q == 2 ? 2.2f : 0.f) : 0.f;
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const float *w = a.hw[g].w1io + (size_t)(608 + q) * 128 + (2 * wave) * 16 + j;
+            const float *w = a.hw[g].w1xio + q * 128 + (2 * wave) * 16 + j;
             const float b0 = w[0], b1 = w[16];
 #pragma unroll
             for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt], b0, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt], b1, acc1[g].v[mt][1]); }
         }
     }
+    __syncthreads();        // region 0 changes role: chunk buffers -> hidden activations
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
     double loss_acc[2] = {0.0, 0.0};
@@ -261,20 +293,27 @@ __global__ __launch_bounds__(256) void query_kernel(const QArgs a)
         const unsigned m1 = bias_relu(acc1[g], hw.b1, wave, lane);
         store_hbuf(acc1[g], H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2io, wave, lane);
+        gemm128(c, H, hw.w2p, wave, lane);
         const unsigned m2 = bias_relu(c, hw.b2, wave, lane);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w3io, wave, lane);
+        gemm128(c, H, hw.w3p, wave, lane);
         const unsigned m3 = bias_relu(c, hw.b3, wave, lane);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
         __syncthreads();
         // layer 4: wave w owns the 16 points of M-tile w, N-tile = up to 16 outputs (zero padded)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const float2 *__restrict__ w4 = reinterpret_cast<const float2 *>(hw.w4p) + q * 16 + j;
 #pragma unroll 8
-        for (int ks = 0; ks < 32; ks++) o4 = MFMA16(H[(wave * 16 + j) * HS + ks * 4 + q], hw.w4io[(ks * 4 + q) * 16 + j], o4);
+            for (int s = 0; s < 16; s++) {
+                const float2 av = *reinterpret_cast<const float2 *>(H + (wave * 16 + j) * HS + 8 * s + 2 * q);
+                const float2 bb = w4[s * 64];
+                o4 = MFMA16(av.x, bb.x, o4); o4 = MFMA16(av.y, bb.y, o4);
+            }
+        }
         const float bias4 = hw.b4[j];
         float go[4];    // upstream gradient of output j at points wave*16 + q*4 + r
 #pragma unroll
@@ -330,24 +369,20 @@ __global__ __launch_bounds__(256) void query_kernel(const QArgs a)
         for (int r = 0; r < 4; r++) Go[(wave * 16 + q * 4 + r) * GS + j] = go[r];
         __syncthreads();
         acc_zero(c);
+        {
+            const float4 *__restrict__ w = reinterpret_cast<const float4 *>(hw.w4tp) + (q * 4 + wave) * 16 + j;
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const float b0 = hw.w4oi[(ks * 4 + q) * 128 + (2 * wave) * 16 + j], b1 = hw.w4oi[(ks * 4 + q) * 128 + (2 * wave + 1) * 16 + j];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                const float av = Go[(mt * 16 + j) * GS + ks * 4 + q];
-                c.v[mt][0] = MFMA16(av, b0, c.v[mt][0]); c.v[mt][1] = MFMA16(av, b1, c.v[mt][1]);
-            }
+            for (int s = 0; s < 2; s++) pair_step(c, Go, GS, s, q, j, w[s * 4 * 64]);
         }
         apply_mask(c, m3);
         store_hbuf(c, H, wave, lane);          // H (h3) was last read before the barrier above
         __syncthreads();
-        gemm128(c, H, hw.w3oi, wave, lane);    // g2 = g3 . W3(out,in)
+        gemm128(c, H, hw.w3tp, wave, lane);    // g2 = g3 . W3(out,in)
         apply_mask(c, m2);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2oi, wave, lane);    // g1 = g2 . W2(out,in)
+        gemm128(c, H, hw.w2tp, wave, lane);    // g1 = g2 . W2(out,in)
         apply_mask(c, m1);
         __syncthreads();
         store_hbuf(c, H, wave, lane);          // H now holds d loss / d (pre-activation 1) of this head
@@ -373,36 +408,42 @@ __global__ __launch_bounds__(256) void query_kernel(const QArgs a)
     if (MODE == MODE_FWD) return;
 
     // ---- backward through layer 1 and the gathers: wave w owns the 16 points of M-tile w
-    float ah[G][32];        // A fragments of d(hidden-1): point wave*16 + j, hidden unit ks*4 + q
+    float2 ah[G][16];       // A pair fragments of d(hidden-1): point wave*16 + j, hidden units 8 s + 2 q + {0,1}
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int ks = 0; ks < 32; ks++) ah[g][ks] = Hb[g * 64 * HS + (wave * 16 + j) * HS + ks * 4 + q];
+        for (int s = 0; s < 16; s++) ah[g][s] = *reinterpret_cast<const float2 *>(Hb + g * 64 * HS + (wave * 16 + j) * HS + 8 * s + 2 * q);
+    __syncthreads();        // region 0 changes role again: hidden activations -> tap-difference double buffers
     float du[4][4], dv[4][4];   // [projection][row r]: partial over the channels this lane owns
 #pragma unroll
     for (int p = 0; p < 4; p++)
 #pragma unroll
         for (int r = 0; r < 4; r++) { du[p][r] = 0.f; dv[p][r] = 0.f; }
+    { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
     for (int ci = 0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);
-        gather_chunk<true>(a, b, mi, co, sUV, Fch, Gvb, tid);
+        float *bu = Cb + (ci & 1) * 2 * 64 * FS, *bv = bu + 64 * FS;
+        // d feat[16 pts x 32 ch] = sum_g dh1[g] . W1(out,in)[g][:, chunk]   (no LDS operand: overlaps the tap loads in flight)
         f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const float *w = a.hw[g].w1oi + ci * 32 + j;
+            const float4 *__restrict__ w = reinterpret_cast<const float4 *>(a.hw[g].w1c) + ((size_t)q * 20 + ci) * 16 + j;
 #pragma unroll 8
-            for (int ks = 0; ks < 32; ks++) {
-                d0 = MFMA16(ah[g][ks], w[(size_t)(ks * 4 + q) * KTOT], d0);
-                d1 = MFMA16(ah[g][ks], w[(size_t)(ks * 4 + q) * KTOT + 16], d1);
+            for (int s = 0; s < 16; s++) {
+                const float4 bb = w[(size_t)s * 4 * 20 * 16];
+                d0 = MFMA16(ah[g][s].x, bb.x, d0); d1 = MFMA16(ah[g][s].x, bb.y, d1);
+                d0 = MFMA16(ah[g][s].y, bb.z, d0); d1 = MFMA16(ah[g][s].y, bb.w, d1);
             }
         }
+        taps_store_grad(tp, bu, bv, tid);
         __syncthreads();
+        if (ci + 1 < NCHUNK) { int m2i, c2o; chunk_info(ci + 1, m2i, c2o); taps_issue(a, b, m2i, c2o, sUV, tid, tp); }
         float su[4], sv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = (wave * 16 + q * 4 + r) * FS;
-            su[r] = d0[r] * Fch[row + j] + d1[r] * Fch[row + 16 + j];
-            sv[r] = d0[r] * Gvb[row + j] + d1[r] * Gvb[row + 16 + j];
+            su[r] = d0[r] * bu[row + j] + d1[r] * bu[row + 16 + j];
+            sv[r] = d0[r] * bv[row + j] + d1[r] * bv[row + 16 + j];
         }
         const int pr = map_proj(mi);
 #pragma unroll
@@ -410,15 +451,17 @@ __global__ __launch_bounds__(256) void query_kernel(const QArgs a)
 #pragma unroll
             for (int r = 0; r < 4; r++) { du[p][r] += su[r]; dv[p][r] += sv[r]; }
         }
-        __syncthreads();
     }
     // direct xyz features: d feat[608..610] = sum_g dh1 . W1(out,in)[:, 608..611]
     f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const float *w = a.hw[g].w1oi + 608 + (j & 3);
+        const float *w = a.hw[g].w1xoi + (j & 3);
 #pragma unroll 8
-        for (int ks = 0; ks < 32; ks++) dz = MFMA16(ah[g][ks], j < 4 ? w[(size_t)(ks * 4 + q) * KTOT] : 0.f, dz);
+        for (int s = 0; s < 16; s++) {
+            const float b0 = j < 4 ? w[(8 * s + 2 * q) * 4] : 0.f, b1 = j < 4 ? w[(8 * s + 2 * q + 1) * 4] : 0.f;
+            dz = MFMA16(ah[g][s].x, b0, dz); dz = MFMA16(ah[g][s].y, b1, dz);
+        }
     }
     // reduce the channel partials over the 16 lanes that share a row group
 #pragma unroll
@@ -474,33 +517,51 @@ extern "C" int vt_selftest_mfma(const float *A, const float *Bm, float *out, voi
 static const int kHeadDims[5] = {2, 9, 14, 3, 1};
 static inline int orig_channel(int k) { return k < 256 ? k : (k < 608 ? k + 3 : (k < 611 ? k - 608 + 256 : -1)); }
 
+// [K/2][4 waves][16 j][2 e][2 nt] pair-step fragments of a K x 128 matrix given as get(k, n)
+template <typename F>
+static void pack_pairs(float *dst, int K, F get)
+{
+    for (int kp = 0; kp < K / 2; kp++) for (int w = 0; w < 4; w++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) for (int nt = 0; nt < 2; nt++)
+        dst[((((size_t)kp * 4 + w) * 16 + j) * 2 + e) * 2 + nt] = get(2 * kp + e, (2 * w + nt) * 16 + j);
+}
+
 extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const float *const *bvec, const float *cam, void *stream)
 {
     VT_REQUIRE(out && w && bvec && cam, "vt_sifnet_create: null argument");
     hipStream_t st = vt_stream(stream);
-    const size_t per_head = (size_t)KTOT * 128 * 2 + 128 + (128 * 128 * 2 + 128) * 2 + 128 * 16 * 2 + 16;
+    // per head (floats): w1p 608*128 | w1c 64*20*16*4 | w1xio 4*128 | w1xoi 128*4 | b1 128 | (w2p, w2tp, b2) | (w3p, w3tp, b3) | w4p 128*16 | w4tp 16*128 | b4 16
+    const size_t per_head = (size_t)608 * 128 + 64 * 20 * 64 + 512 + 512 + 128 + 2 * (2 * 128 * 128 + 128) + 128 * 16 + 16 * 128 + 16;
     float *host = new float[per_head * 5]();
     vt_sifnet *h = new vt_sifnet();
     VT_HIP(hipMalloc(reinterpret_cast<void **>(&h->blob), per_head * 5 * sizeof(float)));
     for (int hd = 0; hd < 5; hd++) {
         float *p = host + per_head * hd; const float *d = h->blob + per_head * hd;
         const int ko = kHeadDims[hd];
+        const float *W1 = w[hd * 4];          // (128, 611) reference channel order
+        auto w1 = [&](int u, int k) { const int c = orig_channel(k); return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c]; };   // internal order
         size_t o = 0;
         HeadW &H = h->head[hd];
         H.kout = ko; H.id = hd;
-        // layer 1 (128 x 611 in the reference order) -> (in,out) [612][128] and (out,in) [128][612], internal order
-        H.w1io = d + o; for (int k = 0; k < KTOT; k++) { const int c = orig_channel(k); for (int u = 0; u < 128; u++) p[o + (size_t)k * 128 + u] = c < 0 ? 0.f : w[hd * 4][(size_t)u * VT_FEAT + c]; } o += (size_t)KTOT * 128;
-        H.w1oi = d + o; for (int u = 0; u < 128; u++) for (int k = 0; k < KTOT; k++) { const int c = orig_channel(k); p[o + (size_t)u * KTOT + k] = c < 0 ? 0.f : w[hd * 4][(size_t)u * VT_FEAT + c]; } o += (size_t)KTOT * 128;
+        H.w1p = d + o; pack_pairs(p + o, 608, [&](int k, int n) { return w1(n, k); }); o += (size_t)608 * 128;
+        H.w1c = d + o;
+        for (int kp = 0; kp < 64; kp++) for (int c = 0; c < 20; c++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) for (int nt = 0; nt < 2; nt++) {
+            const int k = c * 32 + nt * 16 + j;
+            p[o + ((((size_t)kp * 20 + c) * 16 + j) * 2 + e) * 2 + nt] = k < 608 ? w1(2 * kp + e, k) : 0.f;
+        }
+        o += (size_t)64 * 20 * 64;
+        H.w1xio = d + o; for (int k = 0; k < 4; k++) for (int u = 0; u < 128; u++) p[o + k * 128 + u] = w1(u, 608 + k); o += 512;
+        H.w1xoi = d + o; for (int u = 0; u < 128; u++) for (int k = 0; k < 4; k++) p[o + u * 4 + k] = w1(u, 608 + k); o += 512;
         H.b1 = d + o; memcpy(p + o, bvec[hd * 4], 128 * sizeof(float)); o += 128;
         for (int l = 1; l <= 2; l++) {
-            const float *src = w[hd * 4 + l];
-            const float *io = d + o; for (int i = 0; i < 128; i++) for (int u = 0; u < 128; u++) p[o + i * 128 + u] = src[u * 128 + i]; o += 128 * 128;
-            const float *oi = d + o; memcpy(p + o, src, 128 * 128 * sizeof(float)); o += 128 * 128;
+            const float *src = w[hd * 4 + l];      // (out, in)
+            const float *fp_ = d + o; pack_pairs(p + o, 128, [&](int k, int n) { return src[n * 128 + k]; }); o += 128 * 128;    // forward: B[k=in][n=out]
+            const float *bp_ = d + o; pack_pairs(p + o, 128, [&](int k, int n) { return src[k * 128 + n]; }); o += 128 * 128;    // backward: B[k=out][n=in]
             const float *bb = d + o; memcpy(p + o, bvec[hd * 4 + l], 128 * sizeof(float)); o += 128;
-            if (l == 1) { H.w2io = io; H.w2oi = oi; H.b2 = bb; } else { H.w3io = io; H.w3oi = oi; H.b3 = bb; }
+            if (l == 1) { H.w2p = fp_; H.w2tp = bp_; H.b2 = bb; } else { H.w3p = fp_; H.w3tp = bp_; H.b3 = bb; }
         }
-        H.w4io = d + o; for (int i = 0; i < 128; i++) for (int u = 0; u < ko; u++) p[o + i * 16 + u] = w[hd * 4 + 3][u * 128 + i]; o += 128 * 16;
-        H.w4oi = d + o; for (int u = 0; u < ko; u++) for (int i = 0; i < 128; i++) p[o + u * 128 + i] = w[hd * 4 + 3][u * 128 + i]; o += 16 * 128;
+        const float *W4 = w[hd * 4 + 3];           // (ko, 128)
+        H.w4p = d + o; for (int kp = 0; kp < 64; kp++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) p[o + ((size_t)kp * 16 + j) * 2 + e] = j < ko ? W4[j * 128 + 2 * kp + e] : 0.f; o += 128 * 16;
+        H.w4tp = d + o; pack_pairs(p + o, 16, [&](int k, int n) { return k < ko ? W4[k * 128 + n] : 0.f; }); o += 16 * 128;
         H.b4 = d + o; memcpy(p + o, bvec[hd * 4 + 3], ko * sizeof(float)); o += 16;
     }
     VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5 * sizeof(float), hipMemcpyHostToDevice, st));
@@ -512,7 +573,11 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
 }
 extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; hipFree(h->blob); delete h; }
 
-static size_t lds_bytes(int G) { return sizeof(float) * ((size_t)G * 64 * HS + 2 * 64 * FS + 64 * GS + 64 * 3 + 4 * 64 * 2 + 64) + 8 * sizeof(double); }
+static size_t lds_bytes(int G)
+{
+    const size_t r0 = (size_t)G * 64 * HS > (size_t)4 * 64 * FS ? (size_t)G * 64 * HS : (size_t)4 * 64 * FS;
+    return sizeof(float) * (r0 + 64 * GS + 64 * 3 + 4 * 64 * 2 + 64) + 8 * sizeof(double);
+}
 
 template <int G, int MODE>
 static int launch(const QArgs &a, hipStream_t st)
@@ -551,8 +616,6 @@ extern "C" int vt_query_forward(const vt_sifnet *h, const vt_maps *maps, const f
     }
     return VT_OK;
 }
-
-__global__ void add3_kernel(float *dst, const float *src, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] += src[i]; }
 
 extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                  int B, int N, const float *d_df, const float *d_pca, const float *d_parts, const float *d_centers,

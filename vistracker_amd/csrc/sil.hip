@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict
     }
 }
 
-// Kato et al. edge-sweep surrogate gradient, one thread per (frame, doubled face).
+// Kato et al. edge-sweep surrogate gradient, one WAVE per (frame, doubled face): the walk along an edge (d0) is uniform,
+// the pixel sweeps away from / into the face (d1, up to `is` pixels) are spread over the 64 lanes.
 // Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
-__global__ void sil_bwd_face_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
+__global__ __launch_bounds__(64) void sil_bwd_face_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, float eps, float *__restrict__ gproj)
 {
-    const int f2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (f2 >= 2 * NF) return;
+    const int f2 = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const float *pv = proj + (size_t)b * NV * 3;
     const int *fim = face_index + (size_t)b * is * is;
     const float *gal = d_image + (size_t)b * is * is;
@@ -127,7 +127,7 @@ __global__ void sil_bwd_face_kernel(const float *__restrict__ proj, const int *_
                 if (fim[idx_in] == f2) {   // sweep outwards from the edge
                     const int d1_limit = (0 < direction) ? is - 1 : 0;
                     const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
                         const size_t idx = PIX(d0, d1, axis);
                         const float diff_grad = ((fim[idx] >= 0 ? 1.f : 0.f) - alpha_in) * gal[idx];
                         if (diff_grad <= 0) continue;
@@ -141,7 +141,7 @@ __global__ void sil_bwd_face_kernel(const float *__restrict__ proj, const int *_
                     else d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
                     const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
                     const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
                         const size_t idx = PIX(d0, d1, axis);
                         if (fim[idx] != f2) continue;
                         const float diff_grad = (1.f - alpha_out) * gal[idx];
@@ -154,8 +154,10 @@ __global__ void sil_bwd_face_kernel(const float *__restrict__ proj, const int *_
         }
     }
 #undef PIX
-    for (int k = 0; k < 3; k++) for (int c = 0; c < 2; c++)
-        if (gface[k][c] != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, gface[k][c]);
+    for (int k = 0; k < 3; k++) for (int c = 0; c < 2; c++) {
+        const float g = wave_sum(gface[k][c]);
+        if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, g);
+    }
 }
 
 __global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const float *__restrict__ gproj,
@@ -213,7 +215,7 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
     VT_REQUIRE(verts && faces && K && face_index && proj && d_image && gproj && dverts && B > 0, "vt_sil_backward: bad argument");
     hipStream_t st = vt_stream(stream);
     VT_HIP(hipMemsetAsync(gproj, 0, sizeof(float) * (size_t)B * NV * 2, st));
-    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 63) / 64, B), dim3(64), 0, st, proj, faces, NV, NF, size, face_index, d_image, eps, gproj);
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3(2 * NF, B), dim3(64), 0, st, proj, faces, NV, NF, size, face_index, d_image, eps, gproj);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, gproj, dverts);
     VT_LAUNCH_CHECK();
