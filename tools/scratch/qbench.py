@@ -1,0 +1,35 @@
+"""micro-bench of the fused human query kernel at the bench shape (B=96, N=6890, full-resolution maps)"""
+import sys, ctypes as C; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '.')
+import numpy as np, torch
+import torch.nn.functional as F
+from vistracker_amd import ops, synthetic as syn, _lib as L
+B, N = 96, 6890
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+mode = sys.argv[2] if len(sys.argv) > 2 else "human"
+dev = "cuda"
+g = torch.Generator(device=dev); g.manual_seed(0)
+maps = {}
+for name, c, res, _ in syn.MAP_SPECS:
+    lo = torch.randn(B, c, res // 8, res // 8, device=dev, generator=g)
+    maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+fm = ops.FeatureMaps(maps)
+net = ops.SifNetHandle(syn.sifnet_decoders(3))
+if mode == "object":
+    N = 3000
+pts = (torch.randn(B, N, 3, device=dev, generator=g) * 0.3 + torch.tensor([0, 0, 2.2], device=dev)).contiguous()
+cc = torch.tensor([[1018.952, 779.486]] * B, device=dev); bc = torch.tensor([[0, 0, 2.2]] * B, device=dev)
+labels = torch.randint(0, 14, (N,), device=dev, dtype=torch.int32); occ = torch.rand(B, device=dev)
+dp = torch.empty(B, N, 3, device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
+def run():
+    if mode == "human":
+        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, labels.data_ptr(), 100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+    else:
+        L.check(L.lib().vt_query_object_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, occ.data_ptr(), 900.0, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+run(); torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+fl = (4 * ((611*128 + 2*128*128 + 128*2) + (611*128 + 2*128*128 + 128*14)) if mode == "human" else 4 * (611*128 + 2*128*128 + 128*2)) * B * N
+print(f"{mode}: {ms:.3f} ms/launch  {fl/ms/1e9:.1f} TFLOP/s  ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)")

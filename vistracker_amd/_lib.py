@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvistracker_hip.so")
+LIB_PATH = os.environ.get("VT_LIB_PATH", os.path.join(_HERE, "libvistracker_hip.so"))   # override only for kernel A/B experiments
 
 vp = C.c_void_p
 fp = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())

@@ -74,7 +74,7 @@ __device__ __forceinline__ void chunk_info(int i, int &mi, int &co)
 }
 
 // The four bilinear taps of one 32-channel chunk for two points per thread, held in registers while the loads are in flight.
-struct Taps { float4 t[2][4]; float wx1[2], wy1[2]; float sc; };
+struct Taps { float4 t[2][4]; float wx1[2], wy1[2]; int inb[2]; float sc; };
 
 // issue the tap loads of chunk (mi, co): thread = (point pp / pp+32, 16-B piece `sub` of the 128-B tap row)
 __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const float *sUV, int tid, Taps &r)
@@ -94,12 +94,19 @@ __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co
         const int x0 = (int)fxl, y0 = (int)fyl, x1 = x0 + 1, y1 = y0 + 1;
         r.wx1[pass] = ix - fxl; r.wy1[pass] = iy - fyl;
         const bool bx0 = x0 >= 0 && x0 < R, bx1 = x1 >= 0 && x1 < R, by0 = y0 >= 0 && y0 < R, by1 = y1 >= 0 && y1 < R;
+        // zeros padding: always load from a clamped (valid) texel -- plain global_load, no divergent branch, no select between a
+        // global and a private address -- and fold the in-bounds flag into the interpolation weights (see taps_store_*)
+        const int xc0 = min(max(x0, 0), R - 1), xc1 = min(max(x1, 0), R - 1), yc0 = min(max(y0, 0), R - 1), yc1 = min(max(y1, 0), R - 1);
         const size_t rowb = (size_t)b * R;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        r.t[pass][0] = (bx0 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x0) * C + co + sub * 4) : z4;
-        r.t[pass][1] = (bx1 && by0) ? *reinterpret_cast<const float4 *>(map + ((rowb + y0) * R + x1) * C + co + sub * 4) : z4;
-        r.t[pass][2] = (bx0 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x0) * C + co + sub * 4) : z4;
-        r.t[pass][3] = (bx1 && by1) ? *reinterpret_cast<const float4 *>(map + ((rowb + y1) * R + x1) * C + co + sub * 4) : z4;
+#ifdef ABL_NOGATHER
+        r.t[pass][0] = r.t[pass][1] = r.t[pass][2] = r.t[pass][3] = make_float4(u, v, u, v);
+#else
+        r.t[pass][0] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc0) * C + co + sub * 4);
+        r.t[pass][1] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc1) * C + co + sub * 4);
+        r.t[pass][2] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc0) * C + co + sub * 4);
+        r.t[pass][3] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc1) * C + co + sub * 4);
+#endif
+        r.inb[pass] = (bx0 && by0 ? 1 : 0) | (bx1 && by0 ? 2 : 0) | (bx0 && by1 ? 4 : 0) | (bx1 && by1 ? 8 : 0);
     }
 }
 // blend the taps to features and store [pt][FS] (forward) ...
@@ -109,7 +116,8 @@ __device__ __forceinline__ void taps_store_feat(const Taps &r, float *buf, int t
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-        const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+        const int ib = r.inb[pass];
+        const float w00 = (ib & 1) ? wx0 * wy0 : 0.f, w10 = (ib & 2) ? wx1 * wy0 : 0.f, w01 = (ib & 4) ? wx0 * wy1 : 0.f, w11 = (ib & 8) ? wx1 * wy1 : 0.f;
         const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
         *reinterpret_cast<float4 *>(buf + (pp + 32 * pass) * FS + sub * 4) =
             make_float4(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11,
@@ -124,7 +132,11 @@ __device__ __forceinline__ void taps_store_grad(const Taps &r, float *bufU, floa
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-        const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        const int ib = r.inb[pass];
+        const float m0 = (ib & 1) ? 1.f : 0.f, m1 = (ib & 2) ? 1.f : 0.f, m2 = (ib & 4) ? 1.f : 0.f, m3 = (ib & 8) ? 1.f : 0.f;
+        float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        nw.x *= m0; nw.y *= m0; nw.z *= m0; nw.w *= m0; ne.x *= m1; ne.y *= m1; ne.z *= m1; ne.w *= m1;
+        sw.x *= m2; sw.y *= m2; sw.z *= m2; sw.w *= m2; se.x *= m3; se.y *= m3; se.z *= m3; se.w *= m3;
         *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * FS + sub * 4) =
             make_float4(((ne.x - nw.x) * wy0 + (se.x - sw.x) * wy1) * sc, ((ne.y - nw.y) * wy0 + (se.y - sw.y) * wy1) * sc,
                         ((ne.z - nw.z) * wy0 + (se.z - sw.z) * wy1) * sc, ((ne.w - nw.w) * wy0 + (se.w - sw.w) * wy1) * sc);
@@ -192,25 +204,39 @@ __device__ __forceinline__ void pair_step(Acc8 &c, const float *Abase, int strid
 #pragma unroll
     for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt].y, bb.z, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt].y, bb.w, c.v[mt][1]); }
 }
-// out[64 x (32 cols of this wave)] = H[64 x 128] (A, LDS) x W[128 x 128] (B, pair-step fragments from L2), K = 128
-__device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__restrict__ Wp, int wave, int lane)
+// out[64 x (32 cols of this wave)] = H[64 x 128] (A, LDS) x W[128 x 128] (B, pair-step fragments from L2), K = 128.
+// The weights do not depend on the LDS contents: the first 8 fragments are requested BEFORE the barrier that publishes H
+// (wpre), the other 8 while the first MFMAs run.
+struct WPre { float4 v[8]; };
+__device__ __forceinline__ void wprefetch(WPre &p, const float *__restrict__ Wp, int wave, int lane)
+{
+    const float4 *__restrict__ w = reinterpret_cast<const float4 *>(Wp) + ((lane >> 4) * 4 + wave) * 16 + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 8; s++) p.v[s] = w[(size_t)s * 4 * 64];
+}
+__device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__restrict__ Wp, const WPre &p, int wave, int lane)
 {
     acc_zero(c);
     const int q = lane >> 4, j = lane & 15;
     const float4 *__restrict__ w = reinterpret_cast<const float4 *>(Wp) + (q * 4 + wave) * 16 + j;
-#pragma unroll 4
-    for (int s = 0; s < 16; s++) pair_step(c, H, HS, s, q, j, w[(size_t)s * 4 * 64]);
+    float4 late[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) late[s] = w[(size_t)(s + 8) * 4 * 64];
+#pragma unroll
+    for (int s = 0; s < 8; s++) pair_step(c, H, HS, s, q, j, p.v[s]);
+#pragma unroll
+    for (int s = 0; s < 8; s++) pair_step(c, H, HS, s + 8, q, j, late[s]);
 }
 
 template <int G, int MODE>
-__global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
+__global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden activations per head -> tap-difference double
     // buffers (layer-1 backward, after the d(hidden-1) fragments moved to registers).
-    constexpr int R0 = (G * 64 * HS > 4 * 64 * FS) ? G * 64 * HS : 4 * 64 * FS;
+    constexpr int R0 = (G * 64 * HS > 2 * 64 * FS + G * 4096) ? G * 64 * HS : 2 * 64 * FS + G * 4096;
     float *Hb = lds;                        // G x [64][HS]
-    float *Cb = lds;                        // 2 x [64][FS] (fwd)   |   2 x { [64][FS] du, [64][FS] dv } (bwd)
+    float *Cb = lds;                        // 2 x [64][FS] feature chunks (fwd)   |   [64][FS] du, [64][FS] dv, weight slab G x 16 KB (bwd)
     float *Go = lds + R0;                   // [64][GS]       output gradient
     float *sPt = Go + 64 * GS;              // [64][3]
     float *sUV = sPt + 64 * 3;              // [4][64][2]
@@ -218,7 +244,15 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-    const int b = blockIdx.y, n0 = blockIdx.x * 64;
+    // XCD-aware block -> (frame, tile) map: the dispatcher places workgroup L on XCD L % 8 (speed only, never correctness), so
+    // give every XCD whole frames: all ~108 tiles of a frame then gather from the same few MB of maps through ONE L2.
+    int b, tile;
+    {
+        const int tiles = (a.N + 63) >> 6, L = blockIdx.x;
+        if ((a.B & 7) == 0) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / tiles); tile = slot % tiles; }
+        else { b = L / tiles; tile = L % tiles; }
+    }
+    const int n0 = tile * 64;
 
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
     if (tid < 64) {
@@ -245,16 +279,23 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
     for (int g = 0; g < G; g++) acc_zero(acc1[g]);
     Taps tp;
     { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+    float4 bw[G][4], bwn[G][4];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) bw[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)(s * 4 + q) * 4 + wave) * 16 + j];
     for (int ci = 0; ci < NCHUNK; ci++) {
         float *buf = Cb + (ci & 1) * 64 * FS;
         taps_store_feat(tp, buf, tid);
-        float4 bw[G][4];
-#pragma unroll
-        for (int g = 0; g < G; g++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) bw[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)(ci * 16 + s * 4 + q) * 4 + wave) * 16 + j];
         __syncthreads();
-        if (ci + 1 < NCHUNK) { int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+        if (ci + 1 < NCHUNK) {
+            int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp);
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) bwn[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)((ci + 1) * 16 + s * 4 + q) * 4 + wave) * 16 + j];
+        }
+#ifndef ABL_NOFWDL1
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             float2 av[4];
@@ -268,6 +309,13 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
                 for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt].y, bw[g][s].z, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt].y, bw[g][s].w, acc1[g].v[mt][1]); }
             }
         }
+#else
+        for (int g = 0; g < G; g++) acc1[g].v[0][0][0] += bw[g][0].x + buf[(j) * FS + q];
+#endif
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) bw[g][s] = bwn[g][s];
     }
     {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (+ zero pad 611), one plain k-step (k = q)
         float av[4];
@@ -290,15 +338,18 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
         const HeadW &hw = a.hw[g];
         float *H = Hb + g * 64 * HS;
         Acc8 c;
+        WPre wp;
+        wprefetch(wp, hw.w2p, wave, lane);
         const unsigned m1 = bias_relu(acc1[g], hw.b1, wave, lane);
         store_hbuf(acc1[g], H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2p, wave, lane);
+        gemm128(c, H, hw.w2p, wp, wave, lane);
+        wprefetch(wp, hw.w3p, wave, lane);
         const unsigned m2 = bias_relu(c, hw.b2, wave, lane);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w3p, wave, lane);
+        gemm128(c, H, hw.w3p, wp, wave, lane);
         const unsigned m3 = bias_relu(c, hw.b3, wave, lane);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
@@ -307,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
             const float2 *__restrict__ w4 = reinterpret_cast<const float2 *>(hw.w4p) + q * 16 + j;
-#pragma unroll 8
+#pragma unroll
             for (int s = 0; s < 16; s++) {
                 const float2 av = *reinterpret_cast<const float2 *>(H + (wave * 16 + j) * HS + 8 * s + 2 * q);
                 const float2 bb = w4[s * 64];
@@ -374,15 +425,17 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
 #pragma unroll
             for (int s = 0; s < 2; s++) pair_step(c, Go, GS, s, q, j, w[s * 4 * 64]);
         }
+        wprefetch(wp, hw.w3tp, wave, lane);
         apply_mask(c, m3);
         store_hbuf(c, H, wave, lane);          // H (h3) was last read before the barrier above
         __syncthreads();
-        gemm128(c, H, hw.w3tp, wave, lane);    // g2 = g3 . W3(out,in)
+        gemm128(c, H, hw.w3tp, wp, wave, lane);    // g2 = g3 . W3(out,in)
+        wprefetch(wp, hw.w2tp, wave, lane);
         apply_mask(c, m2);
         __syncthreads();
         store_hbuf(c, H, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2tp, wave, lane);    // g1 = g2 . W2(out,in)
+        gemm128(c, H, hw.w2tp, wp, wave, lane);    // g1 = g2 . W2(out,in)
         apply_mask(c, m1);
         __syncthreads();
         store_hbuf(c, H, wave, lane);          // H now holds d loss / d (pre-activation 1) of this head
@@ -414,50 +467,72 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
 #pragma unroll
         for (int s = 0; s < 16; s++) ah[g][s] = *reinterpret_cast<const float2 *>(Hb + g * 64 * HS + (wave * 16 + j) * HS + 8 * s + 2 * q);
     __syncthreads();        // region 0 changes role again: hidden activations -> tap-difference double buffers
-    float du[4][4], dv[4][4];   // [projection][row r]: partial over the channels this lane owns
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) { du[p][r] = 0.f; dv[p][r] = 0.f; }
+    // coordinate-gradient partials of the 4 points (rows) this lane sees, over the channels this lane owns
+    float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
+    // Every wave needs the whole 128G x 32 weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
+    // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
+    float *bu = Cb, *bv = Cb + 64 * FS;                 // tap differences of the current chunk
+    float4 *Sl = reinterpret_cast<float4 *>(Cb + 2 * 64 * FS);   // [G][64 kp][16 j] float4 fragments
+#define SLAB_DMA(ci_)                                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4 * G; i_++) {                                                                    \
+        const int idx_ = tid + 256 * i_, g_ = idx_ >> 10, rem_ = idx_ & 1023;                                                \
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4 *>(a.hw[g_].w1c) + ((size_t)(rem_ >> 4) * 20 + (ci_)) * 16 + (rem_ & 15), \
+                                         (__attribute__((address_space(3))) void *)(Sl + wave * 64 + 256 * i_), 16, 0, 0);    \
+    }
+    SLAB_DMA(0)
     { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+    __syncthreads();
+    const float kx = 2.0f / a.crop * a.fx, ky = 2.0f / a.crop * a.fy;
     for (int ci = 0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);
-        float *bu = Cb + (ci & 1) * 2 * 64 * FS, *bv = bu + 64 * FS;
-        // d feat[16 pts x 32 ch] = sum_g dh1[g] . W1(out,in)[g][:, chunk]   (no LDS operand: overlaps the tap loads in flight)
-        f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f}, d1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // d feat[16 pts x 32 ch] = sum_g dh1[g] . W1(out,in)[g][:, chunk];  four independent accumulators
+        f32x4 dd[2][2];
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const float4 *__restrict__ w = reinterpret_cast<const float4 *>(a.hw[g].w1c) + ((size_t)q * 20 + ci) * 16 + j;
-#pragma unroll 8
-            for (int s = 0; s < 16; s++) {
-                const float4 bb = w[(size_t)s * 4 * 20 * 16];
-                d0 = MFMA16(ah[g][s].x, bb.x, d0); d1 = MFMA16(ah[g][s].x, bb.y, d1);
-                d0 = MFMA16(ah[g][s].y, bb.z, d0); d1 = MFMA16(ah[g][s].y, bb.w, d1);
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) dd[x][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef ABL_NOB1
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const float4 bb = Sl[(g * 64 + 4 * s + q) * 16 + j];
+                const int x0 = (G == 2) ? g : 0, x1 = (G == 2) ? g : 1;
+                dd[x0][0] = MFMA16(ah[g][s].x, bb.x, dd[x0][0]); dd[x0][1] = MFMA16(ah[g][s].x, bb.y, dd[x0][1]);
+                dd[x1][0] = MFMA16(ah[g][s].y, bb.z, dd[x1][0]); dd[x1][1] = MFMA16(ah[g][s].y, bb.w, dd[x1][1]);
             }
         }
+#else
+        dd[0][0][0] += ah[0][3].x + Sl[tid].x; dd[0][1][0] += ah[0][5].y;
+#endif
+        const f32x4 d0 = dd[0][0] + dd[1][0], d1 = dd[0][1] + dd[1][1];
         taps_store_grad(tp, bu, bv, tid);
-        __syncthreads();
-        if (ci + 1 < NCHUNK) { int m2i, c2o; chunk_info(ci + 1, m2i, c2o); taps_issue(a, b, m2i, c2o, sUV, tid, tp); }
-        float su[4], sv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = (wave * 16 + q * 4 + r) * FS;
-            su[r] = d0[r] * bu[row + j] + d1[r] * bu[row + 16 + j];
-            sv[r] = d0[r] * bv[row + j] + d1[r] * bv[row + 16 + j];
-        }
+        __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
+        if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
         const int pr = map_proj(mi);
 #pragma unroll
-        for (int p = 0; p < 4; p++) if (p == pr) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) { du[p][r] += su[r]; dv[p][r] += sv[r]; }
+        for (int r = 0; r < 4; r++) {
+            const int pt = wave * 16 + q * 4 + r, row = pt * FS;
+            const float su = d0[r] * bu[row + j] + d1[r] * bu[row + 16 + j];
+            const float sv = d0[r] * bv[row + j] + d1[r] * bv[row + 16 + j];
+            // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251)
+            if (pr == 0) {
+                const float x = sPt[pt * 3], y = sPt[pt * 3 + 1], iz = 1.0f / sPt[pt * 3 + 2];
+                gx[r] += su * kx * iz; gy[r] += sv * ky * iz; gz[r] -= (su * kx * x + sv * ky * y) * iz * iz;
+            } else if (pr == 1) { gz[r] += su; gy[r] += sv; }     // right (c2, c1)
+            else if (pr == 2) { gx[r] -= su; gy[r] += sv; }       // back  (-c0, c1)
+            else { gx[r] += su; gz[r] -= sv; }                    // top   (c0, -c2)
         }
+        __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffer free again
+        if (ci + 1 < NCHUNK) { int m2i, c2o; chunk_info(ci + 1, m2i, c2o); taps_issue(a, b, m2i, c2o, sUV, tid, tp); }
     }
+#undef SLAB_DMA
     // direct xyz features: d feat[608..610] = sum_g dh1 . W1(out,in)[:, 608..611]
     f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const float *w = a.hw[g].w1xoi + (j & 3);
-#pragma unroll 8
+#pragma unroll
         for (int s = 0; s < 16; s++) {
             const float b0 = j < 4 ? w[(8 * s + 2 * q) * 4] : 0.f, b1 = j < 4 ? w[(8 * s + 2 * q + 1) * 4] : 0.f;
             dz = MFMA16(ah[g][s].x, b0, dz); dz = MFMA16(ah[g][s].y, b1, dz);
@@ -465,28 +540,17 @@ __global__ __launch_bounds__(256, 2) void query_kernel(const QArgs a)
     }
     // reduce the channel partials over the 16 lanes that share a row group
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { du[p][r] += __shfl_xor(du[p][r], o, 64); dv[p][r] += __shfl_xor(dv[p][r], o, 64); }
+        for (int o = 1; o < 16; o <<= 1) { gx[r] += __shfl_xor(gx[r], o, 64); gy[r] += __shfl_xor(gy[r], o, 64); gz[r] += __shfl_xor(gz[r], o, 64); }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const float gy_d = __shfl(dz[r], (lane & 48) + 1, 64), gz_d = __shfl(dz[r], (lane & 48) + 2, 64);
         if (j == 0) {
             const int pt = wave * 16 + q * 4 + r, n = n0 + pt;
             if (n < a.N) {
-                const float x = sPt[pt * 3], y = sPt[pt * 3 + 1], z = sPt[pt * 3 + 2];
-                float gx = dz[r], gy = gy_d, gz = gz_d;
-                const float k = 2.0f / a.crop;
-                gx += du[0][r] * k * a.fx / z;
-                gy += dv[0][r] * k * a.fy / z;
-                gz += -du[0][r] * k * a.fx * x / (z * z) - dv[0][r] * k * a.fy * y / (z * z);
-                gz += du[1][r]; gy += dv[1][r];          // right (c2, c1)
-                gx -= du[2][r]; gy += dv[2][r];          // back  (-c0, c1)
-                gx += du[3][r]; gz -= dv[3][r];          // top   (c0, -c2)
                 float *o = a.dpts + ((size_t)b * a.N + n) * 3;
-                o[0] = gx; o[1] = gy; o[2] = gz;
+                o[0] = gx[r] + dz[r]; o[1] = gy[r] + gy_d; o[2] = gz[r] + gz_d;
             }
         }
     }
@@ -575,7 +639,7 @@ extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; hipFree(h->blo
 
 static size_t lds_bytes(int G)
 {
-    const size_t r0 = (size_t)G * 64 * HS > (size_t)4 * 64 * FS ? (size_t)G * 64 * HS : (size_t)4 * 64 * FS;
+    const size_t r0 = (size_t)G * 64 * HS > (size_t)2 * 64 * FS + G * 4096 ? (size_t)G * 64 * HS : (size_t)2 * 64 * FS + G * 4096;
     return sizeof(float) * (r0 + 64 * GS + 64 * 3 + 4 * 64 * 2 + 64) + 8 * sizeof(double);
 }
 
@@ -585,7 +649,7 @@ static int launch(const QArgs &a, hipStream_t st)
     const size_t lds = lds_bytes(G);
     static bool done = false;
     if (!done) { VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(query_kernel<G, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-    hipLaunchKernelGGL((query_kernel<G, MODE>), dim3((a.N + 63) / 64, a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((query_kernel<G, MODE>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, a);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
