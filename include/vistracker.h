@@ -198,15 +198,16 @@ int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int
  * Silhouette.  Replaces neural_renderer.Renderer(K, R=I, t=0, orig_size=1, anti_aliasing=False)(verts, faces,
  * mode='silhouettes') and its backward as used by SilLossROI.forward (recon/obj_pose_roi.py:77-94,183-207).
  * verts (B,NV,3) camera space, faces (NF,3) int32 shared, K (B,9), image (B,size,size) row 0 = top.
- * face_index (B,size,size) int32 and proj (B,NV,3) float are outputs the backward reads again
- * (face id in [0,2*NF) of the doubled fill_back list, -1 = background; projected vertices u,v in [-1,1], z).
+ * face_index (B,size,size) int32 (face id in [0,2*NF) of the doubled fill_back list, -1 = background) and the workspace
+ * `ws` (vt_sil_workspace_floats(B,NV,NF) floats: projected vertices, face corners, pixel boxes, visibility flags) are
+ * written by the forward and read again by the backward.
  * ------------------------------------------------------------------------------------------------- */
+long vt_sil_workspace_floats(int B, int NV, int NF);
 int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
-                   float *image, int *face_index, float *proj, void *stream);
-/* d_image (B,size,size) -> dverts (B,NV,3) (overwritten).  gproj (B,NV,2) float scratch. eps = NMR's 1e-4. */
+                   float *image, int *face_index, float *ws, void *stream);
+/* d_image (B,size,size) -> dverts (B,NV,3) (overwritten). eps = NMR's 1e-4. */
 int vt_sil_backward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
-                    const int *face_index, const float *proj, const float *d_image, float eps, float *gproj,
-                    float *dverts, void *stream);
+                    const int *face_index, const float *d_image, float eps, float *ws, float *dverts, void *stream);
 /* fused occlusion-aware mask term (obj_pose_roi.py:191-198; recon_fit_trivis_full.py:164-168):
  * per[b] = sum_px (keep*sil - ref)^2 ; *term += mean_b(per[b]*occ[b]); d_image = gscale * d/d sil */
 int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size,

@@ -8,7 +8,8 @@
 //                 nearest face wins; image row r shows yi = is - 1 - r; silhouette = coverage.
 //   backward    : Kato's edge-sweep surrogate gradient on the alpha channel.
 // MI355X mapping: VALU/LDS bound, no MFMA.  Forward = tile binning: one workgroup per 16x16 pixel tile culls the
-// 2*NF faces by bounding box into an LDS list, then each pixel tests only that list.  Backward = one thread per face.
+// faces into an LDS list from precomputed 8-byte pixel boxes, then each pixel tests only that list.  Backward = one wave per
+// visible face (faces that own no pixel are skipped).
 #include "common.h"
 
 #define SIL_NEAR 0.1f
@@ -38,24 +39,55 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
     fc[6] = pv[3 * i2]; fc[7] = pv[3 * i2 + 1]; fc[8] = pv[3 * i2 + 2];
 }
 
-__global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
-                                                         float *__restrict__ image, int *__restrict__ face_index)
+// workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
+// x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2)
+struct SilWs { float *proj, *fc; int2 *fbox; int *visible; float *gproj; };
+static inline SilWs sil_ws(float *ws, int B, int NV, int NF)
+{
+    SilWs w; w.proj = ws; w.fc = w.proj + (size_t)B * NV * 3; w.fbox = reinterpret_cast<int2 *>(w.fc + (size_t)B * 2 * NF * 9);
+    w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<float *>(w.visible + (size_t)B * 2 * NF);
+    return w;
+}
+extern "C" long vt_sil_workspace_floats(int B, int NV, int NF) { return (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 2 + 16; }
+
+// per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
+__global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
+                                      float *__restrict__ fcbuf, int2 *__restrict__ fbox, int *__restrict__ visible)
+{
+    const int f2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (f2 >= 2 * NF) return;
+    float fc[9]; load_face(proj + (size_t)b * NV * 3, faces, NF, f2, fc);
+    float *o = fcbuf + ((size_t)b * 2 * NF + f2) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; e++) o[e] = fc[e];
+    visible[(size_t)b * 2 * NF + f2] = 0;
+    int x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+    if (!((fc[7] - fc[1]) * (fc[3] - fc[0]) < (fc[4] - fc[1]) * (fc[6] - fc[0]))) {     // front side
+        const float xmin = fminf(fc[0], fminf(fc[3], fc[6])), xmax = fmaxf(fc[0], fmaxf(fc[3], fc[6]));
+        const float ymin = fminf(fc[1], fminf(fc[4], fc[7])), ymax = fmaxf(fc[1], fmaxf(fc[4], fc[7]));
+        // pixel centres xp = (2 xi + 1 - is)/is inside [xmin, xmax]  <=>  xi in [ceil((xmin is + is - 1)/2), floor((xmax is + is - 1)/2)];
+        // one pixel of slack each side keeps the box conservative under rounding
+        const float fx0 = fminf(fmaxf(floorf((xmin * is + is - 1) * 0.5f) - 1.f, -1.f), (float)is), fx1 = fminf(fmaxf(ceilf((xmax * is + is - 1) * 0.5f) + 1.f, -1.f), (float)is);
+        const float fy0 = fminf(fmaxf(floorf((ymin * is + is - 1) * 0.5f) - 1.f, -1.f), (float)is), fy1 = fminf(fmaxf(ceilf((ymax * is + is - 1) * 0.5f) + 1.f, -1.f), (float)is);
+        x0 = max((int)fx0, 0); x1 = min((int)fx1, is - 1); y0 = max((int)fy0, 0); y1 = min((int)fy1, is - 1);
+        if (y0 > y1) { x0 = 1; x1 = 0; }
+    }
+    fbox[(size_t)b * 2 * NF + f2] = make_int2((x0 & 0xffff) | (x1 << 16), (y0 & 0xffff) | (y1 << 16));
+}
+
+__global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
+                                                         float *__restrict__ image, int *__restrict__ face_index, int *__restrict__ visible)
 {
     __shared__ int list[MAXLIST];
     __shared__ int count;
     const int b = blockIdx.z, tx0 = blockIdx.x * TILE, ty0 = blockIdx.y * TILE;   // tile in internal (y-up) pixel coordinates
-    const float *pv = proj + (size_t)b * NV * 3;
     if (threadIdx.x == 0) count = 0;
     __syncthreads();
-    // tile bounds in normalised coordinates of pixel centres
-    const float txmin = (2.0f * tx0 + 1 - is) / is, txmax = (2.0f * (tx0 + TILE - 1) + 1 - is) / is;
-    const float tymin = (2.0f * ty0 + 1 - is) / is, tymax = (2.0f * (ty0 + TILE - 1) + 1 - is) / is;
+    const int2 *fb = fbox + (size_t)b * 2 * NF;
     for (int f2 = threadIdx.x; f2 < 2 * NF; f2 += 256) {
-        float fc[9]; load_face(pv, faces, NF, f2, fc);
-        if ((fc[7] - fc[1]) * (fc[3] - fc[0]) < (fc[4] - fc[1]) * (fc[6] - fc[0])) continue;   // back side
-        const float xmin = fminf(fc[0], fminf(fc[3], fc[6])), xmax = fmaxf(fc[0], fmaxf(fc[3], fc[6]));
-        const float ymin = fminf(fc[1], fminf(fc[4], fc[7])), ymax = fmaxf(fc[1], fmaxf(fc[4], fc[7]));
-        if (xmax < txmin || xmin > txmax || ymax < tymin || ymin > tymax) continue;
+        const int2 bb = fb[f2];
+        const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
+        if (x0 > x1 || x1 < tx0 || x0 > tx0 + TILE - 1 || y1 < ty0 || y0 > ty0 + TILE - 1) continue;
         const int slot = atomicAdd(&count, 1);
         if (slot < MAXLIST) list[slot] = f2;
     }
@@ -66,7 +98,7 @@ __global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict
     float zbest = SIL_FAR; int fbest = -1;
     for (int t = 0; t < n; t++) {
         const int f2 = list[t];
-        float fc[9]; load_face(pv, faces, NF, f2, fc);
+        const float *fc = fcbuf + ((size_t)b * 2 * NF + f2) * 9;
         if (((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
             ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
             ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7]))) continue;
@@ -85,24 +117,28 @@ __global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict
         const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;     // image row 0 = top
         image[o] = fbest >= 0 ? 1.0f : 0.0f;
         face_index[o] = fbest;
+        if (fbest >= 0) visible[(size_t)b * 2 * NF + fbest] = 1;        // benign race: every writer stores 1
     }
 }
 
 // Kato et al. edge-sweep surrogate gradient, one WAVE per (frame, doubled face): the walk along an edge (d0) is uniform,
 // the pixel sweeps away from / into the face (d1, up to `is` pixels) are spread over the 64 lanes.
 // Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
-__global__ __launch_bounds__(64) void sil_bwd_face_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
+__global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, float eps, float *__restrict__ gproj)
 {
-    const int f2 = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const float *pv = proj + (size_t)b * NV * 3;
+    // 4 waves per workgroup, one (frame, doubled face) per wave; faces that own no pixel contribute nothing (both sweeps are
+    // gated by face_index == f2) and leave at once
+    const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+    if (f2 >= 2 * NF || !visible[(size_t)b * 2 * NF + f2]) return;
     const int *fim = face_index + (size_t)b * is * is;
     const float *gal = d_image + (size_t)b * is * is;
     const int f = f2 < NF ? f2 : f2 - NF;
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
-    float fc[9]; load_face(pv, faces, NF, f2, fc);
-    if ((fc[7] - fc[1]) * (fc[3] - fc[0]) < (fc[4] - fc[1]) * (fc[6] - fc[0])) return;
+    float fc[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) fc[e] = fcbuf[((size_t)b * 2 * NF + f2) * 9 + e];
     float gface[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #define PIX(d0_, d1_, axis_) ((axis_) == 0 ? (size_t)(is - 1 - (d1_)) * is + (d0_) : (size_t)(is - 1 - (d0_)) * is + (d1_))
     for (int edge = 0; edge < 3; edge++) {
@@ -197,27 +233,31 @@ __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restr
 }
 
 extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, float *image,
-                              int *face_index, float *proj, void *stream)
+                              int *face_index, float *ws, void *stream)
 {
-    VT_REQUIRE(verts && faces && K && image && face_index && proj && B > 0 && NV > 0 && NF > 0 && size > 0 && size % TILE == 0,
+    VT_REQUIRE(verts && faces && K && image && face_index && ws && B > 0 && NV > 0 && NF > 0 && size > 0 && size % TILE == 0 && size < 32768,
                "vt_sil_forward: bad argument (size must be a multiple of %d)", TILE);
     hipStream_t st = vt_stream(stream);
-    hipLaunchKernelGGL(sil_project_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, proj);
+    const SilWs w = sil_ws(ws, B, NV, NF);
+    hipLaunchKernelGGL(sil_project_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.proj);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_raster_kernel, dim3(size / TILE, size / TILE, B), dim3(256), 0, st, proj, faces, NV, NF, size, image, face_index);
+    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_raster_kernel, dim3(size / TILE, size / TILE, B), dim3(256), 0, st, w.fc, w.fbox, NF, size, image, face_index, w.visible);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
 
 extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, const int *face_index,
-                               const float *proj, const float *d_image, float eps, float *gproj, float *dverts, void *stream)
+                               const float *d_image, float eps, float *ws, float *dverts, void *stream)
 {
-    VT_REQUIRE(verts && faces && K && face_index && proj && d_image && gproj && dverts && B > 0, "vt_sil_backward: bad argument");
+    VT_REQUIRE(verts && faces && K && face_index && d_image && ws && dverts && B > 0, "vt_sil_backward: bad argument");
     hipStream_t st = vt_stream(stream);
-    VT_HIP(hipMemsetAsync(gproj, 0, sizeof(float) * (size_t)B * NV * 2, st));
-    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3(2 * NF, B), dim3(64), 0, st, proj, faces, NV, NF, size, face_index, d_image, eps, gproj);
+    const SilWs w = sil_ws(ws, B, NV, NF);
+    VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(float) * (size_t)B * NV * 2, st));
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image, eps, w.gproj);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, gproj, dverts);
+    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

@@ -285,8 +285,9 @@ class FitContext:
         Rv, tv = obj_R.view(B, 9), obj_t
         if sil is not None:
             Vt = torch.empty(B, NV, 3, device=dev); dVt = torch.empty_like(Vt); img = torch.empty(B, sil.size, sil.size, device=dev)
-            fidx = torch.empty(B, sil.size, sil.size, dtype=torch.int32, device=dev); proj = torch.empty(B, NV, 3, device=dev)
-            gproj = torch.empty(B, NV, 2, device=dev); dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
+            fidx = torch.empty(B, sil.size, sil.size, dtype=torch.int32, device=dev)
+            sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0]), device=dev)
+            dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
         adam = None; res = FitResult(); contact = None; trans_init = None
         for it in range(start, end):
             if it < iter_for_obj:
@@ -327,11 +328,11 @@ class FitContext:
                 if phase == "sil":
                     _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vt.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
-                                               img.data_ptr(), fidx.data_ptr(), proj.data_ptr(), L.stream_ptr()))
+                                               img.data_ptr(), fidx.data_ptr(), sws.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
                                                  terms.ptr("mask"), per.data_ptr(), dimg.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_sil_backward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
-                                                fidx.data_ptr(), proj.data_ptr(), dimg.data_ptr(), 1e-4, gproj.data_ptr(), dVt.data_ptr(), L.stream_ptr()))
+                                                fidx.data_ptr(), dimg.data_ptr(), 1e-4, sws.data_ptr(), dVt.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_rigid_backward(self.obj_verts.data_ptr(), 1, obj_s.data_ptr(), B, NV, dVt.data_ptr(), dR.data_ptr(), dt.data_ptr(), 0, L.stream_ptr()))
                     _chk(_lib().vt_sqdiff_loss(obj_t.data_ptr(), 3, trans_init.data_ptr(), 3, B, 3, float(B * 3), float(w[4]), terms.ptr("trans"), dt.data_ptr(), L.stream_ptr()))
                     acc = 1

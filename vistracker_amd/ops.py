@@ -386,19 +386,19 @@ class _SilFn(torch.autograd.Function):
         verts, K = _f32(verts), _f32(K); B, NV = verts.shape[:2]; NF = faces.shape[0]
         img = torch.empty(B, size, size, device=verts.device)
         fidx = torch.empty(B, size, size, dtype=torch.int32, device=verts.device)
-        proj = torch.empty(B, NV, 3, device=verts.device)
-        L.check(L.lib().vt_sil_forward(L.dptr(verts), B, NV, L.dptr(faces), NF, L.dptr(K), size, L.dptr(img), L.dptr(fidx), L.dptr(proj), L.stream_ptr()))
-        ctx.save_for_backward(verts, faces, K, fidx, proj); ctx.size, ctx.eps = size, eps
+        ws = torch.empty(L.lib().vt_sil_workspace_floats(B, NV, NF), device=verts.device)
+        L.check(L.lib().vt_sil_forward(L.dptr(verts), B, NV, L.dptr(faces), NF, L.dptr(K), size, L.dptr(img), L.dptr(fidx), L.dptr(ws), L.stream_ptr()))
+        ctx.save_for_backward(verts, faces, K, fidx, ws); ctx.size, ctx.eps = size, eps
         return img
 
     @staticmethod
     def backward(ctx, dimg):
-        verts, faces, K, fidx, proj = ctx.saved_tensors
+        verts, faces, K, fidx, ws = ctx.saved_tensors
         B, NV = verts.shape[:2]
         dimg = _f32(dimg)
-        gproj = torch.empty(B, NV, 2, device=verts.device); dverts = torch.empty_like(verts)
-        L.check(L.lib().vt_sil_backward(L.dptr(verts), B, NV, L.dptr(faces), faces.shape[0], L.dptr(K), ctx.size, L.dptr(fidx), L.dptr(proj),
-                                        L.dptr(dimg), ctx.eps, L.dptr(gproj), L.dptr(dverts), L.stream_ptr()))
+        dverts = torch.empty_like(verts)
+        L.check(L.lib().vt_sil_backward(L.dptr(verts), B, NV, L.dptr(faces), faces.shape[0], L.dptr(K), ctx.size, L.dptr(fidx),
+                                        L.dptr(dimg), ctx.eps, L.dptr(ws), L.dptr(dverts), L.stream_ptr()))
         return dverts, None, None, None, None
 
 
