@@ -199,10 +199,11 @@ int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int
  * mode='silhouettes') and its backward as used by SilLossROI.forward (recon/obj_pose_roi.py:77-94,183-207).
  * verts (B,NV,3) camera space, faces (NF,3) int32 shared, K (B,9), image (B,size,size) row 0 = top.
  * face_index (B,size,size) int32 (face id in [0,2*NF) of the doubled fill_back list, -1 = background) and the workspace
- * `ws` (vt_sil_workspace_floats(B,NV,NF) floats: projected vertices, face corners, pixel boxes, visibility flags) are
+ * `ws` (vt_sil_workspace_floats(B,NV,NF,size) floats: depth keys, sweep masks, projected vertices, face corners, pixel boxes,
+ * visibility flags) are
  * written by the forward and read again by the backward.
  * ------------------------------------------------------------------------------------------------- */
-long vt_sil_workspace_floats(int B, int NV, int NF);
+long vt_sil_workspace_floats(int B, int NV, int NF, int size);
 int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
                    float *image, int *face_index, float *ws, void *stream);
 /* d_image (B,size,size) -> dverts (B,NV,3) (overwritten). eps = NMR's 1e-4. */

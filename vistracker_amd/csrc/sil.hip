@@ -7,7 +7,7 @@
 //                 centre ((2 xi + 1 - is)/is, (2 yi + 1 - is)/is) is inside the triangle and near < z < far;
 //                 nearest face wins; image row r shows yi = is - 1 - r; silhouette = coverage.
 //   backward    : Kato's edge-sweep surrogate gradient on the alpha channel.
-// MI355X mapping: VALU/LDS bound, no MFMA.  Forward = tile binning: one workgroup per 16x16 pixel tile culls the
+// MI355X mapping: VALU/latency bound, no MFMA.  Forward = per-face scatter with 64-bit atomicMin depth keys (was: tile binning, the
 // faces into an LDS list from precomputed 8-byte pixel boxes, then each pixel tests only that list.  Backward = one wave per
 // visible face (faces that own no pixel are skipped).
 #include "common.h"
@@ -41,14 +41,22 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
 
 // workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
 // x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2)
-struct SilWs { float *proj, *fc; int2 *fbox; int *visible; float *gproj; };
-static inline SilWs sil_ws(float *ws, int B, int NV, int NF)
+struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; float *gproj; };
+static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
 {
-    SilWs w; w.proj = ws; w.fc = w.proj + (size_t)B * NV * 3; w.fbox = reinterpret_cast<int2 *>(w.fc + (size_t)B * 2 * NF * 9);
+    SilWs w;
+    w.zbuf = reinterpret_cast<unsigned long long *>(ws);                       // (B,is,is) depth|face keys, internal y-up order
+    w.rowmask = w.zbuf + (size_t)B * is * is;                                  // (B,is,is/64) bit xi of row yi: uncovered pixel with d_image < 0
+    w.colmask = w.rowmask + (size_t)B * is * (is / 64);                        // (B,is,is/64) bit yi of column xi
+    w.proj = reinterpret_cast<float *>(w.colmask + (size_t)B * is * (is / 64));
+    w.fc = w.proj + (size_t)B * NV * 3; w.fbox = reinterpret_cast<int2 *>(w.fc + (size_t)B * 2 * NF * 9);
     w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<float *>(w.visible + (size_t)B * 2 * NF);
     return w;
 }
-extern "C" long vt_sil_workspace_floats(int B, int NV, int NF) { return (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 2 + 16; }
+extern "C" long vt_sil_workspace_floats(int B, int NV, int NF, int size)
+{
+    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 2 + 16;
+}
 
 // per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
 __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
@@ -75,64 +83,85 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
     fbox[(size_t)b * 2 * NF + f2] = make_int2((x0 & 0xffff) | (x1 << 16), (y0 & 0xffff) | (y1 << 16));
 }
 
-__global__ __launch_bounds__(256) void sil_raster_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
-                                                         float *__restrict__ image, int *__restrict__ face_index, int *__restrict__ visible)
+// Rasterisation by SCATTER: one wave per (frame, front face) visits only the pixels of the face's box (a 2500-face object covers
+// each pixel ~twice, so this is ~35x fewer point-in-triangle tests than testing every pixel against a per-tile face list) and
+// resolves visibility with a 64-bit atomicMin on key = (bits of z) << 32 | face id: nearest face wins, ties go to the smaller id.
+__global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
+                                                          unsigned long long *__restrict__ zbuf)
 {
-    __shared__ int list[MAXLIST];
-    __shared__ int count;
-    const int b = blockIdx.z, tx0 = blockIdx.x * TILE, ty0 = blockIdx.y * TILE;   // tile in internal (y-up) pixel coordinates
-    if (threadIdx.x == 0) count = 0;
-    __syncthreads();
-    const int2 *fb = fbox + (size_t)b * 2 * NF;
-    for (int f2 = threadIdx.x; f2 < 2 * NF; f2 += 256) {
-        const int2 bb = fb[f2];
-        const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
-        if (x0 > x1 || x1 < tx0 || x0 > tx0 + TILE - 1 || y1 < ty0 || y0 > ty0 + TILE - 1) continue;
-        const int slot = atomicAdd(&count, 1);
-        if (slot < MAXLIST) list[slot] = f2;
-    }
-    __syncthreads();
-    const int n = min(count, MAXLIST);
-    const int xi = tx0 + (threadIdx.x & (TILE - 1)), yi = ty0 + (threadIdx.x >> 4);
-    const float xp = (2.0f * xi + 1 - is) / is, yp = (2.0f * yi + 1 - is) / is;
-    float zbest = SIL_FAR; int fbest = -1;
-    for (int t = 0; t < n; t++) {
-        const int f2 = list[t];
-        const float *fc = fcbuf + ((size_t)b * 2 * NF + f2) * 9;
+    const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+    if (f2 >= 2 * NF) return;
+    const int2 bb = fbox[(size_t)b * 2 * NF + f2];
+    const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
+    if (x0 > x1) return;
+    float fc[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) fc[e] = fcbuf[((size_t)b * 2 * NF + f2) * 9 + e];
+    const float den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
+    if (den == 0.f) return;
+    const int w = x1 - x0 + 1, npx = w * (y1 - y0 + 1);
+    for (int p = lane; p < npx; p += 64) {
+        const int xi = x0 + p % w, yi = y0 + p / w;
+        const float xp = (2.0f * xi + 1 - is) / is, yp = (2.0f * yi + 1 - is) / is;
         if (((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
             ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
             ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7]))) continue;
-        const float den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
-        if (den == 0.f) continue;
         float w0 = ((fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4])) / den;
         float w1 = ((fc[7] - fc[1]) * xp + (fc[0] - fc[6]) * yp + (fc[6] * fc[1] - fc[0] * fc[7])) / den;
         float w2 = ((fc[1] - fc[4]) * xp + (fc[3] - fc[0]) * yp + (fc[0] * fc[4] - fc[3] * fc[1])) / den;
         w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
         const float ws = w0 + w1 + w2;
         const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);
-        if (zp <= SIL_NEAR || zp >= SIL_FAR) continue;
-        if (zp < zbest || (zp == zbest && (fbest < 0 || f2 < fbest))) { zbest = zp; fbest = f2; }
-    }
-    if (xi < is && yi < is) {
-        const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;     // image row 0 = top
-        image[o] = fbest >= 0 ? 1.0f : 0.0f;
-        face_index[o] = fbest;
-        if (fbest >= 0) visible[(size_t)b * 2 * NF + fbest] = 1;        // benign race: every writer stores 1
+        if (!(zp > SIL_NEAR && zp < SIL_FAR)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f2;     // zp > 0: float order == uint order
+        atomicMin(zbuf + ((size_t)b * is + yi) * is + xi, key);
     }
 }
 
-// Kato et al. edge-sweep surrogate gradient, one WAVE per (frame, doubled face): the walk along an edge (d0) is uniform,
-// the pixel sweeps away from / into the face (d1, up to `is` pixels) are spread over the 64 lanes.
+__global__ void sil_resolve_kernel(const unsigned long long *__restrict__ zbuf, int NF, int is, float *__restrict__ image,
+                                   int *__restrict__ face_index, int *__restrict__ visible)
+{
+    const int xi = blockIdx.x * blockDim.x + threadIdx.x, yi = blockIdx.y, b = blockIdx.z;
+    if (xi >= is) return;
+    const unsigned long long key = zbuf[((size_t)b * is + yi) * is + xi];
+    const int f = key == ~0ull ? -1 : (int)(unsigned)(key & 0xffffffffull);
+    const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;     // image row 0 = top
+    image[o] = f >= 0 ? 1.0f : 0.0f;
+    face_index[o] = f;
+    if (f >= 0) visible[(size_t)b * 2 * NF + f] = 1;                // benign race: every writer stores 1
+}
+
+// bit masks of the pixels that can contribute to an outward sweep: uncovered and d_image < 0 (then (alpha - 1) * g > 0)
+__global__ __launch_bounds__(64) void sil_sweep_mask_kernel(const int *__restrict__ face_index, const float *__restrict__ d_image, int is,
+                                                            unsigned long long *__restrict__ rowmask, unsigned long long *__restrict__ colmask)
+{
+    const int word = blockIdx.x, line = blockIdx.y, b = blockIdx.z, k = word * 64 + threadIdx.x;
+    const int wpl = is / 64;
+    {   // row `line` (yi), bit xi = k
+        const size_t o = ((size_t)b * is + (is - 1 - line)) * is + k;
+        const unsigned long long m = __ballot(face_index[o] < 0 && d_image[o] < 0.f);
+        if (threadIdx.x == 0) rowmask[((size_t)b * is + line) * wpl + word] = m;
+    }
+    {   // column `line` (xi), bit yi = k
+        const size_t o = ((size_t)b * is + (is - 1 - k)) * is + line;
+        const unsigned long long m = __ballot(face_index[o] < 0 && d_image[o] < 0.f);
+        if (threadIdx.x == 0) colmask[((size_t)b * is + line) * wpl + word] = m;
+    }
+}
+
+// Kato et al. edge-sweep surrogate gradient, one wave per (frame, visible doubled face).  The six (edge, axis) walks are uniform;
+// lanes take the positions d0 along the edge.  The outward sweep of a position only visits the pixels flagged in the sweep masks
+// (exactly the pixels whose term is non-zero), the inward sweep is bounded by the face itself.
 // Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
 __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
-                                    const int *__restrict__ face_index, const float *__restrict__ d_image, float eps, float *__restrict__ gproj)
+                                    const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
+                                    const unsigned long long *__restrict__ colmask, float eps, float *__restrict__ gproj)
 {
-    // 4 waves per workgroup, one (frame, doubled face) per wave; faces that own no pixel contribute nothing (both sweeps are
-    // gated by face_index == f2) and leave at once
     const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
     if (f2 >= 2 * NF || !visible[(size_t)b * 2 * NF + f2]) return;
     const int *fim = face_index + (size_t)b * is * is;
     const float *gal = d_image + (size_t)b * is * is;
+    const int wpl = is / 64;
     const int f = f2 < NF ? f2 : f2 - NF;
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
@@ -152,38 +181,46 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
             if (axis == 0) direction = (p[0][0] < p[1][0]) ? -1 : 1; else direction = (p[0][0] < p[1][0]) ? 1 : -1;
             const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f);
             const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
-            for (int d0 = d0_from; d0 <= d0_to; d0++) {
+            const unsigned long long *masks = (axis == 0 ? colmask : rowmask) + (size_t)b * is * wpl;
+            for (int d0 = d0_from + lane; d0 <= d0_to; d0 += 64) {
                 const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
                 const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
                 const int d1_out = d1_in + direction;
                 if (d1_in < 0 || is <= d1_in) continue;
                 if (d1_out < 0 || is <= d1_out) continue;
                 const size_t idx_in = PIX(d0, d1_in, axis), idx_out = PIX(d0, d1_out, axis);
-                const float alpha_in = fim[idx_in] >= 0 ? 1.f : 0.f, alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
-                if (fim[idx_in] == f2) {   // sweep outwards from the edge
+                const float alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
+                const float sA = (p[1][0] != d0) ? (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f / is : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
+                const float sB = (p[0][0] != d0) ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f / is : 0.f;   // ... for corner 1
+                if (fim[idx_in] == f2) {   // sweep outwards from the edge: only flagged pixels have a non-zero term (alpha_in = 1)
                     const int d1_limit = (0 < direction) ? is - 1 : 0;
                     const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
-                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
-                        const size_t idx = PIX(d0, d1, axis);
-                        const float diff_grad = ((fim[idx] >= 0 ? 1.f : 0.f) - alpha_in) * gal[idx];
-                        if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) { float dist = (p[1][0] - p[0][0]) / (p[1][0] - d0) * (d1 - d1_cross) * 2.0f / is; dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
-                        if (p[0][0] != d0) { float dist = (p[1][0] - p[0][0]) / (d0 - p[0][0]) * (d1 - d1_cross) * 2.0f / is; dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
+                    for (int wd = d1_from >> 6; wd <= (d1_to >> 6); wd++) {
+                        unsigned long long bits = masks[(size_t)d0 * wpl + wd];
+                        const int lo = max(d1_from - wd * 64, 0), hi = min(d1_to - wd * 64, 63);
+                        bits &= (~0ull << lo) & (~0ull >> (63 - hi));
+                        while (bits) {
+                            const int d1 = wd * 64 + __ffsll((long long)bits) - 1; bits &= bits - 1;
+                            const float diff_grad = -gal[PIX(d0, d1, axis)];
+                            if (diff_grad <= 0) continue;
+                            if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
+                            if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
+                        }
                     }
                 }
-                {                           // sweep inwards over this face's own pixels
+                if (alpha_out == 0.f) {     // sweep inwards over this face's own pixels ((1 - alpha_out) * g vanishes otherwise)
                     float d0_cross2;
                     if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) d0_cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
                     else d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
                     const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
                     const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
-                    for (int d1 = d1_from + lane; d1 <= d1_to; d1 += 64) {
+                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
                         const size_t idx = PIX(d0, d1, axis);
                         if (fim[idx] != f2) continue;
-                        const float diff_grad = (1.f - alpha_out) * gal[idx];
+                        const float diff_grad = gal[idx];
                         if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) { float dist = (p[1][0] - p[0][0]) / (p[1][0] - d0) * (d1 - d1_cross) * 2.0f / is; dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
-                        if (p[0][0] != d0) { float dist = (p[1][0] - p[0][0]) / (d0 - p[0][0]) * (d1 - d1_cross) * 2.0f / is; dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
+                        if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
+                        if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
                     }
                 }
             }
@@ -236,14 +273,18 @@ extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *face
                               int *face_index, float *ws, void *stream)
 {
     VT_REQUIRE(verts && faces && K && image && face_index && ws && B > 0 && NV > 0 && NF > 0 && size > 0 && size % TILE == 0 && size < 32768,
-               "vt_sil_forward: bad argument (size must be a multiple of %d)", TILE);
+               "vt_sil_forward: bad argument (size must be a multiple of 64)");
+    VT_REQUIRE(size % 64 == 0, "vt_sil_forward: size must be a multiple of 64");
     hipStream_t st = vt_stream(stream);
-    const SilWs w = sil_ws(ws, B, NV, NF);
+    const SilWs w = sil_ws(ws, B, NV, NF, size);
     hipLaunchKernelGGL(sil_project_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.proj);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_raster_kernel, dim3(size / TILE, size / TILE, B), dim3(256), 0, st, w.fc, w.fbox, NF, size, image, face_index, w.visible);
+    VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B * size * size, st));
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -253,9 +294,12 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
 {
     VT_REQUIRE(verts && faces && K && face_index && d_image && ws && dverts && B > 0, "vt_sil_backward: bad argument");
     hipStream_t st = vt_stream(stream);
-    const SilWs w = sil_ws(ws, B, NV, NF);
+    const SilWs w = sil_ws(ws, B, NV, NF, size);
     VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(float) * (size_t)B * NV * 2, st));
-    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image, eps, w.gproj);
+    hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3(size / 64, size, B), dim3(64), 0, st, face_index, d_image, size, w.rowmask, w.colmask);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
+                       w.rowmask, w.colmask, eps, w.gproj);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts);
     VT_LAUNCH_CHECK();

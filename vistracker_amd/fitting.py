@@ -286,7 +286,7 @@ class FitContext:
         if sil is not None:
             Vt = torch.empty(B, NV, 3, device=dev); dVt = torch.empty_like(Vt); img = torch.empty(B, sil.size, sil.size, device=dev)
             fidx = torch.empty(B, sil.size, sil.size, dtype=torch.int32, device=dev)
-            sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0]), device=dev)
+            sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0], sil.size), device=dev)
             dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
         adam = None; res = FitResult(); contact = None; trans_init = None
         for it in range(start, end):

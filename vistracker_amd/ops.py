@@ -386,7 +386,7 @@ class _SilFn(torch.autograd.Function):
         verts, K = _f32(verts), _f32(K); B, NV = verts.shape[:2]; NF = faces.shape[0]
         img = torch.empty(B, size, size, device=verts.device)
         fidx = torch.empty(B, size, size, dtype=torch.int32, device=verts.device)
-        ws = torch.empty(L.lib().vt_sil_workspace_floats(B, NV, NF), device=verts.device)
+        ws = torch.empty(L.lib().vt_sil_workspace_floats(B, NV, NF, size), device=verts.device)
         L.check(L.lib().vt_sil_forward(L.dptr(verts), B, NV, L.dptr(faces), NF, L.dptr(K), size, L.dptr(img), L.dptr(fidx), L.dptr(ws), L.stream_ptr()))
         ctx.save_for_backward(verts, faces, K, fidx, ws); ctx.size, ctx.eps = size, eps
         return img
