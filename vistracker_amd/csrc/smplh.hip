@@ -2,11 +2,11 @@
 //
 // Replaces SMPL_Layer.forward (lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:73-176) and the autograd
 // backward the reference gets from ~15k eager ops per call.  Layout decisions (DESIGN.md "SMPL-H"):
-//   * model constants are re-laid out once at handle creation so that a thread == a vertex reads coalesced:
-//       posedirs  -> P_kcv [459][3][VP]   (forward, k-major)   and kept as P_vck [V*3][459] (backward, thread == k)
-//       shapedirs -> S_lcv [10][3][VP]                         and S_vcl [V*3][10]
-//       weights   -> W_jv  [52][VP]
-//     VP = 6912 = 27 * 256 (zero padded) so every workgroup is full.
+//   * blend shapes are ONE matrix: v_posed = [pose_map(459) | betas(10) | 1] . Q with Q = [posedirs ; shapedirs ; template]
+//     (472 rows after zero padding).  It is kept in two layouts so that both GEMMs read row-contiguous MFMA B fragments:
+//       Q_kcv [472][3][VP]   forward  (M = frames, N = vertices, K = 472)
+//       Q_t   [VP*3][480]    backward (M = frames, N = 472 blend columns, K = vertex coordinates), d[pose_map | betas] in one GEMM
+//     both run on v_mfma_f32_16x16x4_f32.  weights -> W_jv [52][VP].  VP = 6912 = 27 * 256 (zero padded).
 //   * the joint regressor is folded on the host: J = J_t + J_s . beta (J = Jreg . v_shaped is linear in beta),
 //     which removes the 52x6890 reduction from every call.
 //   * forward = 2 launches (pose/chain, vertices); backward = 2 launches (vertex tile partials, per-frame
@@ -19,6 +19,10 @@
 #define NP_ VT_SMPL_NP
 #define VP_ 6912
 #define NVT_ 27 /* vertex tiles of 256 */
+#define KQ_ 472 /* 459 pose-map + 10 betas + 1 template + 2 zero rows */
+#define NQ_ 480 /* padded row length of Q_t (30 N-tiles) */
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // per-frame workspace layout (floats)
 #define WS_R 0
@@ -36,7 +40,7 @@
 struct SmplParents { int p[J_]; };
 
 struct vt_smplh {
-    float *P_kcv, *P_vck, *S_lcv, *S_vcl, *T_cv, *W_jv, *J_t, *J_s;
+    float *Q_kcv, *Q_t, *W_jv, *W_v64, *J_t, *J_s;
     SmplParents par;
 };
 
@@ -161,94 +165,119 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward, launch 2: thread == vertex, FB frames per workgroup.  blend shapes + LBS fused
-// (smpl_layer.py:103-112,145-173).  P is streamed once per FB frames, coalesced.
+// forward, launch 2: blend shapes as an MFMA GEMM + LBS (smpl_layer.py:103-112,145-173).
+// Workgroup = 64 vertices x 16 frames; wave w owns vertices 16w..16w+15.  D layout: lane (q = lane>>4, j = lane&15) holds
+// v_posed of vertex j for frames 4q..4q+3 and all three coordinates, so skinning continues in-lane (dense 52-joint LBS with
+// the frame's A matrices broadcast from LDS).
 // ---------------------------------------------------------------------------------------------------
-template <int FB>
-__global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ P_kcv, const float *__restrict__ S_lcv,
-                                                          const float *__restrict__ T_cv, const float *__restrict__ W_jv,
+#define FWD_FB 16
+#define AXS 516   /* LDS stride of an extended pose row [pose_map | betas | 1 | 0 0]: 516 mod 64 = 4 -> conflict-free ds_read_b64 */
+#define SAS 628   /* LDS stride of a frame's 52 x 12 A matrices */
+__global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ Q_kcv, const float *__restrict__ W_jv,
                                                           const float *__restrict__ betas, const float *__restrict__ trans,
                                                           const float *__restrict__ ws, int B,
                                                           float *__restrict__ verts, float *__restrict__ v_posed)
 {
-    __shared__ __attribute__((aligned(16))) float pmT[NP_ * FB];
-    __shared__ __attribute__((aligned(16))) float sA[FB * 624];
-    __shared__ float sBeta[FB * NB_], sTr[FB * 3];
-    const int tid = threadIdx.x, b0 = blockIdx.y * FB, v = blockIdx.x * 256 + tid;
-    for (int i = tid; i < NP_ * FB; i += 256) {
-        const int k = i / FB, f = i % FB, b = min(b0 + f, B - 1), e = k % 9;
-        pmT[i] = ws[(size_t)b * WS_FRAME + WS_R + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sAx = lds;                       // [16][AXS] extended pose rows (GEMM phase) ...
+    float *sA = lds;                        // ... then [16][SAS] A matrices (skinning phase)
+    float *sVp = lds + FWD_FB * SAS;        // [16][64][3] v_posed hand-over
+    float *sW = sVp + FWD_FB * 64 * 3;      // [52][64] skinning weights of the tile
+    float *sTr = sW + J_ * 64;              // [16][3]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int b0 = blockIdx.y * FWD_FB, v = blockIdx.x * 64 + wave * 16 + j;
+    for (int i = tid; i < FWD_FB * KQ_; i += 256) {
+        const int f = i / KQ_, k = i % KQ_, b = min(b0 + f, B - 1);
+        float val;
+        if (k < NP_) { const int e = k % 9; val = ws[(size_t)b * WS_FRAME + WS_R + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
+        else if (k < NP_ + NB_) val = betas[b * NB_ + (k - NP_)];
+        else val = (k == NP_ + NB_) ? 1.f : 0.f;
+        sAx[f * AXS + k] = val;
     }
-    for (int i = tid; i < FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[i] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
-    if (tid < FB * NB_) { const int f = tid / NB_, b = min(b0 + f, B - 1); sBeta[tid] = betas[b * NB_ + tid % NB_]; }
-    if (tid < FB * 3) { const int f = tid / 3, b = min(b0 + f, B - 1); sTr[tid] = trans[b * 3 + tid % 3]; }
+    for (int i = tid; i < J_ * 64; i += 256) sW[i] = W_jv[(i >> 6) * VP_ + blockIdx.x * 64 + (i & 63)];
+    if (tid < FWD_FB * 3) { const int f = tid / 3, b = min(b0 + f, B - 1); sTr[tid] = trans[b * 3 + tid % 3]; }
     __syncthreads();
 
-    float acc[FB][3];
-    {
-        const float t0 = T_cv[v], t1 = T_cv[VP_ + v], t2 = T_cv[2 * VP_ + v];
+    // v_posed[f][v][c] = sum_k Aext[f][k] Q[k][c][v]:  A = pose rows (LDS), B = Q rows (global, 64-B segments), 59 pair steps
+    f32x4 acc[3];
 #pragma unroll
-        for (int f = 0; f < FB; f++) { acc[f][0] = t0; acc[f][1] = t1; acc[f][2] = t2; }
+    for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int s = 0; s < KQ_ / 8; s++) {
+        const float2 av = *reinterpret_cast<const float2 *>(sAx + j * AXS + 8 * s + 2 * q);
+        const float *qk = Q_kcv + (size_t)(8 * s + 2 * q) * 3 * VP_ + v;
+        float bq[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) bq[e][c] = qk[(size_t)(e * 3 + c) * VP_];
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.x, bq[0][c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.y, bq[1][c], acc[c]);
     }
+    // hand v_posed over through LDS so that skinning runs with thread == vertex and a wave-uniform frame: the frame's A
+    // matrices are then true LDS broadcasts and nothing is indexed dynamically in registers
+    __syncthreads();                        // every wave is done with sAx: the region becomes sA
 #pragma unroll
-    for (int l = 0; l < NB_; l++) {
-        const float s0 = S_lcv[(l * 3 + 0) * VP_ + v], s1 = S_lcv[(l * 3 + 1) * VP_ + v], s2 = S_lcv[(l * 3 + 2) * VP_ + v];
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int f = 0; f < FB; f++) { const float bl = sBeta[f * NB_ + l]; acc[f][0] += s0 * bl; acc[f][1] += s1 * bl; acc[f][2] += s2 * bl; }
-    }
-#pragma unroll 4
-    for (int k = 0; k < NP_; k++) {
-        const float p0 = P_kcv[(size_t)(k * 3 + 0) * VP_ + v], p1 = P_kcv[(size_t)(k * 3 + 1) * VP_ + v], p2 = P_kcv[(size_t)(k * 3 + 2) * VP_ + v];
-#pragma unroll
-        for (int f = 0; f < FB; f++) { const float m = pmT[k * FB + f]; acc[f][0] += p0 * m; acc[f][1] += p1 * m; acc[f][2] += p2 * m; }
-    }
-    float w[J_];
-#pragma unroll
-    for (int j = 0; j < J_; j++) w[j] = W_jv[j * VP_ + v];
-#pragma unroll
-    for (int f = 0; f < FB; f++) {
+        for (int c = 0; c < 3; c++) sVp[((4 * q + r) * 64 + wave * 16 + j) * 3 + c] = acc[c][r];
+    for (int i = tid; i < FWD_FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[f * SAS + (i % 624)] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
+    __syncthreads();
+    const int vv = tid & 63, vg = blockIdx.x * 64 + vv;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        const int f = 4 * wave + r, b = b0 + f;
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; e++) T[e] = 0.f;
-#pragma unroll
-        for (int j = 0; j < J_; j++) {
-#pragma unroll
-            for (int e = 0; e < 12; e++) T[e] += w[j] * sA[f * 624 + j * 12 + e];
+        const float4 *Af = reinterpret_cast<const float4 *>(sA + f * SAS);
+#pragma unroll 4
+        for (int jj = 0; jj < J_; jj++) {
+            const float wj = sW[jj * 64 + vv];
+            const float4 a0 = Af[jj * 3], a1 = Af[jj * 3 + 1], a2 = Af[jj * 3 + 2];
+            T[0] += wj * a0.x; T[1] += wj * a0.y; T[2] += wj * a0.z; T[3] += wj * a0.w;
+            T[4] += wj * a1.x; T[5] += wj * a1.y; T[6] += wj * a1.z; T[7] += wj * a1.w;
+            T[8] += wj * a2.x; T[9] += wj * a2.y; T[10] += wj * a2.z; T[11] += wj * a2.w;
         }
-        const int b = b0 + f;
-        if (b < B && v < V_) {
-            const size_t o = ((size_t)b * V_ + v) * 3;
+        if (b < B && vg < V_) {
+            const float p0 = sVp[(f * 64 + vv) * 3], p1 = sVp[(f * 64 + vv) * 3 + 1], p2 = sVp[(f * 64 + vv) * 3 + 2];
+            const size_t o = ((size_t)b * V_ + vg) * 3;
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-                verts[o + r] = T[r * 4] * acc[f][0] + T[r * 4 + 1] * acc[f][1] + T[r * 4 + 2] * acc[f][2] + T[r * 4 + 3] + sTr[f * 3 + r];
-                v_posed[o + r] = acc[f][r];
-            }
+            for (int rr = 0; rr < 3; rr++) verts[o + rr] = T[rr * 4] * p0 + T[rr * 4 + 1] * p1 + T[rr * 4 + 2] * p2 + T[rr * 4 + 3] + sTr[f * 3 + rr];
+            v_posed[o] = p0; v_posed[o + 1] = p1; v_posed[o + 2] = p2;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward, launch 1: per (vertex tile, FB frames) partial sums of dA (624), dtrans (3), dpose_map (459), dbetas (10)
+// backward, launch 1: per (256-vertex tile, FB frames) partial sums of dA (52x12), dtrans (3), d pose_map (459), d betas (10).
+//   phase 1 (thread == vertex): T_rot = sum_j W A_j, d v_posed = T_rot^T dv, dT = dv (x) [v_posed; 1]          -> LDS
+//   phase 2 (MFMA, per frame):  dA[e][j] = sum_v dT[v][e] W[v][j]   M = 12 (->16), N = 52 joints + a ones column (dtrans) (->64), K = 256
+//   phase 3 (MFMA, all frames): d[pose_map | betas][f][n] = sum_r dvp[f][r] Q_t[r][n]   M = FB (->16), N = 480, K = 768
 // ---------------------------------------------------------------------------------------------------
-#define WLD 257 /* padded row of the weight tile in LDS: bank = (j + v) % 32 */
 template <int FB>
-__global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ P_vck, const float *__restrict__ S_vcl,
-                                                             const float *__restrict__ W_jv, const float *__restrict__ ws,
+__global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ Q_t, const float *__restrict__ W_jv,
+                                                             const float *__restrict__ W_v64, const float *__restrict__ ws,
                                                              const float *__restrict__ v_posed, const float *__restrict__ dverts,
                                                              int B, float *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *sW = lds;                         // [52][WLD]
-    float *sdT = sW + J_ * WLD;              // [256][13]
+    float *sdT = lds;                        // [256][13]
     float *sdvp = sdT + 256 * 13;            // [768][FB]
     float *sA = sdvp + 768 * FB;             // [FB][624]
     const int tid = threadIdx.x, tile = blockIdx.x, b0 = blockIdx.y * FB, v0 = tile * 256, v = v0 + tid;
-    for (int i = tid; i < J_ * 256; i += 256) { const int j = i >> 8, vv = i & 255; sW[j * WLD + vv] = W_jv[j * VP_ + v0 + vv]; }
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     for (int i = tid; i < FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[i] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
+    float wv[J_];                            // skinning weights of this thread's vertex: loaded once, reused by all FB frames
+#pragma unroll
+    for (int jj = 0; jj < J_; jj++) wv[jj] = W_jv[jj * VP_ + v];
     __syncthreads();
+#pragma unroll 1
     for (int f = 0; f < FB; f++) {
         const int b = b0 + f;
-        // phase 1: thread == vertex
+        // phase 1
         float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
         if (b < B && v < V_) {
             const size_t o = ((size_t)b * V_ + v) * 3;
@@ -258,9 +287,10 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
         float T[9];
 #pragma unroll
         for (int e = 0; e < 9; e++) T[e] = 0.f;
-        for (int j = 0; j < J_; j++) {
-            const float wj = sW[j * WLD + tid];
-            const float *A = sA + f * 624 + j * 12;
+#pragma unroll
+        for (int jj = 0; jj < J_; jj++) {
+            const float wj = wv[jj];
+            const float *A = sA + f * 624 + jj * 12;
 #pragma unroll
             for (int r = 0; r < 3; r++) { T[r * 3] += wj * A[r * 4]; T[r * 3 + 1] += wj * A[r * 4 + 1]; T[r * 3 + 2] += wj * A[r * 4 + 2]; }
         }
@@ -272,49 +302,58 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
 #pragma unroll
         for (int c = 0; c < 3; c++) sdvp[(tid * 3 + c) * FB + f] = T[c] * dv[0] + T[3 + c] * dv[1] + T[6 + c] * dv[2];
         __syncthreads();
-        // phase 2: thread == output element of dA (j,e) or dtrans
-        if (b < B) {
-            float *dst = part + ((size_t)tile * B + b) * PT_N;
-            for (int o = tid; o < 627; o += 256) {
-                float s = 0.f;
-                if (o < 624) {
-                    const int j = o / 12, e = o % 12;
-                    const float *wr = sW + j * WLD;
-#pragma unroll 8
-                    for (int vv = 0; vv < 256; vv++) s += wr[vv] * sdT[vv * 13 + e];
-                } else {
-                    const int e = (o - 624) * 4 + 3;
-#pragma unroll 8
-                    for (int vv = 0; vv < 256; vv++) s += sdT[vv * 13 + e];
+        // phase 2: wave w owns joints 16w..16w+15 (column 52 of W_v64 is all ones: its "joint" collects dtrans)
+        {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float *wb = W_v64 + (size_t)v0 * 64 + wave * 16 + j;
+#pragma unroll 4
+            for (int ks = 0; ks < 64; ks += 2) {
+                const int va = 4 * ks + q, vb = va + 4;
+                const float a0 = j < 12 ? sdT[va * 13 + j] : 0.f, a1 = j < 12 ? sdT[vb * 13 + j] : 0.f;
+                acc = MFMA16(a0, wb[(size_t)va * 64], acc);
+                acc2 = MFMA16(a1, wb[(size_t)vb * 64], acc2);
+            }
+            acc += acc2;
+            if (b < B) {
+                float *dst = part + ((size_t)tile * B + b) * PT_N;
+                const int jn = wave * 16 + j;                // joint (column of D); rows of D = e = 4q + r
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int e = 4 * q + r;
+                    if (e < 12) {
+                        if (jn < J_) dst[PT_DA + jn * 12 + e] = acc[r];
+                        else if (jn == J_ && (e & 3) == 3) dst[PT_DTR + (e >> 2)] = acc[r];
+                    }
                 }
-                dst[o] = s;
             }
         }
         __syncthreads();
     }
-    // phase 3: thread == pose-map / beta column, reduction over the tile's 768 (vertex, coord) rows
-    for (int k = tid; k < 469; k += 256) {
-        float acc[FB];
-#pragma unroll
-        for (int f = 0; f < FB; f++) acc[f] = 0.f;
+    // phase 3: d[pose_map | betas][f][n] = sum_r dvp[f][r] Q_t[r][n] over the tile's 768 (vertex, coord) rows as an MFMA GEMM:
+    // M = FB frames (rows >= FB are zero padding), N = 480 = 30 N-tiles dealt round-robin to the 4 waves, K = 768.
+    {
         const int nrow = min(768, V_ * 3 - v0 * 3);
-        if (k < NP_) {
-            const float *src = P_vck + (size_t)v0 * 3 * NP_ + k;
-            for (int r = 0; r < nrow; r++) {
-                const float p = src[(size_t)r * NP_];
+        f32x4 acc[8];
 #pragma unroll
-                for (int f = 0; f < FB; f++) acc[f] += p * sdvp[r * FB + f];
-            }
-        } else {
-            const float *src = S_vcl + (size_t)v0 * 3 * NB_ + (k - NP_);
-            for (int r = 0; r < nrow; r++) {
-                const float p = src[(size_t)r * NB_];
+        for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *qb = Q_t + (size_t)v0 * 3 * NQ_ + j;
+#pragma unroll 6
+        for (int ks = 0; ks < 192; ks++) {
+            const int r = 4 * ks + q;
+            const float av = (j < FB && r < nrow) ? sdvp[r * FB + j] : 0.f;
+            const float *row = qb + (size_t)min(r, nrow - 1) * NQ_;
 #pragma unroll
-                for (int f = 0; f < FB; f++) acc[f] += p * sdvp[r * FB + f];
+            for (int t = 0; t < 8; t++) { const int nt = wave + 4 * t; if (nt < 30) acc[t] = MFMA16(av, row[nt * 16], acc[t]); }
+        }
+        // D: rows = frames 4q+r, cols = n = nt*16 + j
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int nt = wave + 4 * t, n = nt * 16 + j;
+            if (nt < 30 && n < NP_ + NB_) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int f = 4 * q + r; if (f < FB && b0 + f < B) part[((size_t)tile * B + b0 + f) * PT_N + PT_DPM + n] = acc[t][r]; }
             }
         }
-#pragma unroll
-        for (int f = 0; f < FB; f++) if (b0 + f < B) part[((size_t)tile * B + b0 + f) * PT_N + PT_DPM + k] = acc[f];
     }
 }
 
@@ -406,34 +445,37 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
     vt_smplh *h = new vt_smplh();
     for (int j = 0; j < J_; j++) h->par.p[j] = (j == 0) ? 0 : parents[j];
     for (int j = 1; j < J_; j++) VT_REQUIRE(h->par.p[j] >= 0 && h->par.p[j] < j, "vt_smplh_create: parents[%d]=%d must be in [0,%d)", j, parents[j], j);
-    float *P_kcv = new float[(size_t)NP_ * 3 * VP_](), *S_lcv = new float[(size_t)NB_ * 3 * VP_](), *T_cv = new float[3 * VP_](),
-          *W_jv = new float[(size_t)J_ * VP_](), *J_t = new float[J_ * 3], *J_s = new float[J_ * 3 * NB_];
+    float *Q_kcv = new float[(size_t)KQ_ * 3 * VP_](), *Q_t = new float[(size_t)VP_ * 3 * NQ_](), *W_jv = new float[(size_t)J_ * VP_](),
+          *J_t = new float[J_ * 3], *J_s = new float[J_ * 3 * NB_];
     for (int v = 0; v < V_; v++) for (int c = 0; c < 3; c++) {
-        T_cv[c * VP_ + v] = v_template[v * 3 + c];
-        for (int l = 0; l < NB_; l++) S_lcv[(size_t)(l * 3 + c) * VP_ + v] = shapedirs[((size_t)v * 3 + c) * NB_ + l];
-        for (int k = 0; k < NP_; k++) P_kcv[(size_t)(k * 3 + c) * VP_ + v] = posedirs[((size_t)v * 3 + c) * NP_ + k];
+        for (int k = 0; k < NP_ + NB_ + 1; k++) {
+            const float val = k < NP_ ? posedirs[((size_t)v * 3 + c) * NP_ + k]
+                            : (k < NP_ + NB_ ? shapedirs[((size_t)v * 3 + c) * NB_ + (k - NP_)] : v_template[v * 3 + c]);
+            Q_kcv[(size_t)(k * 3 + c) * VP_ + v] = val;
+            Q_t[((size_t)v * 3 + c) * NQ_ + k] = val;       // column 469 (template) is computed but never used by the backward
+        }
     }
-    for (int v = 0; v < V_; v++) for (int j = 0; j < J_; j++) W_jv[(size_t)j * VP_ + v] = weights[(size_t)v * J_ + j];
+    float *W_v64 = new float[(size_t)VP_ * 64]();
+    for (int v = 0; v < V_; v++) { for (int j = 0; j < J_; j++) { W_jv[(size_t)j * VP_ + v] = weights[(size_t)v * J_ + j]; W_v64[(size_t)v * 64 + j] = weights[(size_t)v * J_ + j]; } W_v64[(size_t)v * 64 + J_] = 1.0f; }
     for (int j = 0; j < J_; j++) for (int c = 0; c < 3; c++) {
-        double a = 0; double s[NB_] = {0};
+        double a = 0; double sb[NB_] = {0};
         for (int v = 0; v < V_; v++) {
             const double r = J_regressor[(size_t)j * V_ + v];
             if (r == 0.0) continue;
             a += r * v_template[v * 3 + c];
-            for (int l = 0; l < NB_; l++) s[l] += r * shapedirs[((size_t)v * 3 + c) * NB_ + l];
+            for (int l = 0; l < NB_; l++) sb[l] += r * shapedirs[((size_t)v * 3 + c) * NB_ + l];
         }
         J_t[j * 3 + c] = (float)a;
-        for (int l = 0; l < NB_; l++) J_s[(j * 3 + c) * NB_ + l] = (float)s[l];
+        for (int l = 0; l < NB_; l++) J_s[(j * 3 + c) * NB_ + l] = (float)sb[l];
     }
     int rc = VT_OK;
-    if ((rc = vt_upload(&h->P_kcv, P_kcv, (size_t)NP_ * 3 * VP_, st)) || (rc = vt_upload(&h->P_vck, posedirs, (size_t)V_ * 3 * NP_, st)) ||
-        (rc = vt_upload(&h->S_lcv, S_lcv, (size_t)NB_ * 3 * VP_, st)) || (rc = vt_upload(&h->S_vcl, shapedirs, (size_t)V_ * 3 * NB_, st)) ||
-        (rc = vt_upload(&h->T_cv, T_cv, (size_t)3 * VP_, st)) || (rc = vt_upload(&h->W_jv, W_jv, (size_t)J_ * VP_, st)) ||
+    if ((rc = vt_upload(&h->Q_kcv, Q_kcv, (size_t)KQ_ * 3 * VP_, st)) || (rc = vt_upload(&h->Q_t, Q_t, (size_t)VP_ * 3 * NQ_, st)) ||
+        (rc = vt_upload(&h->W_jv, W_jv, (size_t)J_ * VP_, st)) || (rc = vt_upload(&h->W_v64, W_v64, (size_t)VP_ * 64, st)) ||
         (rc = vt_upload(&h->J_t, J_t, (size_t)J_ * 3, st)) || (rc = vt_upload(&h->J_s, J_s, (size_t)J_ * 3 * NB_, st))) {
         return rc;
     }
     VT_HIP(hipStreamSynchronize(st));  // host staging buffers are freed below
-    delete[] P_kcv; delete[] S_lcv; delete[] T_cv; delete[] W_jv; delete[] J_t; delete[] J_s;
+    delete[] Q_kcv; delete[] Q_t; delete[] W_jv; delete[] W_v64; delete[] J_t; delete[] J_s;
     *out = h;
     return VT_OK;
 }
@@ -441,15 +483,14 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
 extern "C" void vt_smplh_destroy(vt_smplh *h)
 {
     if (!h) return;
-    hipFree(h->P_kcv); hipFree(h->P_vck); hipFree(h->S_lcv); hipFree(h->S_vcl); hipFree(h->T_cv); hipFree(h->W_jv); hipFree(h->J_t); hipFree(h->J_s);
+    hipFree(h->Q_kcv); hipFree(h->Q_t); hipFree(h->W_jv); hipFree(h->W_v64); hipFree(h->J_t); hipFree(h->J_s);
     delete h;
 }
 
 extern "C" long vt_smplh_workspace_floats(int B) { return (long)B * WS_FRAME; }
 extern "C" long vt_smplh_bwd_scratch_floats(int B) { return (long)NVT_ * B * PT_N; }
 
-#define FWD_FB 8
-#define BWD_FB 4
+#define BWD_FB 8
 
 extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const float *betas, const float *trans, int B,
                                 float *verts, float *jtr, float *v_posed, float *ws, void *stream)
@@ -458,8 +499,14 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
     hipStream_t st = vt_stream(stream);
     hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smplh_verts_kernel<FWD_FB>, dim3(NVT_, (B + FWD_FB - 1) / FWD_FB), dim3(256), 0, st, h->P_kcv, h->S_lcv, h->T_cv,
-                       h->W_jv, betas, trans, ws, B, verts, v_posed);
+    const size_t lds_f = sizeof(float) * (FWD_FB * SAS + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3);
+    static bool attr_f = false;
+    if (!attr_f) {
+        VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_verts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        attr_f = true;
+    }
+    hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
+                       verts, v_posed);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -471,13 +518,13 @@ extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const flo
     (void)betas;
     VT_REQUIRE(h && pose && dverts && v_posed && ws && scratch && dpose && dbetas && dtrans && B > 0, "vt_smplh_backward: null argument or B <= 0");
     hipStream_t st = vt_stream(stream);
-    const size_t lds = sizeof(float) * (J_ * WLD + 256 * 13 + 768 * BWD_FB + BWD_FB * 624);
+    const size_t lds = sizeof(float) * (256 * 13 + 768 * BWD_FB + BWD_FB * 624);
     static bool attr_done = false;
     if (!attr_done) {
         VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_bwd_tile_kernel<BWD_FB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->P_vck, h->S_vcl, h->W_jv, ws,
+    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->Q_t, h->W_jv, h->W_v64, ws,
                        v_posed, dverts, B, scratch);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, djtr, B, dpose, dbetas, dtrans);
