@@ -5,7 +5,8 @@
 //   * blend shapes are ONE matrix: v_posed = [pose_map(459) | betas(10) | 1] . Q with Q = [posedirs ; shapedirs ; template]
 //     (472 rows after zero padding).  It is kept in two layouts so that both GEMMs read row-contiguous MFMA B fragments:
 //       Q_kcv [472][3][VP]   forward  (M = frames, N = vertices, K = 472)
-//       Q_t   [VP*3][480]    backward (M = frames, N = 472 blend columns, K = vertex coordinates), d[pose_map | betas] in one GEMM
+//       Q_t   [1296 K groups][30 N tiles][64 lanes][4]   backward split-K GEMM (M = frames, N = 472 blend columns, K = vertex
+//             coordinates), stored in MFMA fragment order so that one float4 per lane feeds 4 K steps: d[pose_map | betas]
 //     both run on v_mfma_f32_16x16x4_f32.  weights -> W_jv [52][VP].  VP = 6912 = 27 * 256 (zero padded).
 //   * the joint regressor is folded on the host: J = J_t + J_s . beta (J = Jreg . v_shaped is linear in beta),
 //     which removes the 52x6890 reduction from every call.
@@ -33,9 +34,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // per (tile, frame) partial layout of the backward
 #define PT_DA 0
 #define PT_DTR 624
-#define PT_DPM 627
-#define PT_DB (627 + 459)
-#define PT_N (627 + 469) /* 1096 */
+#define PT_N 627
+#define KTOT_ (VP_ * 3)              /* 20736 rows of the backward blend-shape GEMM */
+#define KG_SLAB 24                   /* 16-row K groups per split-K slab (384 rows) */
+#define NKS_ (KTOT_ / 16 / KG_SLAB)  /* 54 slabs */
 
 struct SmplParents { int p[J_]; };
 
@@ -252,66 +254,86 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward, launch 1: per (256-vertex tile, FB frames) partial sums of dA (52x12), dtrans (3), d pose_map (459), d betas (10).
-//   phase 1 (thread == vertex): T_rot = sum_j W A_j, d v_posed = T_rot^T dv, dT = dv (x) [v_posed; 1]          -> LDS
+// backward, launch 1: per (256-vertex tile, FB frames): partial sums of dA (52x12) and dtrans (3); d v_posed to global.
+//   phase 1 (MFMA, per frame):  T[v][e] = sum_j W[v][j] A_j[e]   M = the wave's 64 vertices, N = 12 (->16), K = 52 joints;
+//                               d v_posed[v] = T_rot^T dv[v] -> dvp_g [B][20736] (the A operand of launch 2)
 //   phase 2 (MFMA, per frame):  dA[e][j] = sum_v dT[v][e] W[v][j]   M = 12 (->16), N = 52 joints + a ones column (dtrans) (->64), K = 256
-//   phase 3 (MFMA, all frames): d[pose_map | betas][f][n] = sum_r dvp[f][r] Q_t[r][n]   M = FB (->16), N = 480, K = 768
+//   with dT[v] = dv[v] (x) [v_posed[v]; 1] staged in LDS by thread == vertex.  The weight fragments of both phases are frame
+//   independent and live in registers (116 VGPRs) across the FB frames.
 // ---------------------------------------------------------------------------------------------------
 template <int FB>
-__global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ Q_t, const float *__restrict__ W_jv,
-                                                             const float *__restrict__ W_v64, const float *__restrict__ ws,
+__global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ W_v64, const float *__restrict__ ws,
                                                              const float *__restrict__ v_posed, const float *__restrict__ dverts,
-                                                             int B, float *__restrict__ part)
+                                                             int B, float *__restrict__ part, float *__restrict__ dvp_g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *sdT = lds;                        // [256][13]
-    float *sdvp = sdT + 256 * 13;            // [768][FB]
-    float *sA = sdvp + 768 * FB;             // [FB][624]
+    float *sdT = lds;                        // [256][13]  dT rows of the frame in flight: dv (x) [v_posed; 1]
+    float *sA = sdT + 256 * 13;              // [FB][624]  skinning transforms A_j (3x4) of the block's frames
     const int tid = threadIdx.x, tile = blockIdx.x, b0 = blockIdx.y * FB, v0 = tile * 256, v = v0 + tid;
     const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     for (int i = tid; i < FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[i] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
-    float wv[J_];                            // skinning weights of this thread's vertex: loaded once, reused by all FB frames
+    // Both MFMA phases read the skinning weights of this tile only; they do not depend on the frame, so each lane keeps its
+    // fragments in registers for all FB frames:
+    //   w1[mt][ks] = W[v0 + 64 wave + 16 mt + j][4 ks + q]   (phase 1, A operand: M = the wave's own 64 vertices, K = joints)
+    //   w2[ks]     = W[v0 + 4 ks + q][16 wave + j]           (phase 2, B operand: K = the tile's 256 vertices, N = joints)
+    float w1[4][13], w2[64];
 #pragma unroll
-    for (int jj = 0; jj < J_; jj++) wv[jj] = W_jv[jj * VP_ + v];
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int ks = 0; ks < 13; ks++) w1[mt][ks] = W_v64[(size_t)(v0 + 64 * wave + 16 * mt + j) * 64 + 4 * ks + q];
+#pragma unroll
+    for (int ks = 0; ks < 64; ks++) w2[ks] = W_v64[(size_t)(v0 + 4 * ks + q) * 64 + wave * 16 + j];
+    // (phase 1's K = 52 joints is exactly 13 steps: the all-ones column 52 of W_v64, phase 2's dtrans collector, is never touched)
     __syncthreads();
 #pragma unroll 1
     for (int f = 0; f < FB; f++) {
         const int b = b0 + f;
-        // phase 1
         float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
         if (b < B && v < V_) {
             const size_t o = ((size_t)b * V_ + v) * 3;
             dv[0] = dverts[o]; dv[1] = dverts[o + 1]; dv[2] = dverts[o + 2];
             vp[0] = v_posed[o]; vp[1] = v_posed[o + 1]; vp[2] = v_posed[o + 2];
         }
-        float T[9];
-#pragma unroll
-        for (int e = 0; e < 9; e++) T[e] = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < J_; jj++) {
-            const float wj = wv[jj];
-            const float *A = sA + f * 624 + jj * 12;
-#pragma unroll
-            for (int r = 0; r < 3; r++) { T[r * 3] += wj * A[r * 4]; T[r * 3 + 1] += wj * A[r * 4 + 1]; T[r * 3 + 2] += wj * A[r * 4 + 2]; }
-        }
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             sdT[tid * 13 + r * 4 + 0] = dv[r] * vp[0]; sdT[tid * 13 + r * 4 + 1] = dv[r] * vp[1];
             sdT[tid * 13 + r * 4 + 2] = dv[r] * vp[2]; sdT[tid * 13 + r * 4 + 3] = dv[r];
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) sdvp[(tid * 3 + c) * FB + f] = T[c] * dv[0] + T[3 + c] * dv[1] + T[6 + c] * dv[2];
         __syncthreads();
-        // phase 2: wave w owns joints 16w..16w+15 (column 52 of W_v64 is all ones: its "joint" collects dtrans)
+        // phase 1 (MFMA): T[v][e] = sum_j W[v][j] A_j[e]  (e = 4 r + c), then d v_posed[v][c] = sum_r T[v][4r + c] dv[v][r]:
+        // lane (q, e) of M-tile mt holds T for vertices 16 mt + 4 q + reg; it scales by dv[.][e >> 2] (column 3 of the dT row)
+        // and the three r-lanes of a column c are summed with two in-row shuffles.
+        {
+            f32x4 t[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) t[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 13; ks++) {
+                const float bv = j < 12 ? sA[f * 624 + (4 * ks + q) * 12 + j] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) t[mt] = MFMA16(w1[mt][ks], bv, t[mt]);
+            }
+            const int r4 = (j < 12 ? (j >> 2) : 0) * 4 + 3;
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int vl = 64 * wave + 16 * mt + 4 * q + r;
+                    float x = t[mt][r] * sdT[vl * 13 + r4];
+                    x += __shfl_down(x, 4, 16) + __shfl_down(x, 8, 16);
+                    if (j < 3 && b < B) dvp_g[(size_t)b * KTOT_ + (size_t)(v0 + vl) * 3 + j] = x;   // zero on the padding vertices
+                }
+            }
+        }
+        // phase 2 (MFMA): dA[e][jn] = sum_v dT[v][e] W[v][jn]; wave w owns joints 16w..16w+15
         {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float *wb = W_v64 + (size_t)v0 * 64 + wave * 16 + j;
-#pragma unroll 4
+#pragma unroll
             for (int ks = 0; ks < 64; ks += 2) {
                 const int va = 4 * ks + q, vb = va + 4;
                 const float a0 = j < 12 ? sdT[va * 13 + j] : 0.f, a1 = j < 12 ? sdT[vb * 13 + j] : 0.f;
-                acc = MFMA16(a0, wb[(size_t)va * 64], acc);
-                acc2 = MFMA16(a1, wb[(size_t)vb * 64], acc2);
+                acc = MFMA16(a0, w2[ks], acc);
+                acc2 = MFMA16(a1, w2[ks + 1], acc2);
             }
             acc += acc2;
             if (b < B) {
@@ -329,44 +351,77 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
         }
         __syncthreads();
     }
-    // phase 3: d[pose_map | betas][f][n] = sum_r dvp[f][r] Q_t[r][n] over the tile's 768 (vertex, coord) rows as an MFMA GEMM:
-    // M = FB frames (rows >= FB are zero padding), N = 480 = 30 N-tiles dealt round-robin to the 4 waves, K = 768.
-    {
-        const int nrow = min(768, V_ * 3 - v0 * 3);
-        f32x4 acc[8];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, launch 2: d[pose_map | betas][b][n] = sum_k dvp[b][k] Q[k][n] as one split-K fp32 MFMA GEMM over the whole batch:
+// M = frames (96 per block: 6 M-tiles), N = 480 (4 column blocks of 8 N-tiles, 2 per wave), K = 20736 in 54 slabs of 384 rows.
+// Within a 16-row K group lane (j,q) takes rows 16g + 4q + s for MFMA step s on BOTH operands (a sum over K does not care
+// about the order), so one float4 feeds 4 steps: A from the LDS-staged dvp rows, B from Q packed in exactly that fragment order.
+// ---------------------------------------------------------------------------------------------------
+#define BL_M 96
+#define BL_AS 132   /* LDS row stride of the staged A chunk (128 k + 4: stride = 4 mod 64 banks) */
+__global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__restrict__ Q_p, const float *__restrict__ dvp_g, int B,
+                                                              float *__restrict__ part3)
+{
+    __shared__ __attribute__((aligned(16))) float sA[BL_M * BL_AS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int ks = blockIdx.x, m0 = blockIdx.z * BL_M, nt0 = blockIdx.y * 8 + wave * 2;
+    const bool v0 = nt0 < NQ_ / 16, v1 = nt0 + 1 < NQ_ / 16;
+    f32x4 acc[6][2];
 #pragma unroll
-        for (int t = 0; t < 8; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float *qb = Q_t + (size_t)v0 * 3 * NQ_ + j;
-#pragma unroll 6
-        for (int ks = 0; ks < 192; ks++) {
-            const int r = 4 * ks + q;
-            const float av = (j < FB && r < nrow) ? sdvp[r * FB + j] : 0.f;
-            const float *row = qb + (size_t)min(r, nrow - 1) * NQ_;
-#pragma unroll
-            for (int t = 0; t < 8; t++) { const int nt = wave + 4 * t; if (nt < 30) acc[t] = MFMA16(av, row[nt * 16], acc[t]); }
+    for (int mt = 0; mt < 6; mt++) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float4 *Q4 = reinterpret_cast<const float4 *>(Q_p);
+#pragma unroll 1
+    for (int c = 0; c < KG_SLAB / 8; c++) {
+        __syncthreads();
+        for (int i = tid; i < BL_M * 32; i += 256) {
+            const int row = i >> 5, c4 = i & 31, b = m0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < B) v = *reinterpret_cast<const float4 *>(dvp_g + (size_t)b * KTOT_ + (size_t)(ks * KG_SLAB + c * 8) * 16 + c4 * 4);
+            *reinterpret_cast<float4 *>(sA + row * BL_AS + c4 * 4) = v;
         }
-        // D: rows = frames 4q+r, cols = n = nt*16 + j
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int nt = wave + 4 * t, n = nt * 16 + j;
-            if (nt < 30 && n < NP_ + NB_) {
+        for (int g = 0; g < 8; g++) {
+            const size_t kg = (size_t)ks * KG_SLAB + c * 8 + g;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 f0 = Q4[(kg * (NQ_ / 16) + min(nt0, NQ_ / 16 - 1)) * 64 + lane], f1 = Q4[(kg * (NQ_ / 16) + min(nt0 + 1, NQ_ / 16 - 1)) * 64 + lane];
+            const float bq0[4] = {f0.x, f0.y, f0.z, f0.w}, bq1[4] = {f1.x, f1.y, f1.z, f1.w};
+            (void)z4;
 #pragma unroll
-                for (int r = 0; r < 4; r++) { const int f = 4 * q + r; if (f < FB && b0 + f < B) part[((size_t)tile * B + b0 + f) * PT_N + PT_DPM + n] = acc[t][r]; }
+            for (int mt = 0; mt < 6; mt++) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(sA + (mt * 16 + j) * BL_AS + g * 16 + q * 4);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int s = 0; s < 4; s++) { acc[mt][0] = MFMA16(av[s], bq0[s], acc[mt][0]); acc[mt][1] = MFMA16(av[s], bq1[s], acc[mt][1]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int b = m0 + mt * 16 + 4 * q + r;
+            if (b < B) {
+                float *dst = part3 + ((size_t)ks * B + b) * NQ_;
+                if (v0) dst[nt0 * 16 + j] = acc[mt][0][r];
+                if (v1) dst[(nt0 + 1) * 16 + j] = acc[mt][1][r];
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward, launch 2: per frame -- reduce the 27 tile partials, VJP of A, chain, pose map, rodrigues, joints
+// backward, launch 3: per frame -- reduce the 27 tile partials and the 54 K-slab partials, VJP of A, chain, pose map, rodrigues, joints
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__restrict__ pose, const float *__restrict__ J_s,
                                                               SmplParents par, const float *__restrict__ ws,
-                                                              const float *__restrict__ part, const float *__restrict__ djtr,
-                                                              int B, float *__restrict__ dpose, float *__restrict__ dbetas,
+                                                              const float *__restrict__ part, const float *__restrict__ part3,
+                                                              const float *__restrict__ djtr, int B, float *__restrict__ dpose, float *__restrict__ dbetas,
                                                               float *__restrict__ dtrans)
 {
-    __shared__ float red[PT_N];
+    __shared__ float red[PT_N], red3[NQ_];
     __shared__ float sdG[J_ * 12], sdJ[J_ * 3], sdR[J_ * 9];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *w = ws + (size_t)b * WS_FRAME;
@@ -374,6 +429,11 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
         float s = 0.f;
         for (int t = 0; t < NVT_; t++) s += part[((size_t)t * B + b) * PT_N + i];
         red[i] = s;
+    }
+    for (int i = tid; i < NQ_; i += 256) {
+        float s = 0.f;
+        for (int t = 0; t < NKS_; t++) s += part3[((size_t)t * B + b) * NQ_ + i];
+        red3[i] = s;
     }
     __syncthreads();
     if (tid < J_) {
@@ -418,12 +478,12 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
         const int j = tid;
         float g[9], t[3] = {pose[(b * J_ + j) * 3], pose[(b * J_ + j) * 3 + 1], pose[(b * J_ + j) * 3 + 2]}, d[3];
 #pragma unroll
-        for (int e = 0; e < 9; e++) g[e] = sdR[9 * j + e] + (j >= 1 ? red[PT_DPM + (j - 1) * 9 + e] : 0.f);
+        for (int e = 0; e < 9; e++) g[e] = sdR[9 * j + e] + (j >= 1 ? red3[(j - 1) * 9 + e] : 0.f);
         rodrigues_bwd(t, g, d);
         dpose[(b * J_ + j) * 3] = d[0]; dpose[(b * J_ + j) * 3 + 1] = d[1]; dpose[(b * J_ + j) * 3 + 2] = d[2];
     } else if (tid >= 64 && tid < 64 + NB_) {
         const int l = tid - 64;
-        float s = red[PT_DB + l];
+        float s = red3[NP_ + l];
         for (int i = 0; i < J_ * 3; i++) s += J_s[i * NB_ + l] * sdJ[i];
         dbetas[b * NB_ + l] = s;
     } else if (tid >= 128 && tid < 131) {
@@ -452,7 +512,10 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
             const float val = k < NP_ ? posedirs[((size_t)v * 3 + c) * NP_ + k]
                             : (k < NP_ + NB_ ? shapedirs[((size_t)v * 3 + c) * NB_ + (k - NP_)] : v_template[v * 3 + c]);
             Q_kcv[(size_t)(k * 3 + c) * VP_ + v] = val;
-            Q_t[((size_t)v * 3 + c) * NQ_ + k] = val;       // column 469 (template) is computed but never used by the backward
+            {   // fragment-ordered Q for the backward GEMM: [k group][N tile][lane = (q, j)][step s] <- row 16g + 4q + s, column 16nt + j
+                const size_t kr = (size_t)v * 3 + c, g = kr >> 4, qq = (kr & 15) >> 2, ss = kr & 3;
+                Q_t[((g * (NQ_ / 16) + (k >> 4)) * 64 + qq * 16 + (k & 15)) * 4 + ss] = val;   // column 469 (template) is never used
+            }
         }
     }
     float *W_v64 = new float[(size_t)VP_ * 64]();
@@ -488,7 +551,7 @@ extern "C" void vt_smplh_destroy(vt_smplh *h)
 }
 
 extern "C" long vt_smplh_workspace_floats(int B) { return (long)B * WS_FRAME; }
-extern "C" long vt_smplh_bwd_scratch_floats(int B) { return (long)NVT_ * B * PT_N; }
+extern "C" long vt_smplh_bwd_scratch_floats(int B) { return (long)NVT_ * B * PT_N + (long)B * KTOT_ + (long)NKS_ * B * NQ_; }
 
 #define BWD_FB 8
 
@@ -518,16 +581,18 @@ extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const flo
     (void)betas;
     VT_REQUIRE(h && pose && dverts && v_posed && ws && scratch && dpose && dbetas && dtrans && B > 0, "vt_smplh_backward: null argument or B <= 0");
     hipStream_t st = vt_stream(stream);
-    const size_t lds = sizeof(float) * (256 * 13 + 768 * BWD_FB + BWD_FB * 624);
+    const size_t lds = sizeof(float) * (256 * 13 + BWD_FB * 624);
+    float *dvp_g = scratch + (size_t)NVT_ * B * PT_N, *part3 = dvp_g + (size_t)B * KTOT_;
     static bool attr_done = false;
     if (!attr_done) {
         VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_bwd_tile_kernel<BWD_FB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->Q_t, h->W_jv, h->W_v64, ws,
-                       v_posed, dverts, B, scratch);
+    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->W_v64, ws, v_posed, dverts, B, scratch, dvp_g);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, djtr, B, dpose, dbetas, dtrans);
+    hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, 4, (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, part3, djtr, B, dpose, dbetas, dtrans);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
