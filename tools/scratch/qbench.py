@@ -3,7 +3,8 @@ import sys, ctypes as C; sys.path.insert(0, '/root/repo'); sys.path.insert(0, '.
 import numpy as np, torch
 import torch.nn.functional as F
 from vistracker_amd import ops, synthetic as syn, _lib as L
-B, N = 96, 6890
+import os
+B, N = int(os.environ.get("QB", 96)), int(os.environ.get("QN", 6890))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 mode = sys.argv[2] if len(sys.argv) > 2 else "human"
 dev = "cuda"
@@ -14,7 +15,7 @@ for name, c, res, _ in syn.MAP_SPECS:
     maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
 fm = ops.FeatureMaps(maps)
 net = ops.SifNetHandle(syn.sifnet_decoders(3))
-if mode == "object":
+if mode == "object" and "QN" not in os.environ:
     N = 3000
 pts = (torch.randn(B, N, 3, device=dev, generator=g) * 0.3 + torch.tensor([0, 0, 2.2], device=dev)).contiguous()
 cc = torch.tensor([[1018.952, 779.486]] * B, device=dev); bc = torch.tensor([[0, 0, 2.2]] * B, device=dev)
@@ -33,3 +34,23 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = (4 * ((611*128 + 2*128*128 + 128*2) + (611*128 + 2*128*128 + 128*14)) if mode == "human" else 4 * (611*128 + 2*128*128 + 128*2)) * B * N
 print(f"{mode}: {ms:.3f} ms/launch  {fl/ms/1e9:.1f} TFLOP/s  ({fl/ms/1e9/157.3*100:.1f}% of fp32 MFMA peak)")
+if len(sys.argv) > 3 and sys.argv[3] == "det":
+    outs = []
+    for i in range(6):
+        dp.zero_(); terms.zero_(); run(); torch.cuda.synchronize(); outs.append((dp.clone(), terms.clone()))
+    for i in range(1, 6):
+        d = (outs[i][0] - outs[0][0]).abs()
+        nz = (d > 0).nonzero()
+        print("run", i, "max diff", d.max().item(), "n diff", nz.shape[0], "terms diff", (outs[i][1] - outs[0][1]).abs().max().item(), nz[:5].tolist() if nz.shape[0] else "")
+    d = (outs[1][0] - outs[0][0]).abs() > 0
+    print("per component", d.sum((0,1)).tolist())
+    n = torch.arange(N, device=dev)
+    for w in range(4): print("wave", w, d[:, (n % 64)//16 == w].sum().item())
+    print("per frame", d.sum((1,2))[:16].tolist())
+    dd_ = (outs[1][0] - outs[0][0]).abs().flatten()
+    qs = torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999], device=dev)
+    srt = dd_.sort().values
+    print("abs diff quantiles", [srt[int(q * (srt.numel() - 1))].item() for q in qs.tolist()], "max", srt[-1].item())
+    big = ((outs[1][0] - outs[0][0]).abs() > 1e-5).nonzero()
+    print("n big", big.shape[0], big[:20].tolist())
+    print("finite", torch.isfinite(outs[0][0]).all().item(), "absmax", outs[0][0].abs().max().item())

@@ -6,14 +6,22 @@
 // model/chore.py:113-126).  Design (DESIGN.md "point query"):
 //   * workgroup = 64 consecutive query points of one frame, 4 wavefronts.
 //   * feature maps are channel-last (NHWC): one bilinear tap of a 32-channel chunk is a 128-B burst, 8 lanes x 16 B.
-//     Chunks (19 x 32 map channels + the xyz triple) are staged through LDS as the A operand of the layer-1 GEMM;
+//     Chunks (19 x 32 map channels + the xyz triple) are staged through LDS as one operand of the layer-1 GEMM;
 //     the 611-wide feature vector is never materialised in HBM.
-//   * all GEMMs (611->128->128->128->k, and their transposes in the backward) run on v_mfma_f32_16x16x4_f32
-//     (exact fp32, no TF32 on gfx950).  Per wave: 4 M-tiles (64 points) x 2 N-tiles (32 hidden units) of accumulators;
-//     weights are the B operand, read straight from L2 (0.56 M params per head stay cache resident), both (in,out) and
-//     (out,in) copies are kept so that every B fragment is a row-contiguous 64-B segment.
-//   * hidden activations move D-layout -> A-layout through one padded LDS buffer per head; ReLU masks stay in
-//     registers (1 bit per accumulator element), so the backward needs no activation storage in HBM.
+//   * ARITHMETIC: every GEMM (611->128->128->128->k and the transposes of the backward) runs on v_mfma_f32_16x16x32_f16 with
+//     SPLIT operands and fp32 accumulation: a value x (pre-scaled by an exact power of two into the upper fp16 range) is carried
+//     as hi = fp16(x), lo = fp16(x - hi), i.e. 22 significand bits, and a product is three MFMAs  hi.hi + hi.lo + lo.hi
+//     (the dropped lo.lo term is 2^-22 relative).  That is 16/3 = 5.3x the rate of the f32-input MFMA at an error of
+//     ~3 x 2^-22 per product -- two orders of magnitude tighter than the TF32 (10-bit) cuDNN path the reference's nn.Conv1d
+//     decoders take on its own GPUs (model/chore.py:113-126).  Weights are split once at handle creation (scale 2^k per matrix,
+//     max |w| -> [2^13, 2^14)); activations are scaled by 2^6 (|x| < 1023 representable), upstream gradients are normalised per
+//     point to [2^5, 2^6).  All scales are powers of two and are undone exactly in the fp32 epilogues.
+//   * orientation: hidden layers are computed transposed, D[n][pt] = W[n][k] . X[k][pt] (weights = A operand, read straight
+//     from L2 in fragment order; activations = B operand from LDS), because the D fragment then holds 4 CONSECUTIVE hidden
+//     units of one point per lane: the next layer's operand is written with 8-byte LDS stores instead of 2-byte scatters.
+//     Per wave: 32 hidden units x 64 points = 2 x 4 tiles of 16x16.
+//   * LDS operand planes are K-block major, plane[k / 8][point][8 halves]: a fragment load is one conflict-free ds_read_b128.
+//   * ReLU masks stay in registers (1 bit per accumulator element), so the backward needs no activation storage in HBM.
 //   * the backward of layer 1 contracts d(features) with the bilinear tap differences chunk by chunk and applies the
 //     projection Jacobians in the epilogue: only (B,N,3) gradients are written.
 //   * fused objective variants (human: clamp(df_h)-mean + part cross-entropy; object: visibility weighted clamp(df_o))
@@ -21,29 +29,35 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 #define KTOT 612            /* 608 map channels + x,y,z-2.2 + 1 zero pad (internal channel order) */
 #define NCHUNK 19
-#define FS 36               /* LDS stride of a 32-channel chunk row   [pt][32 + 4]:  36 j mod 64 distinct -> conflict-free ds_read_b64 */
-#define HS 132              /* LDS stride of a hidden activation row  [pt][128 + 4]: 132 j mod 64 = 4 j                                  */
-#define GS 20               /* LDS stride of an output-gradient row   [pt][16 + 4]                                                       */
+#define NSTEP1 20           /* K32 steps of layer 1: 19 map chunks + the xyz step */
+#define TS 36               /* LDS stride (floats) of a tap-difference row [pt][32 + 4] */
 #define OUT_DIST 5.0f       /* chore.py:93 */
+#define ACT_SCALE 64.0f     /* forward activations enter the MFMAs as 2^6 x */
+#define GO_EXP 5            /* upstream gradients are normalised per point to [2^5, 2^6) */
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3 };
 
-// Weight fragments.  All GEMMs walk K in "pair steps": lane (q = lane>>4, j = lane&15) owns k = 8 s + 2 q + e, e in {0,1}, so
-// its two A values are one ds_read_b64 and its B values for both k's and both N-tiles of the wave are one 16-B global load.
-//   wNp  : [K/2][4 waves][16 j][2 e][2 nt]   element = W[k = 2 kp + e][n = (2 wave + nt) 16 + j]        (layers 1-3 fwd and bwd, layer-4 bwd)
-//   w1c  : [64 kp][20 chunks][16 j][2 e][2 nt] element = W1(out,in)[u = 2 kp + e][c = chunk 32 + nt 16 + j]   (layer-1 backward)
-//   w4p  : [64 kp][16 j][2 e]                element = W4(in,out)[k = 2 kp + e][o = j]
+// Weight fragments (uint4 = 8 halves).  "T" GEMMs: D[row][pt], the weight matrix M[row][k] is the A operand:
+//   T-pack : [K/32 steps][4 waves][2 nt][hi|lo][64 lanes]   halves t = M[32 wave + 16 nt + (lane & 15)][32 s + 8 (lane >> 4) + t]
+//   w4p    : [4 steps][hi|lo][64 lanes]                     halves t = W4[o = lane & 15][32 s + 8 (lane >> 4) + t]   (B operand of layer 4)
+//   w1c    : [20 chunks][4 steps][2 ct][hi|lo][64 lanes]    halves t = W1[u = 32 s + 8 (lane >> 4) + t][c = 32 chunk + 16 ct + (lane & 15)]
 struct HeadW {
-    const float *w1p, *w1c, *w1xio, *w1xoi, *b1, *w2p, *w2tp, *b2, *w3p, *w3tp, *b3, *w4p, *w4tp, *b4;
+    const uint4 *w1p, *w1c, *w2p, *w2tp, *w3p, *w3tp, *w4p, *w4tp;
+    const float *b1, *b2, *b3, *b4;
+    float cf[4];            // forward epilogue scale of layers 1..4: 1 / (ACT_SCALE * s_W)
+    float cb[4];            // backward epilogue scale: 1 / s_W
     int kout, id;
 };
 
 struct vt_sifnet {
-    float *blob;            // all weights of the 5 heads
+    void *blob;             // all weights of the 5 heads
     HeadW head[5];
     float cam[5];
 };
@@ -73,6 +87,16 @@ __device__ __forceinline__ void chunk_info(int i, int &mi, int &co)
     else { mi = 5 + (i - 13) / 2; co = 32 * ((i - 13) & 1); }
 }
 
+__device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
+// x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
+{
+    const h2 a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)x2, (_Float16)x3};
+    const h2 c = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])}, d = {(_Float16)(x2 - (float)b[0]), (_Float16)(x3 - (float)b[1])};
+    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
+
 // The four bilinear taps of one 32-channel chunk for two points per thread, held in registers while the loads are in flight.
 struct Taps { float4 t[2][4]; float wx1[2], wy1[2]; int inb[2]; float sc; };
 
@@ -98,33 +122,31 @@ __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co
         // global and a private address -- and fold the in-bounds flag into the interpolation weights (see taps_store_*)
         const int xc0 = min(max(x0, 0), R - 1), xc1 = min(max(x1, 0), R - 1), yc0 = min(max(y0, 0), R - 1), yc1 = min(max(y1, 0), R - 1);
         const size_t rowb = (size_t)b * R;
-#ifdef ABL_NOGATHER
-        r.t[pass][0] = r.t[pass][1] = r.t[pass][2] = r.t[pass][3] = make_float4(u, v, u, v);
-#else
         r.t[pass][0] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc0) * C + co + sub * 4);
         r.t[pass][1] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc1) * C + co + sub * 4);
         r.t[pass][2] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc0) * C + co + sub * 4);
         r.t[pass][3] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc1) * C + co + sub * 4);
-#endif
         r.inb[pass] = (bx0 && by0 ? 1 : 0) | (bx1 && by0 ? 2 : 0) | (bx0 && by1 ? 4 : 0) | (bx1 && by1 ? 8 : 0);
     }
 }
-// blend the taps to features and store [pt][FS] (forward) ...
-__device__ __forceinline__ void taps_store_feat(const Taps &r, float *buf, int tid)
+// blend the taps to (scaled) features, split, and store into the K-block-major chunk planes [4 kb][64 pt][8 halves] (forward) ...
+__device__ __forceinline__ void taps_store_feat(const Taps &r, uint2 *hi8, uint2 *lo8, int tid)
 {
     const int sub = tid & 7, pp = tid >> 3;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
         const int ib = r.inb[pass];
-        const float w00 = (ib & 1) ? wx0 * wy0 : 0.f, w10 = (ib & 2) ? wx1 * wy0 : 0.f, w01 = (ib & 4) ? wx0 * wy1 : 0.f, w11 = (ib & 8) ? wx1 * wy1 : 0.f;
+        const float w00 = (ib & 1) ? wx0 * wy0s : 0.f, w10 = (ib & 2) ? wx1 * wy0s : 0.f, w01 = (ib & 4) ? wx0 * wy1s : 0.f, w11 = (ib & 8) ? wx1 * wy1s : 0.f;
         const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
-        *reinterpret_cast<float4 *>(buf + (pp + 32 * pass) * FS + sub * 4) =
-            make_float4(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11,
-                        nw.z * w00 + ne.z * w10 + sw.z * w01 + se.z * w11, nw.w * w00 + ne.w * w10 + sw.w * w01 + se.w * w11);
+        uint2 hi, lo;
+        split4(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11,
+               nw.z * w00 + ne.z * w10 + sw.z * w01 + se.z * w11, nw.w * w00 + ne.w * w10 + sw.w * w01 + se.w * w11, hi, lo);
+        const int idx = (((sub >> 1) * 64 + pp + 32 * pass) << 1) + (sub & 1);
+        hi8[idx] = hi; lo8[idx] = lo;
     }
 }
-// ... or the tap differences d feat / d u, d feat / d v scaled by (res-1)/2 (backward)
+// ... or the tap differences d feat / d u, d feat / d v scaled by (res-1)/2, fp32 rows [pt][TS] (backward)
 __device__ __forceinline__ void taps_store_grad(const Taps &r, float *bufU, float *bufV, int tid)
 {
     const int sub = tid & 7, pp = tid >> 3;
@@ -137,110 +159,119 @@ __device__ __forceinline__ void taps_store_grad(const Taps &r, float *bufU, floa
         float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
         nw.x *= m0; nw.y *= m0; nw.z *= m0; nw.w *= m0; ne.x *= m1; ne.y *= m1; ne.z *= m1; ne.w *= m1;
         sw.x *= m2; sw.y *= m2; sw.z *= m2; sw.w *= m2; se.x *= m3; se.y *= m3; se.z *= m3; se.w *= m3;
-        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * FS + sub * 4) =
+        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * TS + sub * 4) =
             make_float4(((ne.x - nw.x) * wy0 + (se.x - sw.x) * wy1) * sc, ((ne.y - nw.y) * wy0 + (se.y - sw.y) * wy1) * sc,
                         ((ne.z - nw.z) * wy0 + (se.z - sw.z) * wy1) * sc, ((ne.w - nw.w) * wy0 + (se.w - sw.w) * wy1) * sc);
-        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * FS + sub * 4) =
+        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * TS + sub * 4) =
             make_float4(((sw.x - nw.x) * wx0 + (se.x - ne.x) * wx1) * sc, ((sw.y - nw.y) * wx0 + (se.y - ne.y) * wx1) * sc,
                         ((sw.z - nw.z) * wx0 + (se.z - ne.z) * wx1) * sc, ((sw.w - nw.w) * wx0 + (se.w - ne.w) * wx1) * sc);
     }
 }
 
-// D-layout accumulators of one wave: acc[mt][nt] covers points mt*16 + (lane>>4)*4 + r, hidden unit (2*wave+nt)*16 + (lane&15)
-struct Acc8 { f32x4 v[4][2]; };
+// D fragments of one wave: acc.v[nt][p] covers hidden unit 32 wave + 16 nt + 4 (lane >> 4) + r, point 16 p + (lane & 15)
+struct Acc8 { f32x4 v[2][4]; };
 
 __device__ __forceinline__ void acc_zero(Acc8 &c)
 {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) c.v[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < 4; p++) c.v[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
-
-// bias + ReLU on the D fragments; returns the mask (bit = mt*8 + nt*4 + r) of positive pre-activations
-__device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__ bias, int wave, int lane)
+// one K32 step of the wave tile: weights (A) w[nt][hi|lo], activations (B) from the planes; hi.hi, hi.lo, lo.hi
+__device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const uint4 *Xhi, const uint4 *Xlo, int kb_base, int lane)
+{
+    const int q = lane >> 4, j = lane & 15;
+    h8 xh[4], xl[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[(kb_base + q) * 64 + 16 * p + j]); xl[p] = as_h8(Xlo[(kb_base + q) * 64 + 16 * p + j]); }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xh[p], c.v[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xl[p], c.v[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
+}
+// scale + bias + ReLU on the D fragments; returns the mask (bit = (nt*4 + p)*4 + r) of positive pre-activations
+__device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__ bias, float sc, int wave, int lane)
 {
     unsigned m = 0;
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
-        const float bb = bias[(2 * wave + nt) * 16 + (lane & 15)];
+        const float4 bb = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4));
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int p = 0; p < 4; p++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float x = c.v[mt][nt][r] + bb;
-                if (x > 0.f) { m |= 1u << (mt * 8 + nt * 4 + r); c.v[mt][nt][r] = x; } else c.v[mt][nt][r] = 0.f;
+                const float x = c.v[nt][p][r] * sc + bv[r];
+                if (x > 0.f) { m |= 1u << ((nt * 4 + p) * 4 + r); c.v[nt][p][r] = x; } else c.v[nt][p][r] = 0.f;
             }
     }
     return m;
 }
-__device__ __forceinline__ void apply_mask(Acc8 &c, unsigned m)
+// backward: scale and apply the ReLU mask
+__device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
 {
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c.v[nt][p][r] = ((m >> ((nt * 4 + p) * 4 + r)) & 1u) ? c.v[nt][p][r] * sc : 0.f;
+}
+// D fragments -> split planes [16 kb][64 pt][8 halves] (8-B units); `pre` scales the values first (ACT_SCALE forward, 1 backward)
+__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, float pre, int wave, int lane)
+{
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            uint2 hi, lo;
+            split4(c.v[nt][p][0] * pre, c.v[nt][p][1] * pre, c.v[nt][p][2] * pre, c.v[nt][p][3] * pre, hi, lo);
+            const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
+            hi8[idx] = hi; lo8[idx] = lo;
+        }
+}
+// out[32 rows of this wave][64 pts] = M[128 x 128] (A, T-pack fragments from L2) x X[128 x 64 pts] (B, LDS planes), K = 128.
+// The weights do not depend on the LDS contents: all 16 fragments are requested BEFORE the barrier that publishes X (wprefetch).
+struct WPre { uint4 v[4][2][2]; };
+__device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp, int wave, int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) if (!((m >> (mt * 8 + nt * 4 + r)) & 1u)) c.v[mt][nt][r] = 0.f;
+            for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[((((size_t)s * 4 + wave) * 2 + nt) * 2 + hl) * 64 + lane];
 }
-// D fragments -> LDS activation buffer [pt][HS]
-__device__ __forceinline__ void store_hbuf(const Acc8 &c, float *H, int wave, int lane)
-{
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) H[(mt * 16 + (lane >> 4) * 4 + r) * HS + (2 * wave + nt) * 16 + (lane & 15)] = c.v[mt][nt][r];
-}
-// one pair step of the wave tile: A pairs of the 4 M-tiles (LDS, row stride `stride`), B float4 = {e0nt0, e0nt1, e1nt0, e1nt1}
-__device__ __forceinline__ void pair_step(Acc8 &c, const float *Abase, int stride, int s, int q, int j, const float4 bb)
-{
-    float2 av[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) av[mt] = *reinterpret_cast<const float2 *>(Abase + (mt * 16 + j) * stride + 8 * s + 2 * q);
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt].x, bb.x, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt].x, bb.y, c.v[mt][1]); }
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) { c.v[mt][0] = MFMA16(av[mt].y, bb.z, c.v[mt][0]); c.v[mt][1] = MFMA16(av[mt].y, bb.w, c.v[mt][1]); }
-}
-// out[64 x (32 cols of this wave)] = H[64 x 128] (A, LDS) x W[128 x 128] (B, pair-step fragments from L2), K = 128.
-// The weights do not depend on the LDS contents: the first 8 fragments are requested BEFORE the barrier that publishes H
-// (wpre), the other 8 while the first MFMAs run.
-struct WPre { float4 v[8]; };
-__device__ __forceinline__ void wprefetch(WPre &p, const float *__restrict__ Wp, int wave, int lane)
-{
-    const float4 *__restrict__ w = reinterpret_cast<const float4 *>(Wp) + ((lane >> 4) * 4 + wave) * 16 + (lane & 15);
-#pragma unroll
-    for (int s = 0; s < 8; s++) p.v[s] = w[(size_t)s * 4 * 64];
-}
-__device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__restrict__ Wp, const WPre &p, int wave, int lane)
+__device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
 {
     acc_zero(c);
-    const int q = lane >> 4, j = lane & 15;
-    const float4 *__restrict__ w = reinterpret_cast<const float4 *>(Wp) + (q * 4 + wave) * 16 + j;
-    float4 late[8];
 #pragma unroll
-    for (int s = 0; s < 8; s++) late[s] = w[(size_t)(s + 8) * 4 * 64];
-#pragma unroll
-    for (int s = 0; s < 8; s++) pair_step(c, H, HS, s, q, j, p.v[s]);
-#pragma unroll
-    for (int s = 0; s < 8; s++) pair_step(c, H, HS, s + 8, q, j, late[s]);
+    for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
 }
 
 template <int G, int MODE>
 __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden activations per head -> tap-difference double
-    // buffers (layer-1 backward, after the d(hidden-1) fragments moved to registers).
-    constexpr int R0 = (G * 64 * HS > 2 * 64 * FS + G * 4096) ? G * 64 * HS : 2 * 64 * FS + G * 4096;
-    float *Hb = lds;                        // G x [64][HS]
-    float *Cb = lds;                        // 2 x [64][FS] feature chunks (fwd)   |   [64][FS] du, [64][FS] dv, weight slab G x 16 KB (bwd)
-    float *Go = lds + R0;                   // [64][GS]       output gradient
-    float *sPt = Go + 64 * GS;              // [64][3]
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden-activation planes per head -> tap-difference
+    // buffers + weight slab (layer-1 backward, after the d(hidden-1) fragments moved to registers).
+    constexpr int R0 = (G * 2048 > 1152 + G * 1024) ? G * 2048 : 1152 + G * 1024;      // uint4 units
+    uint4 *Hp = lds;                        // G x {hi [16 kb][64], lo [16 kb][64]}
+    uint4 *Go = lds + R0;                   // {hi [2 kb][64], lo [2 kb][64]}  normalised output gradient
+    float *sPt = reinterpret_cast<float *>(Go + 256);   // [64][3]
     float *sUV = sPt + 64 * 3;              // [4][64][2]
-    int *sIn = reinterpret_cast<int *>(sUV + 4 * 64 * 2);  // [64]
+    float *sInv = sUV + 4 * 64 * 2;         // [G][64] inverse of the per-point gradient normalisation
+    int *sIn = reinterpret_cast<int *>(sInv + G * 64);   // [64]
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
@@ -273,97 +304,86 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     __syncthreads();
 
     // ---- layer 1: stream the 19 chunks (all heads of the group at once); the tap loads of chunk i+1 are in flight
-    //      while the MFMAs of chunk i run (one barrier per chunk thanks to the double buffer)
+    //      while the MFMAs of chunk i run (one barrier per chunk thanks to the double buffer); the weight fragments of
+    //      chunk i+1 are requested as soon as the MFMAs of chunk i have been issued.
     Acc8 acc1[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc_zero(acc1[g]);
     Taps tp;
     { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
-    float4 bw[G][4], bwn[G][4];
-#pragma unroll
-    for (int g = 0; g < G; g++)
-#pragma unroll
-        for (int s = 0; s < 4; s++) bw[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)(s * 4 + q) * 4 + wave) * 16 + j];
+    uint4 wf[G][2][2];
+#define LOAD_W1(step_)                                                                                                       \
+    _Pragma("unroll") for (int g = 0; g < G; g++)                                                                            \
+        _Pragma("unroll") for (int nt = 0; nt < 2; nt++)                                                                     \
+            _Pragma("unroll") for (int hl = 0; hl < 2; hl++)                                                                 \
+                wf[g][nt][hl] = a.hw[g].w1p[((((size_t)(step_) * 4 + wave) * 2 + nt) * 2 + hl) * 64 + lane];
+    LOAD_W1(0)
     for (int ci = 0; ci < NCHUNK; ci++) {
-        float *buf = Cb + (ci & 1) * 64 * FS;
-        taps_store_feat(tp, buf, tid);
+        uint4 *buf = lds + (ci & 1) * 512;          // {hi [4 kb][64], lo [4 kb][64]}
+        taps_store_feat(tp, reinterpret_cast<uint2 *>(buf), reinterpret_cast<uint2 *>(buf + 256), tid);
         __syncthreads();
-        if (ci + 1 < NCHUNK) {
-            int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp);
+        if (ci + 1 < NCHUNK) { int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
 #pragma unroll
-            for (int g = 0; g < G; g++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) bwn[g][s] = reinterpret_cast<const float4 *>(a.hw[g].w1p)[((size_t)((ci + 1) * 16 + s * 4 + q) * 4 + wave) * 16 + j];
-        }
-#ifndef ABL_NOFWDL1
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            float2 av[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) av[mt] = *reinterpret_cast<const float2 *>(buf + (mt * 16 + j) * FS + 8 * s + 2 * q);
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt].x, bw[g][s].x, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt].x, bw[g][s].y, acc1[g].v[mt][1]); }
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt].y, bw[g][s].z, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt].y, bw[g][s].w, acc1[g].v[mt][1]); }
-            }
-        }
-#else
-        for (int g = 0; g < G; g++) acc1[g].v[0][0][0] += bw[g][0].x + buf[(j) * FS + q];
-#endif
-#pragma unroll
-        for (int g = 0; g < G; g++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) bw[g][s] = bwn[g][s];
+        for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
+        LOAD_W1(ci + 1)
     }
-    {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (+ zero pad 611), one plain k-step (k = q)
-        float av[4];
+    {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (K32 step 19, k = 8 q + t: only q == 0, t < 3 are non-zero)
+        uint4 xh[4], xl[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) av[mt] = q < 3 ? sPt[(mt * 16 + j) * 3 + q] - (q == 2 ? 2.2f : 0.f) : 0.f;
+        for (int p = 0; p < 4; p++) {
+            uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
+            if (q == 0) {
+                const float *pp = sPt + (16 * p + j) * 3;
+                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo);
+            }
+            xh[p] = make_uint4(hi.x, hi.y, 0u, 0u); xl[p] = make_uint4(lo.x, lo.y, 0u, 0u);
+        }
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const float *w = a.hw[g].w1xio + q * 128 + (2 * wave) * 16 + j;
-            const float b0 = w[0], b1 = w[16];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) { acc1[g].v[mt][0] = MFMA16(av[mt], b0, acc1[g].v[mt][0]); acc1[g].v[mt][1] = MFMA16(av[mt], b1, acc1[g].v[mt][1]); }
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    acc1[g].v[nt][p] = MFMAH(as_h8(wf[g][nt][0]), as_h8(xh[p]), acc1[g].v[nt][p]);
+                    acc1[g].v[nt][p] = MFMAH(as_h8(wf[g][nt][0]), as_h8(xl[p]), acc1[g].v[nt][p]);
+                    acc1[g].v[nt][p] = MFMAH(as_h8(wf[g][nt][1]), as_h8(xh[p]), acc1[g].v[nt][p]);
+                }
         }
     }
-    __syncthreads();        // region 0 changes role: chunk buffers -> hidden activations
+#undef LOAD_W1
+    __syncthreads();        // region 0 changes role: chunk buffers -> hidden-activation planes
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
     double loss_acc[2] = {0.0, 0.0};
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const HeadW &hw = a.hw[g];
-        float *H = Hb + g * 64 * HS;
+        uint4 *Hhi = Hp + g * 2048, *Hlo = Hhi + 1024;
+        uint2 *Hhi8 = reinterpret_cast<uint2 *>(Hhi), *Hlo8 = reinterpret_cast<uint2 *>(Hlo);
         Acc8 c;
         WPre wp;
         wprefetch(wp, hw.w2p, wave, lane);
-        const unsigned m1 = bias_relu(acc1[g], hw.b1, wave, lane);
-        store_hbuf(acc1[g], H, wave, lane);
+        const unsigned m1 = bias_relu(acc1[g], hw.b1, hw.cf[0], wave, lane);
+        store_planes(acc1[g], Hhi8, Hlo8, ACT_SCALE, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2p, wp, wave, lane);
+        gemm128(c, Hhi, Hlo, wp, lane);
         wprefetch(wp, hw.w3p, wave, lane);
-        const unsigned m2 = bias_relu(c, hw.b2, wave, lane);
+        const unsigned m2 = bias_relu(c, hw.b2, hw.cf[1], wave, lane);
         __syncthreads();
-        store_hbuf(c, H, wave, lane);
+        store_planes(c, Hhi8, Hlo8, ACT_SCALE, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w3p, wp, wave, lane);
-        const unsigned m3 = bias_relu(c, hw.b3, wave, lane);
+        gemm128(c, Hhi, Hlo, wp, lane);
+        const unsigned m3 = bias_relu(c, hw.b3, hw.cf[2], wave, lane);
         __syncthreads();
-        store_hbuf(c, H, wave, lane);
+        store_planes(c, Hhi8, Hlo8, ACT_SCALE, wave, lane);
         __syncthreads();
-        // layer 4: wave w owns the 16 points of M-tile w, N-tile = up to 16 outputs (zero padded)
+        // layer 4 (points as rows): wave w owns the 16 points of tile w, columns = up to 16 outputs (zero padded)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {
-            const float2 *__restrict__ w4 = reinterpret_cast<const float2 *>(hw.w4p) + q * 16 + j;
 #pragma unroll
-            for (int s = 0; s < 16; s++) {
-                const float2 av = *reinterpret_cast<const float2 *>(H + (wave * 16 + j) * HS + 8 * s + 2 * q);
-                const float2 bb = w4[s * 64];
-                o4 = MFMA16(av.x, bb.x, o4); o4 = MFMA16(av.y, bb.y, o4);
-            }
+        for (int s = 0; s < 4; s++) {
+            const h8 xh = as_h8(Hhi[(4 * s + q) * 64 + 16 * wave + j]), xl = as_h8(Hlo[(4 * s + q) * 64 + 16 * wave + j]);
+            const h8 wh = as_h8(hw.w4p[(s * 2 + 0) * 64 + lane]), wl = as_h8(hw.w4p[(s * 2 + 1) * 64 + lane]);
+            o4 = MFMAH(xh, wh, o4); o4 = MFMAH(xl, wh, o4); o4 = MFMAH(xh, wl, o4);
         }
         const float bias4 = hw.b4[j];
         float go[4];    // upstream gradient of output j at points wave*16 + q*4 + r
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             const int pt = wave * 16 + q * 4 + r, n = n0 + pt;
             const bool valid = n < a.N, live = j < hw.kout;
             const bool inimg = sIn[pt] != 0;
-            float val = o4[r] + bias4;
+            float val = o4[r] * hw.cf[3] + bias4;
             go[r] = 0.f;
             if (MODE == MODE_FWD) {
                 if (hw.id == 0 && !inimg) val = OUT_DIST;                       // df[~in_img] = 5.0 (chore_triplane.py:156-159)
@@ -415,30 +435,63 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             }
         }
         if (MODE == MODE_FWD) { __syncthreads(); continue; }
-        // ---- backward through layer 4: g3 = go[64 x 16] . W4(out,in)[16 x 128]
+        // ---- normalise the upstream gradient per point (the backward chain is linear in it): go' = go * 2^e with
+        //      max_o |go'| in [2^GO_EXP, 2^(GO_EXP+1)); the inverse is applied to d(features) in the layer-1 backward
 #pragma unroll
-        for (int r = 0; r < 4; r++) Go[(wave * 16 + q * 4 + r) * GS + j] = go[r];
-        __syncthreads();
-        acc_zero(c);
-        {
-            const float4 *__restrict__ w = reinterpret_cast<const float4 *>(hw.w4tp) + (q * 4 + wave) * 16 + j;
+        for (int r = 0; r < 4; r++) {
+            float m = fabsf(go[r]);
 #pragma unroll
-            for (int s = 0; s < 2; s++) pair_step(c, Go, GS, s, q, j, w[s * 4 * 64]);
+            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const int eb = (int)((__float_as_uint(m) >> 23) & 255u);
+            const bool ok = eb >= GO_EXP + 2 && eb < 255;       // zero / denormal-sized / non-finite gradients pass unscaled
+            const float s = ok ? __uint_as_float((unsigned)(254 + GO_EXP - eb) << 23) : 1.0f;
+            const float inv = ok ? __uint_as_float((unsigned)(eb - GO_EXP) << 23) : 1.0f;
+            const int pt = wave * 16 + q * 4 + r;
+            if (j == 0) sInv[g * 64 + pt] = inv;
+            const float x = go[r] * s;
+            const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+            _Float16 *gh = reinterpret_cast<_Float16 *>(Go), *gl = reinterpret_cast<_Float16 *>(Go + 128);
+            gh[((j >> 3) * 64 + pt) * 8 + (j & 7)] = hi; gl[((j >> 3) * 64 + pt) * 8 + (j & 7)] = lo;
         }
-        wprefetch(wp, hw.w3tp, wave, lane);
-        apply_mask(c, m3);
-        store_hbuf(c, H, wave, lane);          // H (h3) was last read before the barrier above
+        // ---- backward through layer 4: g3[n][pt] = W4[o][n] . go'[o][pt]   (K = 16 outputs, zero padded to one K32 step)
+        WPre wq;
+        {
+            uint4 w[2][2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int hl = 0; hl < 2; hl++) w[nt][hl] = hw.w4tp[(((size_t)wave * 2 + nt) * 2 + hl) * 64 + lane];
+            wprefetch(wq, hw.w3tp, wave, lane);
+            __syncthreads();                       // Go visible; H (h3) no longer read
+            acc_zero(c);
+            h8 xh[4], xl[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                xh[p] = as_h8(q < 2 ? Go[q * 64 + 16 * p + j] : z); xl[p] = as_h8(q < 2 ? Go[128 + q * 64 + 16 * p + j] : z);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xh[p], c.v[nt][p]);
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xl[p], c.v[nt][p]);
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
+                }
+        }
+        scale_mask(c, hw.cb[3], m3);
+        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w3tp, wp, wave, lane);    // g2 = g3 . W3(out,in)
-        wprefetch(wp, hw.w2tp, wave, lane);
-        apply_mask(c, m2);
+        gemm128(c, Hhi, Hlo, wq, lane);            // g2 = W3^T . g3
+        wprefetch(wq, hw.w2tp, wave, lane);
+        scale_mask(c, hw.cb[2], m2);
         __syncthreads();
-        store_hbuf(c, H, wave, lane);
+        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);
         __syncthreads();
-        gemm128(c, H, hw.w2tp, wp, wave, lane);    // g1 = g2 . W2(out,in)
-        apply_mask(c, m1);
+        gemm128(c, Hhi, Hlo, wq, lane);            // g1 = W2^T . g2
+        scale_mask(c, hw.cb[1], m1);
         __syncthreads();
-        store_hbuf(c, H, wave, lane);          // H now holds d loss / d (pre-activation 1) of this head
+        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);   // the planes now hold d loss' / d (pre-activation 1) of this head
         __syncthreads();
     }
 
@@ -460,104 +513,113 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     }
     if (MODE == MODE_FWD) return;
 
-    // ---- backward through layer 1 and the gathers: wave w owns the 16 points of M-tile w
-    float2 ah[G][16];       // A pair fragments of d(hidden-1): point wave*16 + j, hidden units 8 s + 2 q + {0,1}
+    // ---- backward through layer 1 and the gathers: wave w owns the 16 points of tile w (one point per lane column j);
+    //      d feat[c][pt] = sum_g inv[g][pt] / s_W1[g] * ( W1[g][u][c] . dh1'[g][u][pt] ),  c = the chunk's 32 channels
+    uint4 dh[G][4][2];      // B fragments of d(hidden-1): point 16 wave + j, hidden units 32 s + 8 q + t
+    float kscale[G];
 #pragma unroll
-    for (int g = 0; g < G; g++)
+    for (int g = 0; g < G; g++) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) ah[g][s] = *reinterpret_cast<const float2 *>(Hb + g * 64 * HS + (wave * 16 + j) * HS + 8 * s + 2 * q);
-    __syncthreads();        // region 0 changes role again: hidden activations -> tap-difference double buffers
-    // coordinate-gradient partials of the 4 points (rows) this lane sees, over the channels this lane owns
-    float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
-    // Every wave needs the whole 128G x 32 weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
-    // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
-    float *bu = Cb, *bv = Cb + 64 * FS;                 // tap differences of the current chunk
-    float4 *Sl = reinterpret_cast<float4 *>(Cb + 2 * 64 * FS);   // [G][64 kp][16 j] float4 fragments
-#define SLAB_DMA(ci_)                                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4 * G; i_++) {                                                                    \
-        const int idx_ = tid + 256 * i_, g_ = idx_ >> 10, rem_ = idx_ & 1023;                                                \
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4 *>(a.hw[g_].w1c) + ((size_t)(rem_ >> 4) * 20 + (ci_)) * 16 + (rem_ & 15), \
-                                         (__attribute__((address_space(3))) void *)(Sl + wave * 64 + 256 * i_), 16, 0, 0);    \
+        for (int s = 0; s < 4; s++) {
+            dh[g][s][0] = Hp[g * 2048 + (4 * s + q) * 64 + 16 * wave + j];
+            dh[g][s][1] = Hp[g * 2048 + 1024 + (4 * s + q) * 64 + 16 * wave + j];
+        }
+        kscale[g] = sInv[g * 64 + 16 * wave + j] * a.hw[g].cb[0];
     }
+    const int mypt = 16 * wave + j;
+    const float px_ = sPt[mypt * 3], py_ = sPt[mypt * 3 + 1], iz_ = 1.0f / sPt[mypt * 3 + 2];
+    __syncthreads();        // region 0 changes role again: activation planes -> tap-difference buffers + weight slab
+    float gx = 0.f, gy = 0.f, gz = 0.f;     // coordinate-gradient partials of point mypt over the channels this lane sees
+    // Every wave needs the whole weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
+    // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
+    float *bu = reinterpret_cast<float *>(lds), *bv = bu + 64 * TS;      // tap differences of the current chunk
+    uint4 *Sl = lds + 1152;                                              // [G][4 s][2 ct][hi|lo][64 lanes]
+#define SLAB_DMA(ci_)                                                                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                                     \
+            __builtin_amdgcn_global_load_lds(a.hw[g_].w1c + (size_t)(ci_) * 1024 + 256 * i_ + tid,                          \
+                                             (__attribute__((address_space(3))) void *)(Sl + g_ * 1024 + 256 * i_ + wave * 64), 16, 0, 0);
     SLAB_DMA(0)
     { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
     __syncthreads();
     const float kx = 2.0f / a.crop * a.fx, ky = 2.0f / a.crop * a.fy;
+    const float j0x = kx * iz_, j0y = ky * iz_, j0zu = -kx * px_ * iz_ * iz_, j0zv = -ky * py_ * iz_ * iz_;
     for (int ci = 0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);
-        // d feat[16 pts x 32 ch] = sum_g dh1[g] . W1(out,in)[g][:, chunk];  four independent accumulators
-        f32x4 dd[2][2];
+        f32x4 dd[G][2];
 #pragma unroll
-        for (int x = 0; x < 2; x++)
+        for (int g = 0; g < G; g++) { dd[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dd[g][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) dd[x][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifndef ABL_NOB1
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
+        for (int s = 0; s < 4; s++) {
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                const float4 bb = Sl[(g * 64 + 4 * s + q) * 16 + j];
-                const int x0 = (G == 2) ? g : 0, x1 = (G == 2) ? g : 1;
-                dd[x0][0] = MFMA16(ah[g][s].x, bb.x, dd[x0][0]); dd[x0][1] = MFMA16(ah[g][s].x, bb.y, dd[x0][1]);
-                dd[x1][0] = MFMA16(ah[g][s].y, bb.z, dd[x1][0]); dd[x1][1] = MFMA16(ah[g][s].y, bb.w, dd[x1][1]);
+                const uint4 *f = Sl + (((g * 4 + s) * 2) * 2) * 64 + lane;
+                const h8 w0h = as_h8(f[0]), w0l = as_h8(f[64]), w1h = as_h8(f[128]), w1l = as_h8(f[192]);
+                const h8 xh = as_h8(dh[g][s][0]), xl = as_h8(dh[g][s][1]);
+                dd[g][0] = MFMAH(w0h, xh, dd[g][0]); dd[g][1] = MFMAH(w1h, xh, dd[g][1]);
+                dd[g][0] = MFMAH(w0h, xl, dd[g][0]); dd[g][1] = MFMAH(w1h, xl, dd[g][1]);
+                dd[g][0] = MFMAH(w0l, xh, dd[g][0]); dd[g][1] = MFMAH(w1l, xh, dd[g][1]);
             }
         }
-#else
-        dd[0][0][0] += ah[0][3].x + Sl[tid].x; dd[0][1][0] += ah[0][5].y;
-#endif
-        const f32x4 d0 = dd[0][0] + dd[1][0], d1 = dd[0][1] + dd[1][1];
         taps_store_grad(tp, bu, bv, tid);
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
         if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
-        const int pr = map_proj(mi);
+        float su = 0.f, sv = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int pt = wave * 16 + q * 4 + r, row = pt * FS;
-            const float su = d0[r] * bu[row + j] + d1[r] * bu[row + 16 + j];
-            const float sv = d0[r] * bv[row + j] + d1[r] * bv[row + 16 + j];
-            // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251)
-            if (pr == 0) {
-                const float x = sPt[pt * 3], y = sPt[pt * 3 + 1], iz = 1.0f / sPt[pt * 3 + 2];
-                gx[r] += su * kx * iz; gy[r] += sv * ky * iz; gz[r] -= (su * kx * x + sv * ky * y) * iz * iz;
-            } else if (pr == 1) { gz[r] += su; gy[r] += sv; }     // right (c2, c1)
-            else if (pr == 2) { gx[r] -= su; gy[r] += sv; }       // back  (-c0, c1)
-            else { gx[r] += su; gz[r] -= sv; }                    // top   (c0, -c2)
+        for (int ct = 0; ct < 2; ct++) {
+            const float4 u4 = *reinterpret_cast<const float4 *>(bu + mypt * TS + 16 * ct + 4 * q);
+            const float4 v4 = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] += dd[G - 1][ct][r] * kscale[G - 1]; }
+            su += d[0] * u4.x + d[1] * u4.y + d[2] * u4.z + d[3] * u4.w;
+            sv += d[0] * v4.x + d[1] * v4.y + d[2] * v4.z + d[3] * v4.w;
         }
-        __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffer free again
+        // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251), branch-free: the chunk's projection picks the
+        // coefficients of  gx += su cxu,  gy += sv cyv,  gz += su czu + sv czv
+        //   perspective: (kx/z, ky/z, -kx x/z^2, -ky y/z^2)   right (c2, c1): (0, 1, 1, 0)   back (-c0, c1): (-1, 1, 0, 0)   top (c0, -c2): (1, 0, 0, -1)
+        const int pr = map_proj(mi);
+        const float cxu = pr == 0 ? j0x : (pr == 2 ? -1.f : (pr == 3 ? 1.f : 0.f));
+        const float cyv = pr == 0 ? j0y : (pr == 3 ? 0.f : 1.f);
+        const float czu = pr == 0 ? j0zu : (pr == 1 ? 1.f : 0.f);
+        const float czv = pr == 0 ? j0zv : (pr == 3 ? -1.f : 0.f);
+        gx += su * cxu; gy += sv * cyv; gz += su * czu + sv * czv;
+        __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffers free again
         if (ci + 1 < NCHUNK) { int m2i, c2o; chunk_info(ci + 1, m2i, c2o); taps_issue(a, b, m2i, c2o, sUV, tid, tp); }
     }
 #undef SLAB_DMA
-    // direct xyz features: d feat[608..610] = sum_g dh1 . W1(out,in)[:, 608..611]
-    f32x4 dz = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
+        f32x4 dz[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const float *w = a.hw[g].w1xoi + (j & 3);
+        for (int g = 0; g < G; g++) {
+            dz[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const float b0 = j < 4 ? w[(8 * s + 2 * q) * 4] : 0.f, b1 = j < 4 ? w[(8 * s + 2 * q + 1) * 4] : 0.f;
-            dz = MFMA16(ah[g][s].x, b0, dz); dz = MFMA16(ah[g][s].y, b1, dz);
+            for (int s = 0; s < 4; s++) {
+                const uint4 *f = a.hw[g].w1c + (size_t)NCHUNK * 1024 + ((s * 2) * 2) * 64 + lane;
+                const h8 wh = as_h8(f[0]), wl = as_h8(f[64]);
+                const h8 xh = as_h8(dh[g][s][0]), xl = as_h8(dh[g][s][1]);
+                dz[g] = MFMAH(wh, xh, dz[g]); dz[g] = MFMAH(wh, xl, dz[g]); dz[g] = MFMAH(wl, xh, dz[g]);
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g++) { gx += dz[g][0] * kscale[g]; gy += dz[g][1] * kscale[g]; gz += dz[g][2] * kscale[g]; }
         }
     }
-    // reduce the channel partials over the 16 lanes that share a row group
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { gx[r] += __shfl_xor(gx[r], o, 64); gy[r] += __shfl_xor(gy[r], o, 64); gz[r] += __shfl_xor(gz[r], o, 64); }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float gy_d = __shfl(dz[r], (lane & 48) + 1, 64), gz_d = __shfl(dz[r], (lane & 48) + 2, 64);
-        if (j == 0) {
-            const int pt = wave * 16 + q * 4 + r, n = n0 + pt;
-            if (n < a.N) {
-                float *o = a.dpts + ((size_t)b * a.N + n) * 3;
-                o[0] = gx[r] + dz[r]; o[1] = gy[r] + gy_d; o[2] = gz[r] + gz_d;
-            }
+    // reduce the channel partials over the 4 lane groups q that share a point
+    gx += __shfl_xor(gx, 16, 64); gy += __shfl_xor(gy, 16, 64); gz += __shfl_xor(gz, 16, 64);
+    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+    if (q == 0) {
+        const int n = n0 + mypt;
+        if (n < a.N) {
+            float *o = a.dpts + ((size_t)b * a.N + n) * 3;
+            o[0] = gx; o[1] = gy; o[2] = gz;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// MFMA operand-layout self test (A = 16x4, B = 4x16 asymmetric): out = A.B, row-major 16x16
+// MFMA operand-layout self test (f32-input 16x16x4, A = 16x4, B = 4x16 asymmetric): out = A.B, row-major 16x16
 // ---------------------------------------------------------------------------------------------------
 __global__ void mfma_selftest_kernel(const float *A, const float *Bm, float *out)
 {
@@ -575,60 +637,87 @@ extern "C" int vt_selftest_mfma(const float *A, const float *Bm, float *out, voi
 }
 
 // ---------------------------------------------------------------------------------------------------
-// handle: weights re-laid out once.  Internal channel order: 608 map channels (im_feat 256, tmpx 64, tri_tmpx 3x32,
+// handle: weights split and re-laid out once.  Internal channel order: 608 map channels (im_feat 256, tmpx 64, tri_tmpx 3x32,
 // tri_feat 3x64), then x, y, z-2.2, then one zero pad  ->  KTOT = 612.
 // ---------------------------------------------------------------------------------------------------
 static const int kHeadDims[5] = {2, 9, 14, 3, 1};
 static inline int orig_channel(int k) { return k < 256 ? k : (k < 608 ? k + 3 : (k < 611 ? k - 608 + 256 : -1)); }
 
-// [K/2][4 waves][16 j][2 e][2 nt] pair-step fragments of a K x 128 matrix given as get(k, n)
-template <typename F>
-static void pack_pairs(float *dst, int K, F get)
+// power-of-two scale that maps max |w| into [2^13, 2^14)
+static float weight_scale(const float *w, size_t n)
 {
-    for (int kp = 0; kp < K / 2; kp++) for (int w = 0; w < 4; w++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) for (int nt = 0; nt < 2; nt++)
-        dst[((((size_t)kp * 4 + w) * 16 + j) * 2 + e) * 2 + nt] = get(2 * kp + e, (2 * w + nt) * 16 + j);
+    float m = 0.f;
+    for (size_t i = 0; i < n; i++) m = fmaxf(m, fabsf(w[i]));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.0f;
+    int e; frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+static inline void put_split(_Float16 *hi, _Float16 *lo, float x)
+{
+    const _Float16 h = (_Float16)x;
+    *hi = h; *lo = (_Float16)(x - (float)h);
+}
+// T-pack: [K/32][4 waves][2 nt][hi|lo][64 lanes][8 halves] of the 128 x K matrix get(row, k) (already scaled)
+template <typename F>
+static void pack_T(_Float16 *dst, int K, F get)
+{
+    for (int s = 0; s < K / 32; s++) for (int w = 0; w < 4; w++) for (int nt = 0; nt < 2; nt++) for (int l = 0; l < 64; l++) for (int t = 0; t < 8; t++) {
+        const size_t base = ((((size_t)s * 4 + w) * 2 + nt) * 2) * 64;
+        put_split(dst + ((base + l) * 8 + t), dst + ((base + 64 + l) * 8 + t), get(32 * w + 16 * nt + (l & 15), 32 * s + 8 * (l >> 4) + t));
+    }
 }
 
 extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const float *const *bvec, const float *cam, void *stream)
 {
     VT_REQUIRE(out && w && bvec && cam, "vt_sifnet_create: null argument");
     hipStream_t st = vt_stream(stream);
-    // per head (floats): w1p 608*128 | w1c 64*20*16*4 | w1xio 4*128 | w1xoi 128*4 | b1 128 | (w2p, w2tp, b2) | (w3p, w3tp, b3) | w4p 128*16 | w4tp 16*128 | b4 16
-    const size_t per_head = (size_t)608 * 128 + 64 * 20 * 64 + 512 + 512 + 128 + 2 * (2 * 128 * 128 + 128) + 128 * 16 + 16 * 128 + 16;
-    float *host = new float[per_head * 5]();
+    // per head (halves): w1p 20*4*2*2*64*8 | w1c 20*1024*8 | (w2p, w2tp, w3p, w3tp) 4 x 4*4*2*2*64*8 | w4p 4*2*64*8 | w4tp 4*2*2*64*8 ; then floats b1 b2 b3 (128) b4 (16)
+    const size_t n_w1p = (size_t)NSTEP1 * 4 * 2 * 2 * 64 * 8, n_w1c = (size_t)(NCHUNK + 1) * 1024 * 8, n_mid = (size_t)4 * 4 * 2 * 2 * 64 * 8,
+                 n_w4p = (size_t)4 * 2 * 64 * 8, n_w4t = (size_t)4 * 2 * 2 * 64 * 8;
+    const size_t halves = n_w1p + n_w1c + 4 * n_mid + n_w4p + n_w4t, nbias = 128 * 3 + 16;
+    const size_t per_head = halves * sizeof(_Float16) + nbias * sizeof(float);     // multiple of 16 bytes
+    unsigned char *host = new unsigned char[per_head * 5]();
     vt_sifnet *h = new vt_sifnet();
-    VT_HIP(hipMalloc(reinterpret_cast<void **>(&h->blob), per_head * 5 * sizeof(float)));
+    VT_HIP(hipMalloc(&h->blob, per_head * 5));
     for (int hd = 0; hd < 5; hd++) {
-        float *p = host + per_head * hd; const float *d = h->blob + per_head * hd;
+        _Float16 *p = reinterpret_cast<_Float16 *>(host + per_head * hd);
+        const unsigned char *d = reinterpret_cast<const unsigned char *>(h->blob) + per_head * hd;
+        auto dev = [&](size_t off_halves) { return reinterpret_cast<const uint4 *>(d + off_halves * sizeof(_Float16)); };
         const int ko = kHeadDims[hd];
-        const float *W1 = w[hd * 4];          // (128, 611) reference channel order
-        auto w1 = [&](int u, int k) { const int c = orig_channel(k); return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c]; };   // internal order
-        size_t o = 0;
         HeadW &H = h->head[hd];
         H.kout = ko; H.id = hd;
-        H.w1p = d + o; pack_pairs(p + o, 608, [&](int k, int n) { return w1(n, k); }); o += (size_t)608 * 128;
-        H.w1c = d + o;
-        for (int kp = 0; kp < 64; kp++) for (int c = 0; c < 20; c++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) for (int nt = 0; nt < 2; nt++) {
-            const int k = c * 32 + nt * 16 + j;
-            p[o + ((((size_t)kp * 20 + c) * 16 + j) * 2 + e) * 2 + nt] = k < 608 ? w1(2 * kp + e, k) : 0.f;
+        const float *W1 = w[hd * 4], *W2 = w[hd * 4 + 1], *W3 = w[hd * 4 + 2], *W4 = w[hd * 4 + 3];   // (out, in), W1 in reference channel order
+        const float s1 = weight_scale(W1, (size_t)128 * VT_FEAT), s2 = weight_scale(W2, 128 * 128), s3 = weight_scale(W3, 128 * 128),
+                    s4 = weight_scale(W4, (size_t)ko * 128);
+        const float sc[4] = {s1, s2, s3, s4};
+        for (int l = 0; l < 4; l++) { H.cf[l] = 1.0f / (ACT_SCALE * sc[l]); H.cb[l] = 1.0f / sc[l]; }
+        auto w1 = [&](int u, int k) { const int c = k < KTOT ? orig_channel(k) : -1; return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c] * s1; };   // internal order
+        size_t o = 0;
+        H.w1p = dev(o); pack_T(p + o, 32 * NSTEP1, [&](int n, int k) { return w1(n, k); }); o += n_w1p;
+        H.w1c = dev(o);
+        for (int ci = 0; ci <= NCHUNK; ci++) for (int s = 0; s < 4; s++) for (int ct = 0; ct < 2; ct++) for (int l = 0; l < 64; l++) for (int t = 0; t < 8; t++) {
+            const size_t base = (size_t)ci * 1024 + ((s * 2 + ct) * 2) * 64;
+            put_split(p + o + (base + l) * 8 + t, p + o + (base + 64 + l) * 8 + t, w1(32 * s + 8 * (l >> 4) + t, 32 * ci + 16 * ct + (l & 15)));
         }
-        o += (size_t)64 * 20 * 64;
-        H.w1xio = d + o; for (int k = 0; k < 4; k++) for (int u = 0; u < 128; u++) p[o + k * 128 + u] = w1(u, 608 + k); o += 512;
-        H.w1xoi = d + o; for (int u = 0; u < 128; u++) for (int k = 0; k < 4; k++) p[o + u * 4 + k] = w1(u, 608 + k); o += 512;
-        H.b1 = d + o; memcpy(p + o, bvec[hd * 4], 128 * sizeof(float)); o += 128;
-        for (int l = 1; l <= 2; l++) {
-            const float *src = w[hd * 4 + l];      // (out, in)
-            const float *fp_ = d + o; pack_pairs(p + o, 128, [&](int k, int n) { return src[n * 128 + k]; }); o += 128 * 128;    // forward: B[k=in][n=out]
-            const float *bp_ = d + o; pack_pairs(p + o, 128, [&](int k, int n) { return src[k * 128 + n]; }); o += 128 * 128;    // backward: B[k=out][n=in]
-            const float *bb = d + o; memcpy(p + o, bvec[hd * 4 + l], 128 * sizeof(float)); o += 128;
-            if (l == 1) { H.w2p = fp_; H.w2tp = bp_; H.b2 = bb; } else { H.w3p = fp_; H.w3tp = bp_; H.b3 = bb; }
+        o += n_w1c;
+        H.w2p = dev(o); pack_T(p + o, 128, [&](int n, int k) { return W2[n * 128 + k] * s2; }); o += n_mid;
+        H.w2tp = dev(o); pack_T(p + o, 128, [&](int n, int k) { return W2[k * 128 + n] * s2; }); o += n_mid;
+        H.w3p = dev(o); pack_T(p + o, 128, [&](int n, int k) { return W3[n * 128 + k] * s3; }); o += n_mid;
+        H.w3tp = dev(o); pack_T(p + o, 128, [&](int n, int k) { return W3[k * 128 + n] * s3; }); o += n_mid;
+        H.w4p = dev(o);
+        for (int s = 0; s < 4; s++) for (int l = 0; l < 64; l++) for (int t = 0; t < 8; t++) {
+            const int oo = l & 15, k = 32 * s + 8 * (l >> 4) + t;
+            put_split(p + o + (((size_t)s * 2) * 64 + l) * 8 + t, p + o + (((size_t)s * 2 + 1) * 64 + l) * 8 + t, oo < ko ? W4[oo * 128 + k] * s4 : 0.f);
         }
-        const float *W4 = w[hd * 4 + 3];           // (ko, 128)
-        H.w4p = d + o; for (int kp = 0; kp < 64; kp++) for (int j = 0; j < 16; j++) for (int e = 0; e < 2; e++) p[o + ((size_t)kp * 16 + j) * 2 + e] = j < ko ? W4[j * 128 + 2 * kp + e] : 0.f; o += 128 * 16;
-        H.w4tp = d + o; pack_pairs(p + o, 16, [&](int k, int n) { return k < ko ? W4[k * 128 + n] : 0.f; }); o += 16 * 128;
-        H.b4 = d + o; memcpy(p + o, bvec[hd * 4 + 3], ko * sizeof(float)); o += 16;
+        o += n_w4p;
+        H.w4tp = dev(o); pack_T(p + o, 32, [&](int n, int k) { return k < ko ? W4[k * 128 + n] * s4 : 0.f; }); o += n_w4t;
+        float *bp = reinterpret_cast<float *>(p + o);
+        const float *bd = reinterpret_cast<const float *>(d + o * sizeof(_Float16));
+        H.b1 = bd; H.b2 = bd + 128; H.b3 = bd + 256; H.b4 = bd + 384;
+        memcpy(bp, bvec[hd * 4], 128 * sizeof(float)); memcpy(bp + 128, bvec[hd * 4 + 1], 128 * sizeof(float));
+        memcpy(bp + 256, bvec[hd * 4 + 2], 128 * sizeof(float)); memcpy(bp + 384, bvec[hd * 4 + 3], ko * sizeof(float));
     }
-    VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5 * sizeof(float), hipMemcpyHostToDevice, st));
+    VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5, hipMemcpyHostToDevice, st));
     VT_HIP(hipStreamSynchronize(st));
     delete[] host;
     for (int i = 0; i < 5; i++) h->cam[i] = cam[i];
@@ -639,8 +728,8 @@ extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; hipFree(h->blo
 
 static size_t lds_bytes(int G)
 {
-    const size_t r0 = (size_t)G * 64 * HS > (size_t)2 * 64 * FS + G * 4096 ? (size_t)G * 64 * HS : (size_t)2 * 64 * FS + G * 4096;
-    return sizeof(float) * (r0 + 64 * GS + 64 * 3 + 4 * 64 * 2 + 64) + 8 * sizeof(double);
+    const size_t r0 = (size_t)G * 2048 > (size_t)1152 + G * 1024 ? (size_t)G * 2048 : (size_t)1152 + G * 1024;
+    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64) + 8 * sizeof(double);
 }
 
 template <int G, int MODE>
