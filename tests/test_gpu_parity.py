@@ -127,17 +127,19 @@ def test_query_vs_golden(hip):
     maps = _maps(hip, 4, 4, float(g["res_scale"]))
     pts = cu(g["pts"]).requires_grad_(True)
     outs = ops.sifnet_query(hip["net"], maps, pts, cu(g["crop_center"]), cu(g["body_center"]))
+    # the decoders run on split-f16 MFMA operands (22 significand bits, fp32 accumulate): the bar is fp32 round-off of the reference
+    # itself (measured 4e-7 .. 1e-6 of the output range), NOT a reduced-precision tolerance
     for name, o in zip(ops.HEADS, outs):
-        assert np.abs(npy(o) - g[name]).max() < 5e-5 * max(1.0, np.abs(g[name]).max()), name
+        assert np.abs(npy(o) - g[name]).max() < 5e-6 * max(1.0, np.abs(g[name]).max()), name
     assert (npy(outs[0])[0, :, :4] == 5.0).all()
     for i, name in enumerate(ops.HEADS):
         pts.grad = None
         (outs[i] * cu(g["g_" + name])).sum().backward(retain_graph=True)
-        assert rel(npy(pts.grad), g["dpts_" + name]) < 3e-4, name
+        assert rel(npy(pts.grad), g["dpts_" + name]) < 5e-6, name          # measured 4e-7 .. 5e-7
     # two heads at once (the G = 2 instantiation)
     pts.grad = None
     ((outs[0] * cu(g["g_df"])).sum() + (outs[2] * cu(g["g_parts"])).sum()).backward()
-    assert rel(npy(pts.grad), g["dpts_df"] + g["dpts_parts"]) < 3e-4
+    assert rel(npy(pts.grad), g["dpts_df"] + g["dpts_parts"]) < 5e-6
 
 
 def test_query_fused_objectives_vs_oracle(hip, synth):

@@ -51,7 +51,7 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3 };
 struct HeadW {
     const uint4 *w1p, *w1c, *w2p, *w2tp, *w3p, *w3tp, *w4p, *w4tp;
     const float *b1, *b2, *b3, *b4;
-    float cf[4];            // forward epilogue scale of layers 1..4: 1 / (ACT_SCALE * s_W)
+    float cf[4];            // forward epilogue scale: layers 1..3 1 / s_W (output stays in ACT_SCALE units), layer 4 1 / (ACT_SCALE s_W)
     float cb[4];            // backward epilogue scale: 1 / s_W
     int kout, id;
 };
@@ -88,25 +88,39 @@ __device__ __forceinline__ void chunk_info(int i, int &mi, int &co)
 }
 
 __device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
-// x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32
+// x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32.  Two elements cost 4 VALU instructions: one packed
+// RTN conversion, two mixed-precision FMAs (v_fma_mix_f32: -hi * 1 + x, reading hi straight from its packed half), one packed conversion.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+}
 __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
 {
-    const h2 a = {(_Float16)x0, (_Float16)x1}, b = {(_Float16)x2, (_Float16)x3};
-    const h2 c = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])}, d = {(_Float16)(x2 - (float)b[0]), (_Float16)(x3 - (float)b[1])};
-    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+    split2(x0, x1, hi.x, lo.x);
+    split2(x2, x3, hi.y, lo.y);
 }
 
-// The four bilinear taps of one 32-channel chunk for two points per thread, held in registers while the loads are in flight.
-struct Taps { float4 t[2][4]; float wx1[2], wy1[2]; int inb[2]; float sc; };
+// Bilinear sampling, split in two so that nothing is recomputed per chunk:
+//   TapGeom -- per MAP (8 of them over the 19 chunks): the four texel byte offsets (32-bit, inside the frame's map) and the four tap
+//              coefficients of two points per thread (thread = point pp / pp+32, 16-B piece `sub` of a tap row).  Forward (NC = 1):
+//              the bilinear weights x ACT_SCALE; backward (NC = 2): the coefficients of d feat / d u and d feat / d v,
+//              d/du = sc ((ne - nw) wy0 + (se - sw) wy1),  d/dv = sc ((sw - nw) wx0 + (se - ne) wx1), sc = (res - 1) / 2.
+//              Out-of-bounds taps (zeros padding) get coefficient 0 and are loaded from a clamped, valid texel: plain global_load,
+//              no divergent branch, no select between a global and a private address.
+//   Taps    -- per CHUNK: the 4 x 2 float4 tap loads, in flight in registers while the previous chunk's MFMAs run
+template <int NC> struct TapGeom { unsigned o[2][4]; float c[NC][2][4]; };
+struct Taps { float4 t[2][4]; };
 
-// issue the tap loads of chunk (mi, co): thread = (point pp / pp+32, 16-B piece `sub` of the 128-B tap row)
-__device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const float *sUV, int tid, Taps &r)
+template <int NC>
+__device__ __forceinline__ void taps_geom(const QArgs &a, int mi, const float *sUV, int tid, TapGeom<NC> &g)
 {
-    const float *__restrict__ map = a.maps[mi];
     const int R = a.res[mi], C = map_channels(mi), pr = map_proj(mi);
     const int sub = tid & 7, pp = tid >> 3;
-    r.sc = 0.5f * (float)(R - 1);
+    const float sc = 0.5f * (float)(R - 1);
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         const int pt = pp + 32 * pass;
@@ -116,55 +130,60 @@ __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co
         ix = fminf(fmaxf(ix, -2.0f), (float)(R + 1)); iy = fminf(fmaxf(iy, -2.0f), (float)(R + 1));
         const float fxl = floorf(ix), fyl = floorf(iy);
         const int x0 = (int)fxl, y0 = (int)fyl, x1 = x0 + 1, y1 = y0 + 1;
-        r.wx1[pass] = ix - fxl; r.wy1[pass] = iy - fyl;
+        const float wx1 = ix - fxl, wy1 = iy - fyl;
         const bool bx0 = x0 >= 0 && x0 < R, bx1 = x1 >= 0 && x1 < R, by0 = y0 >= 0 && y0 < R, by1 = y1 >= 0 && y1 < R;
-        // zeros padding: always load from a clamped (valid) texel -- plain global_load, no divergent branch, no select between a
-        // global and a private address -- and fold the in-bounds flag into the interpolation weights (see taps_store_*)
+        const bool i0 = bx0 && by0, i1 = bx1 && by0, i2 = bx0 && by1, i3 = bx1 && by1;
         const int xc0 = min(max(x0, 0), R - 1), xc1 = min(max(x1, 0), R - 1), yc0 = min(max(y0, 0), R - 1), yc1 = min(max(y1, 0), R - 1);
-        const size_t rowb = (size_t)b * R;
-        r.t[pass][0] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc0) * C + co + sub * 4);
-        r.t[pass][1] = *reinterpret_cast<const float4 *>(map + ((rowb + yc0) * R + xc1) * C + co + sub * 4);
-        r.t[pass][2] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc0) * C + co + sub * 4);
-        r.t[pass][3] = *reinterpret_cast<const float4 *>(map + ((rowb + yc1) * R + xc1) * C + co + sub * 4);
-        r.inb[pass] = (bx0 && by0 ? 1 : 0) | (bx1 && by0 ? 2 : 0) | (bx0 && by1 ? 4 : 0) | (bx1 && by1 ? 8 : 0);
+        const unsigned r0 = (unsigned)(yc0 * R) * (unsigned)C + (unsigned)(sub * 4), r1 = (unsigned)(yc1 * R) * (unsigned)C + (unsigned)(sub * 4);
+        g.o[pass][0] = (r0 + (unsigned)(xc0 * C)) * 4u; g.o[pass][1] = (r0 + (unsigned)(xc1 * C)) * 4u;
+        g.o[pass][2] = (r1 + (unsigned)(xc0 * C)) * 4u; g.o[pass][3] = (r1 + (unsigned)(xc1 * C)) * 4u;
+        if (NC == 1) {
+            const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
+            g.c[0][pass][0] = i0 ? wx0 * wy0s : 0.f; g.c[0][pass][1] = i1 ? wx1 * wy0s : 0.f;
+            g.c[0][pass][2] = i2 ? wx0 * wy1s : 0.f; g.c[0][pass][3] = i3 ? wx1 * wy1s : 0.f;
+        } else {
+            const float sx1 = wx1 * sc, sy1 = wy1 * sc, sx0 = sc - sx1, sy0 = sc - sy1;
+            g.c[0][pass][0] = i0 ? -sy0 : 0.f; g.c[0][pass][1] = i1 ? sy0 : 0.f; g.c[0][pass][2] = i2 ? -sy1 : 0.f; g.c[0][pass][3] = i3 ? sy1 : 0.f;
+            g.c[NC - 1][pass][0] = i0 ? -sx0 : 0.f; g.c[NC - 1][pass][1] = i1 ? -sx1 : 0.f; g.c[NC - 1][pass][2] = i2 ? sx0 : 0.f; g.c[NC - 1][pass][3] = i3 ? sx1 : 0.f;
+        }
     }
 }
+// issue the tap loads of chunk (mi, co): uniform base = frame b of map mi + channel offset, per-lane 32-bit byte offsets from the geometry
+template <int NC>
+__device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const TapGeom<NC> &g, Taps &r)
+{
+    const int R = a.res[mi], C = map_channels(mi);
+    const char *__restrict__ fb = reinterpret_cast<const char *>(a.maps[mi] + (size_t)b * R * R * C + co);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.t[pass][k] = *reinterpret_cast<const float4 *>(fb + g.o[pass][k]);
+}
+#define TAPSUM_(c_, w_) __builtin_fmaf(se.c_, (w_)[3], __builtin_fmaf(sw.c_, (w_)[2], __builtin_fmaf(ne.c_, (w_)[1], nw.c_ * (w_)[0])))
 // blend the taps to (scaled) features, split, and store into the K-block-major chunk planes [4 kb][64 pt][8 halves] (forward) ...
-__device__ __forceinline__ void taps_store_feat(const Taps &r, uint2 *hi8, uint2 *lo8, int tid)
+__device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> &g, uint2 *hi8, uint2 *lo8, int tid)
 {
     const int sub = tid & 7, pp = tid >> 3;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
-        const int ib = r.inb[pass];
-        const float w00 = (ib & 1) ? wx0 * wy0s : 0.f, w10 = (ib & 2) ? wx1 * wy0s : 0.f, w01 = (ib & 4) ? wx0 * wy1s : 0.f, w11 = (ib & 8) ? wx1 * wy1s : 0.f;
         const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        const float *w = g.c[0][pass];
         uint2 hi, lo;
-        split4(nw.x * w00 + ne.x * w10 + sw.x * w01 + se.x * w11, nw.y * w00 + ne.y * w10 + sw.y * w01 + se.y * w11,
-               nw.z * w00 + ne.z * w10 + sw.z * w01 + se.z * w11, nw.w * w00 + ne.w * w10 + sw.w * w01 + se.w * w11, hi, lo);
+        split4(TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w), hi, lo);
         const int idx = (((sub >> 1) * 64 + pp + 32 * pass) << 1) + (sub & 1);
         hi8[idx] = hi; lo8[idx] = lo;
     }
 }
-// ... or the tap differences d feat / d u, d feat / d v scaled by (res-1)/2, fp32 rows [pt][TS] (backward)
-__device__ __forceinline__ void taps_store_grad(const Taps &r, float *bufU, float *bufV, int tid)
+// ... or the tap differences d feat / d u, d feat / d v, fp32 rows [pt][TS] (backward): 4 + 4 multiply-adds per channel
+__device__ __forceinline__ void taps_store_grad(const Taps &r, const TapGeom<2> &g, float *bufU, float *bufV, int tid)
 {
     const int sub = tid & 7, pp = tid >> 3;
-    const float sc = r.sc;
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const float wx1 = r.wx1[pass], wy1 = r.wy1[pass], wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-        const int ib = r.inb[pass];
-        const float m0 = (ib & 1) ? 1.f : 0.f, m1 = (ib & 2) ? 1.f : 0.f, m2 = (ib & 4) ? 1.f : 0.f, m3 = (ib & 8) ? 1.f : 0.f;
-        float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
-        nw.x *= m0; nw.y *= m0; nw.z *= m0; nw.w *= m0; ne.x *= m1; ne.y *= m1; ne.z *= m1; ne.w *= m1;
-        sw.x *= m2; sw.y *= m2; sw.z *= m2; sw.w *= m2; se.x *= m3; se.y *= m3; se.z *= m3; se.w *= m3;
-        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * TS + sub * 4) =
-            make_float4(((ne.x - nw.x) * wy0 + (se.x - sw.x) * wy1) * sc, ((ne.y - nw.y) * wy0 + (se.y - sw.y) * wy1) * sc,
-                        ((ne.z - nw.z) * wy0 + (se.z - sw.z) * wy1) * sc, ((ne.w - nw.w) * wy0 + (se.w - sw.w) * wy1) * sc);
-        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * TS + sub * 4) =
-            make_float4(((sw.x - nw.x) * wx0 + (se.x - ne.x) * wx1) * sc, ((sw.y - nw.y) * wx0 + (se.y - ne.y) * wx1) * sc,
-                        ((sw.z - nw.z) * wx0 + (se.z - ne.z) * wx1) * sc, ((sw.w - nw.w) * wx0 + (se.w - ne.w) * wx1) * sc);
+        const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
+        const float *cu = g.c[0][pass], *cv = g.c[1][pass];
+        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * TS + sub * 4) = make_float4(TAPSUM_(x, cu), TAPSUM_(y, cu), TAPSUM_(z, cu), TAPSUM_(w, cu));
+        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * TS + sub * 4) = make_float4(TAPSUM_(x, cv), TAPSUM_(y, cv), TAPSUM_(z, cv), TAPSUM_(w, cv));
     }
 }
 
@@ -198,7 +217,8 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
 #pragma unroll
         for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
 }
-// scale + bias + ReLU on the D fragments; returns the mask (bit = (nt*4 + p)*4 + r) of positive pre-activations
+// scale + bias + ReLU on the D fragments, result left in the ACT_SCALE-d units the next layer's operands use (bias = ACT_SCALE * b,
+// sc = ACT_SCALE * cf); returns the mask of positive pre-activations, bit 31 - ((nt*4 + p)*4 + r)  (shift-in order)
 __device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__ bias, float sc, int wave, int lane)
 {
     unsigned m = 0;
@@ -210,13 +230,16 @@ __device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__
         for (int p = 0; p < 4; p++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float x = c.v[nt][p][r] * sc + bv[r];
-                if (x > 0.f) { m |= 1u << ((nt * 4 + p) * 4 + r); c.v[nt][p][r] = x; } else c.v[nt][p][r] = 0.f;
+                const float x = __builtin_fmaf(c.v[nt][p][r], sc, bv[r]);
+                // m = 2 m + (x > 0): compare into VCC, add-with-carry.  Opaque on purpose: left to itself hipcc keeps the 32 compares
+                // as lane masks, runs out of SGPRs and spills the pre-activations to scratch to redo the compares in the backward.
+                asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
+                c.v[nt][p][r] = fmaxf(x, 0.f);
             }
     }
     return m;
 }
-// backward: scale and apply the ReLU mask
+// backward: scale and apply the ReLU mask (bit 31 - k of m belongs to element k)
 __device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
 {
 #pragma unroll
@@ -224,10 +247,14 @@ __device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
 #pragma unroll
         for (int p = 0; p < 4; p++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) c.v[nt][p][r] = ((m >> ((nt * 4 + p) * 4 + r)) & 1u) ? c.v[nt][p][r] * sc : 0.f;
+            for (int r = 0; r < 4; r++) {
+                const int k = (nt * 4 + p) * 4 + r;
+                const unsigned keep = (unsigned)((int)(m << k) >> 31);          // all ones where the unit was active
+                c.v[nt][p][r] = __uint_as_float(__float_as_uint(c.v[nt][p][r] * sc) & keep);
+            }
 }
-// D fragments -> split planes [16 kb][64 pt][8 halves] (8-B units); `pre` scales the values first (ACT_SCALE forward, 1 backward)
-__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, float pre, int wave, int lane)
+// D fragments (already in operand units) -> split planes [16 kb][64 pt][8 halves] (8-B units)
+__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, int wave, int lane)
 {
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
@@ -235,7 +262,7 @@ __device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *l
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             uint2 hi, lo;
-            split4(c.v[nt][p][0] * pre, c.v[nt][p][1] * pre, c.v[nt][p][2] * pre, c.v[nt][p][3] * pre, hi, lo);
+            split4(c.v[nt][p][0], c.v[nt][p][1], c.v[nt][p][2], c.v[nt][p][3], hi, lo);
             const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
             hi8[idx] = hi; lo8[idx] = lo;
         }
@@ -250,7 +277,7 @@ __device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp,
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[((((size_t)s * 4 + wave) * 2 + nt) * 2 + hl) * 64 + lane];
+            for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[(unsigned)(wave * 256 + lane) + (unsigned)(s * 1024 + (nt * 2 + hl) * 64)];
 }
 __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
 {
@@ -310,19 +337,26 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #pragma unroll
     for (int g = 0; g < G; g++) acc_zero(acc1[g]);
     Taps tp;
-    { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+    TapGeom<1> tg;
+    { int mi, co; chunk_info(0, mi, co); taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
     uint4 wf[G][2][2];
+    const unsigned wvo = (unsigned)(wave * 256 + lane);       // per-lane part of a T-pack fragment index; the rest is uniform / immediate
 #define LOAD_W1(step_)                                                                                                       \
-    _Pragma("unroll") for (int g = 0; g < G; g++)                                                                            \
+    _Pragma("unroll") for (int g = 0; g < G; g++) {                                                                          \
+        const uint4 *__restrict__ wp_ = a.hw[g].w1p + (size_t)(step_) * 1024;                                                \
         _Pragma("unroll") for (int nt = 0; nt < 2; nt++)                                                                     \
-            _Pragma("unroll") for (int hl = 0; hl < 2; hl++)                                                                 \
-                wf[g][nt][hl] = a.hw[g].w1p[((((size_t)(step_) * 4 + wave) * 2 + nt) * 2 + hl) * 64 + lane];
+            _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[g][nt][hl] = wp_[wvo + (nt * 2 + hl) * 64];                  \
+    }
     LOAD_W1(0)
     for (int ci = 0; ci < NCHUNK; ci++) {
         uint4 *buf = lds + (ci & 1) * 512;          // {hi [4 kb][64], lo [4 kb][64]}
-        taps_store_feat(tp, reinterpret_cast<uint2 *>(buf), reinterpret_cast<uint2 *>(buf + 256), tid);
+        taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(buf), reinterpret_cast<uint2 *>(buf + 256), tid);
         __syncthreads();
-        if (ci + 1 < NCHUNK) { int mi, co; chunk_info(ci + 1, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+        if (ci + 1 < NCHUNK) {
+            int mi, co; chunk_info(ci + 1, mi, co);
+            if (co == 0) taps_geom(a, mi, sUV, tid, tg);        // a new map: new texel offsets / fractions (uniform branch)
+            taps_issue(a, b, mi, co, tg, tp);
+        }
 #pragma unroll
         for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
         LOAD_W1(ci + 1)
@@ -352,6 +386,14 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     }
 #undef LOAD_W1
     __syncthreads();        // region 0 changes role: chunk buffers -> hidden-activation planes
+    // hidden-1 activations of ALL heads go to their planes right away: no head's layer-1 accumulators stay live in registers
+    // while another head runs its layers 2..4 and backward
+    unsigned m1s[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        m1s[g] = bias_relu(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave, lane);
+        store_planes(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane);
+    }
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
     double loss_acc[2] = {0.0, 0.0};
@@ -363,19 +405,18 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         Acc8 c;
         WPre wp;
         wprefetch(wp, hw.w2p, wave, lane);
-        const unsigned m1 = bias_relu(acc1[g], hw.b1, hw.cf[0], wave, lane);
-        store_planes(acc1[g], Hhi8, Hlo8, ACT_SCALE, wave, lane);
-        __syncthreads();
+        const unsigned m1 = m1s[g];
+        if (g == 0) __syncthreads();           // hidden-1 planes of all heads visible
         gemm128(c, Hhi, Hlo, wp, lane);
         wprefetch(wp, hw.w3p, wave, lane);
         const unsigned m2 = bias_relu(c, hw.b2, hw.cf[1], wave, lane);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, ACT_SCALE, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         gemm128(c, Hhi, Hlo, wp, lane);
         const unsigned m3 = bias_relu(c, hw.b3, hw.cf[2], wave, lane);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, ACT_SCALE, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         // layer 4 (points as rows): wave w owns the 16 points of tile w, columns = up to 16 outputs (zero padded)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -480,18 +521,18 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                 }
         }
         scale_mask(c, hw.cb[3], m3);
-        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g2 = W3^T . g3
         wprefetch(wq, hw.w2tp, wave, lane);
         scale_mask(c, hw.cb[2], m2);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g1 = W2^T . g2
         scale_mask(c, hw.cb[1], m1);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, 1.0f, wave, lane);   // the planes now hold d loss' / d (pre-activation 1) of this head
+        store_planes(c, Hhi8, Hlo8, wave, lane);   // the planes now hold d loss' / d (pre-activation 1) of this head
         __syncthreads();
     }
 
@@ -540,7 +581,8 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             __builtin_amdgcn_global_load_lds(a.hw[g_].w1c + (size_t)(ci_) * 1024 + 256 * i_ + tid,                          \
                                              (__attribute__((address_space(3))) void *)(Sl + g_ * 1024 + 256 * i_ + wave * 64), 16, 0, 0);
     SLAB_DMA(0)
-    { int mi, co; chunk_info(0, mi, co); taps_issue(a, b, mi, co, sUV, tid, tp); }
+    TapGeom<2> tgb;
+    { int mi, co; chunk_info(0, mi, co); taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
     __syncthreads();
     const float kx = 2.0f / a.crop * a.fx, ky = 2.0f / a.crop * a.fy;
     const float j0x = kx * iz_, j0y = ky * iz_, j0zu = -kx * px_ * iz_ * iz_, j0zv = -ky * py_ * iz_ * iz_;
@@ -561,7 +603,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                 dd[g][0] = MFMAH(w0l, xh, dd[g][0]); dd[g][1] = MFMAH(w1l, xh, dd[g][1]);
             }
         }
-        taps_store_grad(tp, bu, bv, tid);
+        taps_store_grad(tp, tgb, bu, bv, tid);
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
         if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
         float su = 0.f, sv = 0.f;
@@ -571,9 +613,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             const float4 v4 = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
             float d[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] += dd[G - 1][ct][r] * kscale[G - 1]; }
-            su += d[0] * u4.x + d[1] * u4.y + d[2] * u4.z + d[3] * u4.w;
-            sv += d[0] * v4.x + d[1] * v4.y + d[2] * v4.z + d[3] * v4.w;
+            for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] = __builtin_fmaf(dd[G - 1][ct][r], kscale[G - 1], d[r]); }
+            su = __builtin_fmaf(d[3], u4.w, __builtin_fmaf(d[2], u4.z, __builtin_fmaf(d[1], u4.y, __builtin_fmaf(d[0], u4.x, su))));
+            sv = __builtin_fmaf(d[3], v4.w, __builtin_fmaf(d[2], v4.z, __builtin_fmaf(d[1], v4.y, __builtin_fmaf(d[0], v4.x, sv))));
         }
         // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251), branch-free: the chunk's projection picks the
         // coefficients of  gx += su cxu,  gy += sv cyv,  gz += su czu + sv czv
@@ -583,9 +625,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         const float cyv = pr == 0 ? j0y : (pr == 3 ? 0.f : 1.f);
         const float czu = pr == 0 ? j0zu : (pr == 1 ? 1.f : 0.f);
         const float czv = pr == 0 ? j0zv : (pr == 3 ? -1.f : 0.f);
-        gx += su * cxu; gy += sv * cyv; gz += su * czu + sv * czv;
+        gx = __builtin_fmaf(su, cxu, gx); gy = __builtin_fmaf(sv, cyv, gy); gz = __builtin_fmaf(sv, czv, __builtin_fmaf(su, czu, gz));
         __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffers free again
-        if (ci + 1 < NCHUNK) { int m2i, c2o; chunk_info(ci + 1, m2i, c2o); taps_issue(a, b, m2i, c2o, sUV, tid, tp); }
+        if (ci + 1 < NCHUNK) {
+            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
+            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
+            taps_issue(a, b, m2i, c2o, tgb, tp);
+        }
     }
 #undef SLAB_DMA
     {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
@@ -690,7 +736,7 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
         const float s1 = weight_scale(W1, (size_t)128 * VT_FEAT), s2 = weight_scale(W2, 128 * 128), s3 = weight_scale(W3, 128 * 128),
                     s4 = weight_scale(W4, (size_t)ko * 128);
         const float sc[4] = {s1, s2, s3, s4};
-        for (int l = 0; l < 4; l++) { H.cf[l] = 1.0f / (ACT_SCALE * sc[l]); H.cb[l] = 1.0f / sc[l]; }
+        for (int l = 0; l < 4; l++) { H.cf[l] = l < 3 ? 1.0f / sc[l] : 1.0f / (ACT_SCALE * sc[l]); H.cb[l] = 1.0f / sc[l]; }
         auto w1 = [&](int u, int k) { const int c = k < KTOT ? orig_channel(k) : -1; return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c] * s1; };   // internal order
         size_t o = 0;
         H.w1p = dev(o); pack_T(p + o, 32 * NSTEP1, [&](int n, int k) { return w1(n, k); }); o += n_w1p;
@@ -714,8 +760,8 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
         float *bp = reinterpret_cast<float *>(p + o);
         const float *bd = reinterpret_cast<const float *>(d + o * sizeof(_Float16));
         H.b1 = bd; H.b2 = bd + 128; H.b3 = bd + 256; H.b4 = bd + 384;
-        memcpy(bp, bvec[hd * 4], 128 * sizeof(float)); memcpy(bp + 128, bvec[hd * 4 + 1], 128 * sizeof(float));
-        memcpy(bp + 256, bvec[hd * 4 + 2], 128 * sizeof(float)); memcpy(bp + 384, bvec[hd * 4 + 3], ko * sizeof(float));
+        for (int l = 0; l < 3; l++) for (int i = 0; i < 128; i++) bp[l * 128 + i] = bvec[hd * 4 + l][i] * ACT_SCALE;   // hidden biases in operand units (exact)
+        memcpy(bp + 384, bvec[hd * 4 + 3], ko * sizeof(float));
     }
     VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5, hipMemcpyHostToDevice, st));
     VT_HIP(hipStreamSynchronize(st));
