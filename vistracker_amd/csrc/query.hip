@@ -348,17 +348,23 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[g][nt][hl] = wp_[wvo + (nt * 2 + hl) * 64];                  \
     }
     LOAD_W1(0)
+    // software pipeline: the features of chunk ci+1 are blended / split / stored (VALU + LDS stores) in the same barrier interval
+    // as the MFMAs of chunk ci, so the two interleave; the taps of chunk ci+2 are requested as soon as the tap registers are free
+    taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(lds), reinterpret_cast<uint2 *>(lds + 256), tid);
+    { int mi, co; chunk_info(1, mi, co); if (co == 0) taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
     for (int ci = 0; ci < NCHUNK; ci++) {
-        uint4 *buf = lds + (ci & 1) * 512;          // {hi [4 kb][64], lo [4 kb][64]}
-        taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(buf), reinterpret_cast<uint2 *>(buf + 256), tid);
-        __syncthreads();
-        if (ci + 1 < NCHUNK) {
-            int mi, co; chunk_info(ci + 1, mi, co);
-            if (co == 0) taps_geom(a, mi, sUV, tid, tg);        // a new map: new texel offsets / fractions (uniform branch)
-            taps_issue(a, b, mi, co, tg, tp);
-        }
+        uint4 *buf = lds + (ci & 1) * 512, *nbuf = lds + ((ci + 1) & 1) * 512;      // {hi [4 kb][64], lo [4 kb][64]}
+        __syncthreads();                        // chunk ci visible; the other buffer's readers (MFMAs of chunk ci-1) are done
 #pragma unroll
         for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
+        if (ci + 1 < NCHUNK) {
+            taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid);
+            if (ci + 2 < NCHUNK) {
+                int mi, co; chunk_info(ci + 2, mi, co);
+                if (co == 0) taps_geom(a, mi, sUV, tid, tg);        // a new map: new texel offsets / coefficients (uniform branch)
+                taps_issue(a, b, mi, co, tg, tp);
+            }
+        }
         LOAD_W1(ci + 1)
     }
     {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (K32 step 19, k = 8 q + t: only q == 0, t < 3 are non-zero)
@@ -593,17 +599,28 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         for (int g = 0; g < G; g++) { dd[g][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dd[g][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
+            // all (head, channel tile) accumulators take their hi.hi product first, then hi.lo, then lo.hi: 2 G independent MFMAs
+            // sit between two that touch the same accumulator
+            h8 wh[G][2], wl[G][2], xh[G], xl[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const uint4 *f = Sl + (((g * 4 + s) * 2) * 2) * 64 + lane;
-                const h8 w0h = as_h8(f[0]), w0l = as_h8(f[64]), w1h = as_h8(f[128]), w1l = as_h8(f[192]);
-                const h8 xh = as_h8(dh[g][s][0]), xl = as_h8(dh[g][s][1]);
-                dd[g][0] = MFMAH(w0h, xh, dd[g][0]); dd[g][1] = MFMAH(w1h, xh, dd[g][1]);
-                dd[g][0] = MFMAH(w0h, xl, dd[g][0]); dd[g][1] = MFMAH(w1h, xl, dd[g][1]);
-                dd[g][0] = MFMAH(w0l, xh, dd[g][0]); dd[g][1] = MFMAH(w1l, xh, dd[g][1]);
+                wh[g][0] = as_h8(f[0]); wl[g][0] = as_h8(f[64]); wh[g][1] = as_h8(f[128]); wl[g][1] = as_h8(f[192]);
+                xh[g] = as_h8(dh[g][s][0]); xl[g] = as_h8(dh[g][s][1]);
             }
+#pragma unroll
+            for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wh[g][0], xh[g], dd[g][0]); dd[g][1] = MFMAH(wh[g][1], xh[g], dd[g][1]); }
+#pragma unroll
+            for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wh[g][0], xl[g], dd[g][0]); dd[g][1] = MFMAH(wh[g][1], xl[g], dd[g][1]); }
+#pragma unroll
+            for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wl[g][0], xh[g], dd[g][0]); dd[g][1] = MFMAH(wl[g][1], xh[g], dd[g][1]); }
         }
         taps_store_grad(tp, tgb, bu, bv, tid);
+        if (ci + 1 < NCHUNK) {                             // the tap registers are free again: request chunk ci+1 right away
+            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
+            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
+            taps_issue(a, b, m2i, c2o, tgb, tp);
+        }
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
         if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
         float su = 0.f, sv = 0.f;
@@ -627,11 +644,6 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         const float czv = pr == 0 ? j0zv : (pr == 3 ? -1.f : 0.f);
         gx = __builtin_fmaf(su, cxu, gx); gy = __builtin_fmaf(sv, cyv, gy); gz = __builtin_fmaf(sv, czv, __builtin_fmaf(su, czu, gz));
         __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffers free again
-        if (ci + 1 < NCHUNK) {
-            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
-            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
-            taps_issue(a, b, m2i, c2o, tgb, tp);
-        }
     }
 #undef SLAB_DMA
     {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
