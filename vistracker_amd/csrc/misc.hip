@@ -356,50 +356,45 @@ extern "C" int vt_rigid_backward(const float *X0, int shared_x0, const float *s,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// temporal stencils: thread == one column of v (B,D), walks the frames with a sliding window so that every
-// gradient element is written exactly once (no atomics):  a_b = 2 v_b - v_{b-1} - v_{b+1}
+// temporal stencils over the frames of a batch, v (B, D):  a_b = 2 v_b - v_{b-1} - v_{b+1}  (b = 1 .. B-2).
+// thread == one ELEMENT (frame f, column i): it sums the (up to three) stencils that touch v[f][i], so every gradient element is
+// written exactly once (no atomics) and the B frames are not walked serially (a thread-per-column walk was latency bound: 59 us).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict__ v, int B, int Dcols, int D, const float *__restrict__ elem_w,
                                                          float gs, double *term, float *__restrict__ dv)
 {
     // D = row stride (floats per frame), Dcols = columns that take part
     __shared__ double red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (i < Dcols) {
+    // grid-stride over the elements: at most 512 blocks, so the fp64 atomics on the loss term (one per block, all arriving at the end)
+    // do not serialise the tail of the kernel
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B * Dcols; t += gridDim.x * 256) {
+        const int f = t / Dcols, i = t - f * Dcols;
         const float w = elem_w ? elem_w[i] : 1.f;
-        float vm = v[i], v0 = v[(size_t)D + i], vp = v[(size_t)2 * D + i];
-        float a_prev = 0.f, a_cur = 2.f * v0 - vm - vp, a_next;
-        // b = index of a_cur's centre frame
-        for (int b = 1; b <= B - 2; b++) {
-            float vpp = 0.f;
-            if (b + 2 < B) { vpp = v[(size_t)(b + 2) * D + i]; a_next = 2.f * vp - v0 - vpp; } else a_next = 0.f;
-            acc += (double)(w * a_cur * a_cur);
-            if (dv) {
-                if (b == 1) dv[i] += gs * w * (-a_cur);
-                dv[(size_t)b * D + i] += gs * w * (2.f * a_cur - a_prev - a_next);
-                if (b == B - 2) dv[(size_t)(B - 1) * D + i] += gs * w * (-a_cur);
-            }
-            a_prev = a_cur; a_cur = a_next; vm = v0; v0 = vp; vp = vpp;
-        }
+        auto at = [&](int b) { return v[(size_t)min(max(b, 0), B - 1) * D + i]; };
+        const float vm2 = at(f - 2), vm1 = at(f - 1), v0 = at(f), vp1 = at(f + 1), vp2 = at(f + 2);
+        // stencils centred on f-1, f, f+1 (a stencil exists for centres 1 .. B-2)
+        const float a_m = (f - 1 >= 1 && f - 1 <= B - 2) ? 2.f * vm1 - vm2 - v0 : 0.f;
+        const float a_0 = (f >= 1 && f <= B - 2) ? 2.f * v0 - vm1 - vp1 : 0.f;
+        const float a_p = (f + 1 >= 1 && f + 1 <= B - 2) ? 2.f * vp1 - v0 - vp2 : 0.f;
+        acc += (double)(w * a_0 * a_0);
+        if (dv) dv[(size_t)f * D + i] += gs * w * (2.f * a_0 - a_m - a_p);
     }
     term_add(acc / ((double)(B - 2) * Dcols), term, red);
 }
 
+// d_b = v_b - v_{b-1} (b = 1 .. B-1): loss mean(d^2); thread == one element, as above
 __global__ __launch_bounds__(256) void velocity_loss_kernel(const float *__restrict__ v, int B, int D, float gs, double *term, float *__restrict__ dv)
 {
     __shared__ double red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (i < D) {
-        float prev = v[i], d_prev = 0.f;
-        for (int b = 1; b < B; b++) {
-            const float cur = v[(size_t)b * D + i], d = cur - prev;
-            acc += (double)(d * d);
-            if (dv) dv[(size_t)(b - 1) * D + i] += gs * (d_prev - d);
-            d_prev = d; prev = cur;
-        }
-        if (dv) dv[(size_t)(B - 1) * D + i] += gs * d_prev;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B * D; t += gridDim.x * 256) {
+        const int f = t / D, i = t - f * D;
+        const float v0 = v[(size_t)f * D + i];
+        const float d0 = f >= 1 ? v0 - v[(size_t)(f - 1) * D + i] : 0.f;          // d_f
+        const float d1 = f + 1 < B ? v[(size_t)(f + 1) * D + i] - v0 : 0.f;        // d_{f+1}
+        acc += (double)(d0 * d0);
+        if (dv) dv[(size_t)f * D + i] += gs * (d0 - d1);
     }
     term_add(acc / ((double)(B - 1) * D), term, red);
 }
@@ -409,7 +404,7 @@ extern "C" int vt_accel_loss(const float *v, int B, int D, const float *elem_w, 
     VT_REQUIRE(v && B >= 3 && D > 0, "vt_accel_loss: needs B >= 3 (the reference returns NaN for empty stencils)");
     // d/dv of mean(w a^2): 2 w a / cnt per stencil element; a's own coefficient 2 is folded in the kernel
     const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
-    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, D, elem_w, gs, term, dv);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, D, elem_w, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -417,7 +412,7 @@ extern "C" int vt_accel_loss_strided(const float *v, int B, int D, int stride, c
 {
     VT_REQUIRE(v && B >= 3 && D > 0 && stride >= D, "vt_accel_loss_strided: needs B >= 3 and stride >= D");
     const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
-    hipLaunchKernelGGL(accel_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, stride, elem_w, gs, term, dv);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, stride, elem_w, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -425,7 +420,7 @@ extern "C" int vt_velocity_loss(const float *v, int B, int D, float gscale, doub
 {
     VT_REQUIRE(v && B >= 2 && D > 0, "vt_velocity_loss: needs B >= 2");
     const float gs = 2.f * gscale / ((float)(B - 1) * (float)D);
-    hipLaunchKernelGGL(velocity_loss_kernel, dim3((D + 255) / 256), dim3(256), 0, vt_stream(stream), v, B, D, gs, term, dv);
+    hipLaunchKernelGGL(velocity_loss_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

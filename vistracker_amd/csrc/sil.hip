@@ -149,10 +149,11 @@ __global__ __launch_bounds__(64) void sil_sweep_mask_kernel(const int *__restric
     }
 }
 
-// Kato et al. edge-sweep surrogate gradient, one wave per (frame, visible doubled face).  The six (edge, axis) walks are uniform;
-// lanes take the positions d0 along the edge.  The outward sweep of a position only visits the pixels flagged in the sweep masks
-// (exactly the pixels whose term is non-zero), the inward sweep is bounded by the face itself.
-// Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
+// Kato et al. edge-sweep surrogate gradient, one wave per (frame, visible doubled face).  A face has six (edge, axis) walks of
+// a few positions d0 each; their positions are laid end to end and dealt to the lanes, so all six walks run concurrently (walking
+// them one after the other left ~10 of 64 lanes busy and chained six rounds of dependent loads).  The outward sweep of a position
+// only visits the pixels flagged in the sweep masks (exactly the pixels whose term is non-zero), the inward sweep is bounded by
+// the face itself.  Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
 __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
                                     const unsigned long long *__restrict__ colmask, float eps, float *__restrict__ gproj)
@@ -165,72 +166,100 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
     const int f = f2 < NF ? f2 : f2 - NF;
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
-    float fc[9];
+    float P[3][2];          // corners in pixel units
 #pragma unroll
-    for (int e = 0; e < 9; e++) fc[e] = fcbuf[((size_t)b * 2 * NF + f2) * 9 + e];
-    float gface[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int k = 0; k < 3; k++) {
+        P[k][0] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k] * is + is - 1);
+        P[k][1] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k + 1] * is + is - 1);
+    }
+    // walk w = 2 edge + axis covers d0 in [from[w], from[w] + cnt[w]) along the axis; start[] = exclusive prefix of cnt[]
+    int from[6], start[7];
+    start[0] = 0;
+#pragma unroll
+    for (int w = 0; w < 6; w++) {
+        const int edge = w >> 1, axis = w & 1;
+        const float a0 = P[edge][axis], a1 = P[(edge + 1) % 3][axis];
+        const int d0_from = (int)fmaxf(ceilf(fminf(a0, a1)), 0.0f), d0_to = (int)fminf(fmaxf(a0, a1), (float)(is - 1));
+        from[w] = d0_from; start[w + 1] = start[w] + max(d0_to - d0_from + 1, 0);
+    }
+    float acc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #define PIX(d0_, d1_, axis_) ((axis_) == 0 ? (size_t)(is - 1 - (d1_)) * is + (d0_) : (size_t)(is - 1 - (d0_)) * is + (d1_))
-    for (int edge = 0; edge < 3; edge++) {
-        int pi[3]; float pp[3][2];
-        for (int k = 0; k < 3; k++) pi[k] = (edge + k) % 3;
-        for (int k = 0; k < 3; k++) for (int dim = 0; dim < 2; dim++) pp[k][dim] = 0.5f * (fc[3 * pi[k] + dim] * is + is - 1);
-        for (int axis = 0; axis < 2; axis++) {
-            float p[3][2];
-            for (int k = 0; k < 3; k++) for (int dim = 0; dim < 2; dim++) p[k][dim] = pp[k][(dim + axis) % 2];
-            int direction;
-            if (axis == 0) direction = (p[0][0] < p[1][0]) ? -1 : 1; else direction = (p[0][0] < p[1][0]) ? 1 : -1;
-            const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f);
-            const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
-            const unsigned long long *masks = (axis == 0 ? colmask : rowmask) + (size_t)b * is * wpl;
-            for (int d0 = d0_from + lane; d0 <= d0_to; d0 += 64) {
-                const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-                const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-                const int d1_out = d1_in + direction;
-                if (d1_in < 0 || is <= d1_in) continue;
-                if (d1_out < 0 || is <= d1_out) continue;
-                const size_t idx_in = PIX(d0, d1_in, axis), idx_out = PIX(d0, d1_out, axis);
-                const float alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
-                const float sA = (p[1][0] != d0) ? (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f / is : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
-                const float sB = (p[0][0] != d0) ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f / is : 0.f;   // ... for corner 1
-                if (fim[idx_in] == f2) {   // sweep outwards from the edge: only flagged pixels have a non-zero term (alpha_in = 1)
-                    const int d1_limit = (0 < direction) ? is - 1 : 0;
-                    const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
-                    for (int wd = d1_from >> 6; wd <= (d1_to >> 6); wd++) {
-                        unsigned long long bits = masks[(size_t)d0 * wpl + wd];
-                        const int lo = max(d1_from - wd * 64, 0), hi = min(d1_to - wd * 64, 63);
-                        bits &= (~0ull << lo) & (~0ull >> (63 - hi));
-                        while (bits) {
-                            const int d1 = wd * 64 + __ffsll((long long)bits) - 1; bits &= bits - 1;
-                            const float diff_grad = -gal[PIX(d0, d1, axis)];
-                            if (diff_grad <= 0) continue;
-                            if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
-                            if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
-                        }
-                    }
-                }
-                if (alpha_out == 0.f) {     // sweep inwards over this face's own pixels ((1 - alpha_out) * g vanishes otherwise)
-                    float d0_cross2;
-                    if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) d0_cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-                    else d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
-                    const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
-                    const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
-                    for (int d1 = d1_from; d1 <= d1_to; d1++) {
-                        const size_t idx = PIX(d0, d1, axis);
-                        if (fim[idx] != f2) continue;
-                        const float diff_grad = gal[idx];
+    for (int base = 0; base < start[6]; base += 64) {
+        const int idx = base + lane;
+        if (idx >= start[6]) continue;
+        int w = 0, d0 = from[0] + idx;
+#pragma unroll
+        for (int k = 1; k < 6; k++) if (idx >= start[k]) { w = k; d0 = from[k] + idx - start[k]; }
+        const int edge = w >> 1, axis = w & 1;
+        // corners of this walk: p[k] = P[(edge + k) % 3] with the walk axis first
+        float p[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float q0 = edge == 0 ? P[k][0] : (edge == 1 ? P[(k + 1) % 3][0] : P[(k + 2) % 3][0]);
+            const float q1 = edge == 0 ? P[k][1] : (edge == 1 ? P[(k + 1) % 3][1] : P[(k + 2) % 3][1]);
+            p[k][0] = axis == 0 ? q0 : q1; p[k][1] = axis == 0 ? q1 : q0;
+        }
+        int direction;
+        if (axis == 0) direction = (p[0][0] < p[1][0]) ? -1 : 1; else direction = (p[0][0] < p[1][0]) ? 1 : -1;
+        const unsigned long long *masks = (axis == 0 ? colmask : rowmask) + (size_t)b * is * wpl;
+        float ga = 0.f, gb = 0.f;       // gradient of corner edge (p[0]) and corner edge+1 (p[1]) along the other axis
+        do {
+            const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+            const int d1_in = (0 < direction) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+            const int d1_out = d1_in + direction;
+            if (d1_in < 0 || is <= d1_in) break;
+            if (d1_out < 0 || is <= d1_out) break;
+            const size_t idx_in = PIX(d0, d1_in, axis), idx_out = PIX(d0, d1_out, axis);
+            const float alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
+            const float sA = (p[1][0] != d0) ? (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f / is : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
+            const float sB = (p[0][0] != d0) ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f / is : 0.f;   // ... for corner 1
+            if (fim[idx_in] == f2) {   // sweep outwards from the edge: only flagged pixels have a non-zero term (alpha_in = 1)
+                const int d1_limit = (0 < direction) ? is - 1 : 0;
+                const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
+                for (int wd = d1_from >> 6; wd <= (d1_to >> 6); wd++) {
+                    unsigned long long bits = masks[(size_t)d0 * wpl + wd];
+                    const int lo = max(d1_from - wd * 64, 0), hi = min(d1_to - wd * 64, 63);
+                    bits &= (~0ull << lo) & (~0ull >> (63 - hi));
+                    while (bits) {
+                        const int d1 = wd * 64 + __ffsll((long long)bits) - 1; bits &= bits - 1;
+                        const float diff_grad = -gal[PIX(d0, d1, axis)];
                         if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[0]][1 - axis] -= diff_grad / dist; }
-                        if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gface[pi[1]][1 - axis] -= diff_grad / dist; }
+                        if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= diff_grad / dist; }
+                        if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= diff_grad / dist; }
                     }
                 }
             }
-        }
+            if (alpha_out == 0.f) {     // sweep inwards over this face's own pixels ((1 - alpha_out) * g vanishes otherwise)
+                float d0_cross2;
+                if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) d0_cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+                else d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
+                const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
+                const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
+                for (int d1 = d1_from; d1 <= d1_to; d1++) {
+                    const size_t ix = PIX(d0, d1, axis);
+                    if (fim[ix] != f2) continue;
+                    const float diff_grad = gal[ix];
+                    if (diff_grad <= 0) continue;
+                    if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= diff_grad / dist; }
+                    if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= diff_grad / dist; }
+                }
+            }
+        } while (false);
+        // corner `edge` takes ga, corner (edge + 1) % 3 takes gb, both in the component perpendicular to the walk axis
+        const int ka = edge, kb = edge == 2 ? 0 : edge + 1, c = 1 - axis;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) acc[k][cc] += (cc == c) ? ((k == ka ? ga : 0.f) + (k == kb ? gb : 0.f)) : 0.f;
     }
 #undef PIX
-    for (int k = 0; k < 3; k++) for (int c = 0; c < 2; c++) {
-        const float g = wave_sum(gface[k][c]);
-        if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, g);
-    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float g = wave_sum(acc[k][c]);
+            if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, g);
+        }
 }
 
 __global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const float *__restrict__ gproj,
@@ -249,11 +278,14 @@ __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restr
                                                             const float *__restrict__ occ, int B, int npx, float gs, double *term,
                                                             float *per_frame, float *__restrict__ d_image)
 {
+    // grid = (slices, B): a frame's pixels are split over gridDim.x blocks (one block per frame left most of the chip idle);
+    // per_frame is only supported with one slice
     __shared__ double red[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const float ob = occ[b];
     double acc = 0;
-    for (int i = threadIdx.x; i < npx; i += 256) {
+    const int per_slice = (npx + gridDim.x - 1) / gridDim.x, i_end = min(npx, (int)(blockIdx.x + 1) * per_slice);
+    for (int i = blockIdx.x * per_slice + threadIdx.x; i < i_end; i += 256) {
         const size_t o = (size_t)b * npx + i;
         const float d = keep[o] * image[o] - ref[o];
         acc += (double)(d * d);
@@ -310,7 +342,7 @@ extern "C" int vt_sil_mask_loss(const float *image, const float *keep, const flo
                                 double *term, float *per_frame, float *d_image, void *stream)
 {
     VT_REQUIRE(image && keep && ref && occ && B > 0 && size > 0, "vt_sil_mask_loss: bad argument");
-    hipLaunchKernelGGL(sil_mask_loss_kernel, dim3(B), dim3(256), 0, vt_stream(stream), image, keep, ref, occ, B, size * size, gscale / (float)B,
+    hipLaunchKernelGGL(sil_mask_loss_kernel, dim3(per_frame ? 1 : 4, B), dim3(256), 0, vt_stream(stream), image, keep, ref, occ, B, size * size, gscale / (float)B,
                        term, per_frame, d_image);
     VT_LAUNCH_CHECK();
     return VT_OK;
