@@ -34,6 +34,17 @@ FLOP_PER_POINT_OBJECT = 4 * (611 * 128 + 2 * 128 * 128 + 128 * 2)
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
+PMC_FILE = os.path.join(ROOT, "profiles", "r01k_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+
+
+def pmc_traffic_bytes():
+    """HBM-side bytes per launch of the human query kernel from the committed PMC summary: FETCH_SIZE and WRITE_SIZE are in KB and
+    come from separate passes; FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
+    try:
+        d = json.load(open(PMC_FILE))
+        return 1024.0 * (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"])
+    except Exception:
+        return None
 
 
 def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0):
@@ -207,7 +218,8 @@ def main():
                        "early_stop": "reference rule, evaluated on device", "sharding": f"{world} ranks x {args.steps} batches, no collective in the fit"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
-                         "traffic": None, "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01k_pmc_query_human.json)",
+                         "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
                          "avg_launch_ms": 1e3 * float(th.mean()), "launches": int(len(th)), "flop_per_launch": flops_h,
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
