@@ -134,3 +134,50 @@ def test_silhouette_module_and_chamfer_api(synth):
     ref = O.chamfer_ragged([x.detach().cpu().numpy() for x in xs], [y.cpu().numpy() for y in ys])
     assert none is None and abs(d.item() - ref) < 1e-5 * ref
     d.backward(); assert xs[0].grad.abs().sum() > 0
+
+
+def test_recon_fitter_driver_api(synth, dropin):
+    """The driver-level mirror (vistracker_amd.recon_fit.ReconFitterTriVisFull): reference call signatures and return values
+    (recon_fit_triplane.py:70-100 use sites), results identical to the fused loops it wraps."""
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.recon_fit import ReconFitterTriVisFull
+    from vistracker_amd.sifnet import SIFNetQuery
+    from vistracker_amd.silhouette import SilLossROI
+    S = dropin
+    g = golden("smplfit"); B = 4
+    ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, 500, seed=6)
+    fitter = ReconFitterTriVisFull("seq", debug=False, outpath=None, args=None, smpl_model=synth["model"], regressors=synth["regs"],
+                                   priors=synth["priors"], decoders=synth["decoders"], part_labels=synth["labels"], scan=(ov, of), obj_points=opts)
+    net = SIFNetQuery(synth["decoders"]); net.set_feature_maps(syn.feature_maps(B, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+    cc = torch.tensor(g["crop_center"], device="cuda"); bc = torch.tensor(g["body_center"], device="cuda")
+    smpl = S.SMPLHGenerator.get_smplh(g["pose"], g["betas"], g["trans"], "male", "cuda:0", model_root=synth["model"])
+    data = {"net": net, "query_dict": {"crop_center": cc, "body_center": bc}, "body_kpts": torch.tensor(g["body_kpts"], device="cuda")}
+
+    # statics behave like the reference's
+    M = torch.eye(3, device="cuda").repeat(B, 1, 1) + 0.05 * torch.randn(B, 3, 3, device="cuda")
+    R = fitter.project_so3(M)
+    assert torch.allclose(torch.bmm(R, R.transpose(1, 2)), torch.eye(3, device="cuda").repeat(B, 1, 1), atol=1e-5) and (torch.det(R) > 0).all()
+    assert torch.allclose(torch.bmm(fitter.inverse(M), M), torch.eye(3, device="cuda").repeat(B, 1, 1), atol=1e-4)
+    assert set(fitter.get_opt_iters()) == {"sil", "object"} and abs(fitter.get_loss_weights()["df_h"](2.0, 1.0) - 100.0) < 1e-6
+
+    # SMPL stage: same numbers as the fused loop called directly
+    p0, b0, t0 = (torch.tensor(g[k], device="cuda") for k in ("pose", "betas", "trans"))
+    ref = fitter.ctx.optimize_smpl(net.maps, p0, b0, t0, cc, bc, data["body_kpts"], max_iter=2, iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1)
+    smpl_out, scale = fitter.optimize_smpl(smpl, data, iter_for_kpts=1, iter_for_pose=1, iter_for_betas=1, max_iter=2)
+    assert smpl_out is smpl and scale.shape == (B,) and torch.isfinite(scale).all()
+    assert torch.equal(smpl.pose.data, p0) and torch.equal(smpl.trans.data, t0) and torch.equal(smpl.betas.data[:, :2], b0[:, :2])
+    assert np.array_equal(np.asarray(g["betas"], np.float32)[:, 2:], smpl.betas.data[:, 2:].cpu().numpy())      # copy_smpl_params keeps betas[2:]
+    assert fitter.last["smpl"].steps == ref.steps
+
+    # object stage: masks -> SilLossROI -> three phases; obj_R / obj_t updated in place and returned
+    images = torch.zeros(B, 8, 512, 512, device="cuda"); images[:, 4, 200:330, 180:300] = 1.0; images[:, 3, 100:260, 250:330] = 1.0
+    data.update({"images": images, "camera_params": None, "crop_size": 1200, "net_input_size": 512, "smpl": smpl,
+                 "obj_R": torch.eye(3, device="cuda").repeat(B, 1, 1).contiguous(), "obj_t": (bc + torch.tensor([0.3, 0.0, 0.1], device="cuda")).contiguous(),
+                 "obj_s": torch.ones(B, device="cuda"), "occ_ratios": torch.tensor([1.0, 0.8, 0.6, 0.9])})
+    R_before = data["obj_R"].clone()
+    out_smpl, oR, ot = fitter.optimize_smpl_object(net, data, obj_iter=20, joint_iter=10, steps_per_iter=10)
+    assert out_smpl is smpl and oR is data["obj_R"] and ot is data["obj_t"] and isinstance(data["silhouette"], SilLossROI)
+    res = fitter.last["object"]
+    assert res.steps >= 10 and np.isfinite(res.losses[:res.steps]).all() and not torch.equal(oR, R_before)
+    X = fitter.transform_obj_verts(torch.tensor(opts, device="cuda"), fitter.decopose_axis(oR, no_rand=True), ot, data["obj_s"])
+    assert X.shape == (B, 500, 3) and torch.isfinite(X).all()
