@@ -143,6 +143,15 @@ int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *p
                          const float *body_center, int B, int N, const float *occ, float w_obj,
                          float *dpts, double *terms, void *stream);
 
+/* One projection step of the SIF-Net surface-point generator, fused.  Replaces one iteration of
+ * Generator.approx_surface (recon/gen/generator.py:72-103): query -> target = clamp(df[:, df_idx], max = threshold) ->
+ * autograd of sum(target) to the samples -> samples - F.normalize(grad, dim=2) * target.  df_idx 0 = human, 1 = object.
+ * pts_out (B,N,3) may alias pts (every point is read and written by exactly one workgroup); df_target (B,N) or NULL receives
+ * the clamped distance at the INPUT positions (what the caller thresholds with filter_val). */
+int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
+                          const float *body_center, int B, int N, int df_idx, float threshold, float *pts_out,
+                          float *df_target, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * SO(3) projection.  Replaces ReconFitterBase.project_so3 / decopose_axis (recon/recon_fit_base.py:179-199,
  * 462-469): R = U diag(1,1,det(U V^T)) V^T of M; noise (B,3,3) or NULL is the U[0,1) sample, M = M0 + 1e-4*noise.

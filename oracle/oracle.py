@@ -194,6 +194,22 @@ class SifNet:
         return dpts
 
 
+def approx_surface(net: "SifNet", samples, num_steps, crop_center, body_center, df_idx, threshold=1.0):
+    """Generator.approx_surface (recon/gen/generator.py:72-103): num_steps times  target = clamp(df[:, idx], max = thr);
+    g = d sum(target) / d samples;  samples -= g / max(|g|, 1e-12) * target.  Returns (samples, target at the last query)."""
+    x = np.asarray(samples, np.float32).copy()
+    tgt = None
+    for _ in range(num_steps):
+        df = net.query(x, crop_center, body_center, head_mask=1)[0]
+        d = df[:, df_idx].astype(np.float32)
+        tgt = np.minimum(d, np.float32(threshold))
+        d_df = np.zeros_like(df); d_df[:, df_idx] = (d <= threshold).astype(np.float32)
+        g = net.query_bwd(x, crop_center, body_center, d_df=d_df)
+        nrm = np.maximum(np.sqrt((g.astype(np.float32) ** 2).sum(-1, keepdims=True)), np.float32(1e-12))
+        x = (x - g / nrm * tgt[..., None]).astype(np.float32)
+    return x, tgt
+
+
 def so3_project(M):
     M, p = _f(M); B = M.shape[0]; R = np.empty((B, 3, 3), np.float32)
     lib().vto_so3_project(p, B, _fp(R))

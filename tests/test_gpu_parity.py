@@ -300,3 +300,35 @@ def test_kpts_and_sqdiff(hip):
     d = a[:, 3:72].astype(np.float64) - b
     assert abs(term.item() - (d ** 2).sum() / B) < 1e-5 * (d ** 2).sum() / B
     assert rel(npy(da)[:, 3:72], 2 * d / B * 2.0) < 1e-5 and np.abs(npy(da)[:, 72:]).max() == 0
+
+
+def test_generator_projection_vs_reference(hip, synth):
+    """vt_query_project_step / Generator.approx_surface against the reference's own projection (tests/golden/gensurf.npz) and
+    the generator loop's contract (recon/gen/generator.py:149-257)."""
+    from vistracker_amd.generator import GeneratorTriplaneVis
+    from vistracker_amd.sifnet import SIFNetQuery
+    from vistracker_amd import synthetic as syn
+    g = golden("gensurf"); ops = hip["ops"]
+    B, N = g["pts"].shape[:2]
+    net = SIFNetQuery(synth["decoders"]); net.set_feature_maps(syn.feature_maps(B, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+    gen = GeneratorTriplaneVis(net, "exp", threshold=1.0, filter_val=0.03, seed=5)
+    q = {"crop_center": cu(g["crop_center"]), "body_center": cu(g["body_center"])}
+    for idx, name in enumerate(("human", "object")):
+        one, dft = ops.sifnet_project_step(net.handle, net.maps, cu(g["pts"]), q["crop_center"], q["body_center"], idx, 1.0)
+        assert np.abs(npy(one) - g[name + "_step1"]).max() < 2e-5, name
+        assert dft.shape == (B, N) and bool(torch.isfinite(dft).all()) and float(dft.max()) <= 1.0
+        surf, preds = gen.approx_surface(net, cu(g["pts"]), int(g["steps"]), q, df_type=name)
+        d = np.linalg.norm(npy(surf) - g[name + "_surface"], axis=-1)
+        assert np.median(d) < 2e-5 and np.quantile(d, 0.97) < 1e-3, (name, np.median(d), d.max())
+        # predictions of the last query (positions before the last move), all five heads
+        for k, p in zip(("df", "pca", "parts", "centers", "vis"), preds):
+            ref = g[f"{name}_{k}"]; e = np.abs(npy(p).reshape(ref.shape) - ref)
+            assert np.quantile(e, 0.97) < 1e-4 * max(1.0, np.abs(ref).max()), (name, k, e.max())
+    # the generator loop: enough points, all outputs shaped like the reference's dict
+    batch = {"crop_center": q["crop_center"], "body_center": q["body_center"], "path": ["a"] * B}
+    gen.filter_val = 0.5                                      # random decoders: a loose "near the surface" band keeps the loop short
+    out = gen.gen_pc_batch(net, "object", gen.get_grid_samples(3000, B, q["body_center"]), 200, batch, num_steps=3, max_iter=30)
+    n_out = out["points"].shape[1]                            # the reference keeps min-over-batch of ALL collected points (>= num_points)
+    assert n_out >= 200 and out["points"].shape == (B, n_out, 3) and out["parts"].shape == (B, n_out) and out["pca_axis"].shape == (B, 3, 3)
+    assert out["centers"].shape == (B, 6) and torch.isnan(out["centers"][:, :3]).all() and out["visibility"].shape == (B, 1)
+    assert (out["points"][:, :, 2] > 1.0).all()

@@ -217,3 +217,16 @@ def test_objfit_smooth_field_trajectory(synth):
     assert rel(losses, g["losses64"]) < 1e-3
     assert v2v64 < 1e-3, v2v64
     assert v2v32 < max(1e-3, 2 * ref_self), (v2v32, ref_self)
+
+
+def test_generator_projection(synth):
+    """Generator.approx_surface (recon/gen/generator.py:72-103): one and three projection steps of the reference on CPU."""
+    g = golden("gensurf")
+    net = _net(synth, 3, int(g["maps_seed"]), float(g["res_scale"]))
+    for idx, name in enumerate(("human", "object")):
+        one, _ = O.approx_surface(net, g["pts"], 1, g["crop_center"], g["body_center"], idx)
+        assert np.abs(one - g[name + "_step1"]).max() < 2e-5, name
+        surf, _ = O.approx_surface(net, g["pts"], int(g["steps"]), g["crop_center"], g["body_center"], idx)
+        # a step moves a point by |target| <= 1 m along a unit vector: direction errors compound over the steps
+        d = np.linalg.norm(surf - g[name + "_surface"], axis=-1)
+        assert np.median(d) < 2e-5 and np.quantile(d, 0.97) < 1e-3, (name, np.median(d), d.max())

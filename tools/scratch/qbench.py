@@ -54,3 +54,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "det":
     big = ((outs[1][0] - outs[0][0]).abs() > 1e-5).nonzero()
     print("n big", big.shape[0], big[:20].tolist())
     print("finite", torch.isfinite(outs[0][0]).all().item(), "absmax", outs[0][0].abs().max().item())
+if len(sys.argv) > 3 and sys.argv[3] == "fwd":
+    df = torch.empty(B, 2, N, device=dev); parts = torch.empty(B, 14, N, device=dev)
+    def runf():
+        L.check(L.lib().vt_query_forward(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, df.data_ptr(), None, parts.data_ptr(), None, None, L.stream_ptr()))
+    runf(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps): runf()
+    e1.record(); torch.cuda.synchronize()
+    print("forward only (df, parts):", e0.elapsed_time(e1) / reps, "ms")

@@ -42,7 +42,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define ACT_SCALE 64.0f     /* forward activations enter the MFMAs as 2^6 x */
 #define GO_EXP 5            /* upstream gradients are normalised per point to [2^5, 2^6) */
 
-enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3 };
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3, MODE_PROJECT = 4 };
 
 // Weight fragments (uint4 = 8 halves).  "T" GEMMs: D[row][pt], the weight matrix M[row][k] is the A operand:
 //   T-pack : [K/32 steps][4 waves][2 nt][hi|lo][64 lanes]   halves t = M[32 wave + 16 nt + (lane & 15)][32 s + 8 (lane >> 4) + t]
@@ -74,6 +74,8 @@ struct QArgs {
     float *dpts;
     // fused objectives
     const int *labels; const float *occ; float w0, w1; double *terms;
+    // surface projection step (MODE_PROJECT): w0 = clamp threshold
+    int df_idx; float *pts_out, *dft_out;
 };
 
 __device__ __forceinline__ int map_channels(int mi) { return mi == 0 ? 256 : (mi == 1 ? 64 : (mi < 5 ? 32 : 64)); }
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     float *sPt = reinterpret_cast<float *>(Go + 256);   // [64][3]
     float *sUV = sPt + 64 * 3;              // [4][64][2]
     float *sInv = sUV + 4 * 64 * 2;         // [G][64] inverse of the per-point gradient normalisation
-    int *sIn = reinterpret_cast<int *>(sInv + G * 64);   // [64]
+    float *sDf = sInv + G * 64;             // [64] clamped distance of the point (MODE_PROJECT)
+    int *sIn = reinterpret_cast<int *>(sDf + 64);   // [64]
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
@@ -472,6 +475,14 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                         go[r] = (e / se - (j == lab ? 1.f : 0.f)) * a.w1 / (float)a.B;
                         if (j == lab) loss_acc[1] += (double)(logf(se) - (val - mx));
                     }
+                }
+            } else if (MODE == MODE_PROJECT) {
+                // Generator.approx_surface (recon/gen/generator.py:72-103): target = clamp(df[:, idx], max = threshold), the step
+                // differentiates sum(target): gradient 1 where the prediction is below the threshold and the point is in the image
+                if (j == a.df_idx) {
+                    const float d = inimg ? val : OUT_DIST;
+                    sDf[pt] = fminf(d, a.w0);
+                    if (valid && inimg && d <= a.w0) go[r] = 1.0f;
                 }
             } else {  // MODE_OBJECT: object = mean_B( mean_N clamp(df[:,1], max=.8) * occ )  (recon_fit_trivis_full.py:155-162)
                 if (j == 1 && valid) {
@@ -670,8 +681,16 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     if (q == 0) {
         const int n = n0 + mypt;
         if (n < a.N) {
-            float *o = a.dpts + ((size_t)b * a.N + n) * 3;
-            o[0] = gx; o[1] = gy; o[2] = gz;
+            if (MODE == MODE_PROJECT) {
+                // samples <- samples - normalize(gradient) * target  (F.normalize: g / max(|g|, 1e-12); generator.py:97)
+                const float dft = sDf[mypt], s = dft / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+                float *o = a.pts_out + ((size_t)b * a.N + n) * 3;
+                o[0] = px_ - gx * s; o[1] = py_ - gy * s; o[2] = sPt[mypt * 3 + 2] - gz * s;
+                if (a.dft_out) a.dft_out[(size_t)b * a.N + n] = dft;
+            } else {
+                float *o = a.dpts + ((size_t)b * a.N + n) * 3;
+                o[0] = gx; o[1] = gy; o[2] = gz;
+            }
         }
     }
 }
@@ -787,7 +806,7 @@ extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; hipFree(h->blo
 static size_t lds_bytes(int G)
 {
     const size_t r0 = (size_t)G * 2048 > (size_t)1152 + G * 1024 ? (size_t)G * 2048 : (size_t)1152 + G * 1024;
-    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64) + 8 * sizeof(double);
+    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64 + 64) + 8 * sizeof(double);
 }
 
 template <int G, int MODE>
@@ -851,6 +870,15 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
     VT_REQUIRE(labels && dpts && terms, "vt_query_human_loss: null argument");
     a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
     return launch<2, MODE_HUMAN>(a, vt_stream(stream));
+}
+
+extern "C" int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
+                                     int B, int N, int df_idx, float threshold, float *pts_out, float *df_target, void *stream)
+{
+    QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
+    VT_REQUIRE(pts_out && (df_idx == 0 || df_idx == 1), "vt_query_project_step: pts_out is null or df_idx not in {0 (human), 1 (object)}");
+    a.hw[0] = h->head[0]; a.df_idx = df_idx; a.w0 = threshold; a.pts_out = pts_out; a.dft_out = df_target;
+    return launch<1, MODE_PROJECT>(a, vt_stream(stream));
 }
 
 extern "C" int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,

@@ -1,0 +1,167 @@
+"""SIF-Net surface-point generator on the fused query kernel (generator part).
+
+Mirrors ``recon.gen.generator.Generator`` / ``GeneratorTriplane`` / ``GeneratorTriplaneVis`` (generator.py:23-257,
+generator_triplane.py:14-54, generator_vis.py:14-56): same method names, arguments and output dict.  One projection step
+(query -> clamp -> autograd to the samples -> move along the normalised gradient) is ONE launch
+(``vt_query_project_step``); the predictions the reference returns from ``approx_surface`` -- those of the LAST query, i.e. at
+the positions before the final move -- come from one 5-head forward launch.
+
+Stochastic by construction (grid samples, resampling indices, perturbations): all draws come from one ``torch.Generator``
+(``seed``) on the device, so a run is reproducible, but it is NOT the reference's random stream (the reference mixes CPU
+``torch.randint`` with device ``torch.randn``); parity is pinned per step on ``approx_surface`` (tests/golden/gensurf.npz).
+The image encoder (``filter``) is not part of this module: feed encoder outputs with ``model.set_feature_maps``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class Generator:
+    def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,
+                 filter_val=0.03, seed=0, **kwargs):
+        """``model``: a ``vistracker_amd.sifnet.SIFNetQuery`` (weights already loaded: ``SIFNetQuery.from_state_dict``);
+        ``exp_name / checkpoint / multi_gpus`` are accepted for signature compatibility (generator.py:24-57)."""
+        self.sparse_thres, self.filter_val, self.threshold = sparse_thres, filter_val, threshold
+        self.sample_num = 100000
+        self.model, self.device = model, torch.device(device)
+        self.rng = torch.Generator(device=self.device); self.rng.manual_seed(seed)
+        self.pmin, self.pmax = np.array([-3.0, -0.9, 0.2]), np.array([3.0, 1.80, 4.0])
+        self.init_others(**kwargs)
+
+    def init_others(self, **kwargs):
+        pass
+
+    def update_query_dict(self, points, query_dict):
+        return query_dict
+
+    # ---- the projection (generator.py:72-103) ------------------------------------------------------------------
+    def approx_surface(self, model, samples, num_steps, query_input, df_type):
+        """-> (samples on the surface, predictions of the last query = at the positions before the last move)"""
+        df_idx = 0 if df_type == "human" else 1
+        cc = query_input["crop_center"]; bc = query_input.get("body_center")
+        if bc is None:
+            raise ValueError("the triplane SIF-Net needs body_center in the query input (generator_triplane.py:15-31)")
+        samples = samples.detach().contiguous().clone()
+        preds = None
+        for j in range(num_steps):
+            query_input = self.update_query_dict(samples, query_input)
+            if j == num_steps - 1:
+                model.query(samples, **{k: v for k, v in query_input.items()})
+                preds = model.get_preds()
+            ops.sifnet_project_step(model.handle, model.maps, samples, cc, bc, df_idx, self.threshold, out=samples, want_target=False)
+        return samples, preds
+
+    def get_grid_samples(self, sample_num, batch_size=1, body_center=None):
+        return self.init_samples(sample_num, batch_size)
+
+    def init_samples(self, sample_num, batch_size=1, z_0=2.2):
+        """uniform in x [-3,3], y [-2.5,2.5], z [z_0 - .25, z_0 + .25] (generator.py:318-330)"""
+        s = torch.rand(batch_size, sample_num, 3, device=self.device, generator=self.rng)
+        s[:, :, 0] = s[:, :, 0] * 6 - 3; s[:, :, 1] = s[:, :, 1] * 5 - 2.5; s[:, :, 2] = (s[:, :, 2] - 0.5) * 0.5 + z_0
+        return s
+
+    def filter(self, data):
+        self.model.filter(data["images"].to(self.device))
+
+    def prep_query_input(self, batch):
+        return {"crop_center": batch.get("crop_center").to(self.device)}
+
+    def get_out_names(self):
+        return ["points", "pca_axis", "parts", "centers"]
+
+    def parse_preds(self, batch_size, counts, mask, out_dict, out_names, preds, samples_surface):
+        """collect the near-surface points and their predictions per example (generator.py:118-127); stays on the device"""
+        for i in range(batch_size):
+            out_dict["points"][i].append(samples_surface[i, mask[i]].detach())
+            for name, pred in zip(out_names[1:], preds[1:]):
+                out_dict[name][i].append(pred[i, ..., mask[i]].detach())
+            counts.append(int(mask[i].sum().item()))
+
+    def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=True, filter_images=True):
+        if filter_images:
+            self.filter(data)
+        batch_size = (data.get("images") if data.get("images") is not None else data.get("crop_center")).shape[0]
+        samples = self.get_grid_samples(30000, batch_size=batch_size, body_center=data.get("body_center", None))
+        return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute) for t in ("human", "object")}
+
+    def gen_pc_batch(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter=100, mute=True):
+        """iterate: project -> keep points with target < filter_val and z > 1 -> resample 20 000 around the kept points
+        (generator.py:149-212)"""
+        query_input = self.prep_query_input(batch)
+        df_idx = 0 if df_type == "human" else 1
+        batch_size = samples_init.shape[0]
+        out_names = self.get_out_names()
+        out_dict = {n: [[] for _ in range(batch_size)] for n in out_names}
+        sample_num = 20000
+        it, samples_count = 0, 0
+        samples = samples_init.clone().to(self.device)
+        while samples_count < num_points:
+            samples_surface, preds = self.approx_surface(model, samples, num_steps, query_input, df_type=df_type)
+            df_target = torch.clamp(preds[0][:, df_idx, :], max=self.threshold)
+            mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0)
+            if it > 0:
+                counts = []
+                self.parse_preds(batch_size, counts, mask, out_dict, out_names, preds, samples_surface)
+                samples_count += int(np.min(counts))
+                if not mute:
+                    print(f"{samples_count} points")
+            new = []
+            for i in range(batch_size):
+                s_i = samples[i, mask[i], :]
+                if s_i.shape[0] > 1:
+                    idx = torch.randint(s_i.shape[0], (sample_num,), device=self.device, generator=self.rng)
+                    s_i = s_i[idx] + (self.threshold / 3) * torch.randn(sample_num, 3, device=self.device, generator=self.rng)
+                else:
+                    idx = torch.randint(samples_init.shape[1], (sample_num,), device=self.device, generator=self.rng)
+                    s_i = samples_init[i, idx].to(self.device) + 0.5 * torch.randn(sample_num, 3, device=self.device, generator=self.rng)
+                new.append(s_i.unsqueeze(0))
+            samples = torch.cat(new, 0).detach()
+            it += 1
+            if it == max_iter:
+                raise RuntimeError(f"point generation for df {df_type} failed after {max_iter} iterations for files: {batch.get('path')}")
+        return self.compose_outdict(batch_size, out_dict, out_names, samples_count, obj_mask=False, query_input=query_input)
+
+    def compose_outdict(self, batch_size, out_dict, out_names, samples_count, obj_mask=False, query_input=None):
+        """points (B,N,3), parts (B,N) argmax, pca_axis (B,3,3) mean, centers (B,3) mean (generator.py:217-257)"""
+        for name in out_names:
+            comb = []
+            for i in range(batch_size):
+                if name == "points":
+                    comb.append(torch.cat(out_dict[name][i], 0)[:samples_count, :]); continue
+                o = torch.cat(out_dict[name][i], -1)[..., :samples_count]
+                m = out_dict["obj_mask"][i][:samples_count] if obj_mask else torch.ones(samples_count, dtype=torch.bool, device=o.device)
+                if name == "parts":
+                    o = torch.argmax(o, 0)
+                elif name == "pca_axis":
+                    o = torch.mean(o[:, :, m], -1)
+                elif name in ("centers", "visibility"):
+                    o = torch.mean(o[:, m], -1)
+                comb.append(o)
+            out_dict[name] = torch.stack(comb, 0)
+        return out_dict
+
+
+class GeneratorTriplane(Generator):
+    def prep_query_input(self, batch):
+        return {"crop_center": batch.get("crop_center").to(self.device), "body_center": batch.get("body_center").to(self.device)}
+
+    def get_grid_samples(self, sample_num, batch_size=1, body_center=None):
+        """a 2 x 3 x 1.2 m box around the body centre (generator_triplane.py:33-54)"""
+        assert body_center is not None
+        s = torch.rand(batch_size, sample_num, 3, device=self.device, generator=self.rng)
+        s[:, :, 0] = s[:, :, 0] * 2 - 1; s[:, :, 1] = s[:, :, 1] * 3 - 1.5; s[:, :, 2] = s[:, :, 2] * 1.2 - 0.6
+        return s + body_center.unsqueeze(1).to(self.device)
+
+
+class GeneratorTriplaneVis(GeneratorTriplane):
+    def get_out_names(self):
+        return ["points", "pca_axis", "parts", "centers", "visibility"]
+
+    def compose_outdict(self, batch_size, out_dict, out_names, samples_count, obj_mask=False, query_input=None):
+        out_dict = super().compose_outdict(batch_size, out_dict, out_names, samples_count, obj_mask, query_input)
+        nan = torch.zeros_like(out_dict["centers"]) + float("nan")          # backward compatibility of the reference: (B,6)
+        out_dict["centers"] = torch.cat([nan, out_dict["centers"]], 1)
+        return out_dict

@@ -264,6 +264,18 @@ def sifnet_query(net, maps, pts, crop_center, body_center, head_mask=31):
     return _QueryFn.apply(net, maps, pts, crop_center, body_center, head_mask)
 
 
+def sifnet_project_step(net, maps, pts, crop_center, body_center, df_idx, threshold=1.0, out=None, want_target=True):
+    """One fused projection step of Generator.approx_surface (recon/gen/generator.py:72-103): returns (new points, clamped
+    distance at the input points).  ``out`` may be ``pts`` itself (in place).  No autograd: the reference detaches here too."""
+    pts = _f32(pts.detach()); B, N = pts.shape[:2]
+    cc = _f32(crop_center); bc = _f32(body_center)
+    out = torch.empty_like(pts) if out is None else out
+    dft = torch.empty(B, N, device=pts.device) if want_target else None
+    L.check(L.lib().vt_query_project_step(net.h, C.byref(maps.c), L.dptr(pts), L.dptr(cc), L.dptr(bc), B, N, int(df_idx), float(threshold),
+                                          L.dptr(out), L.dptr(dft), L.stream_ptr()))
+    return out, dft
+
+
 # --------------------------------------------------------------------------------------------------
 # SO(3) projection, rigid transform
 # --------------------------------------------------------------------------------------------------
