@@ -223,6 +223,15 @@ int vt_sil_backward(const float *verts, int B, int NV, const int *faces, int NF,
 int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size,
                      float gscale, double *term, float *per_frame, float *d_image, void *stream);
 
+/* Triplane masks of the SMPL mesh.  Replaces TriplaneNrRenderer.render_3views
+ * (render/render_triplane_nr.py:86-139): the mesh centred on `center` (B,3) (the SMPL centre, body25 joint 8) is rendered
+ * orthographically from the right (x' = z, y' = -y, depth -x + 10), the back (-x, -y, -z + 10) and the top (x, z, y + 10);
+ * mask = a face covers the pixel with 0.1 < depth < 100.  masks (B,3,size,size) in {0,1}, row 0 = top; face_index (B,3,size,size)
+ * int32 scratch output (front face id or -1); ws >= vt_sil_workspace_floats(3 B, NV, NF, size) floats.  PARITY UNPINNED for the
+ * rasterisation rule (neural_renderer, see vt_sil_forward); the view transforms are pinned (tests/golden/triplane_views.npz). */
+int vt_triplane_render(const float *verts, const float *center, int B, int NV, const int *faces, int NF, int size,
+                       float *masks, int *face_index, float *ws, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Adam.  Replaces torch.optim.Adam(...).step() (defaults betas=(.9,.999), eps=1e-8) on one parameter tensor.
  * `stop_flag` (device int, may be NULL): when *stop_flag != 0 the update is skipped (device-side early stop).

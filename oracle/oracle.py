@@ -273,6 +273,29 @@ def sil_forward(verts, faces, K, size=256):
     return img
 
 
+def triplane_render(verts, faces, center, size=512):
+    """TriplaneNrRenderer.render_3views for a batch: (B,NV,3), (NF,3), (B,3) -> (B,3,size,size) masks (right, back, top)"""
+    verts, vp = _f(verts); faces, fp = _i(faces); center, cp = _f(center)
+    B, NV = verts.shape[:2]
+    out = np.zeros((B, 3, size, size), np.float32)
+    lib().vto_triplane_render(vp, cp, B, NV, fp, faces.shape[0], size, _fp(out))
+    return out
+
+
+def transform_view(points_center, view, z_offset=10.0):
+    """TriplaneNrRenderer.transform_view (render/render_triplane_nr.py:110-139)"""
+    p = np.asarray(points_center, np.float32); o = np.empty_like(p)
+    if view == "right":
+        o[:, 0], o[:, 1], o[:, 2] = p[:, 2], -p[:, 1], -p[:, 0] + z_offset
+    elif view == "back":
+        o[:, 0], o[:, 1], o[:, 2] = -p[:, 0], -p[:, 1], -p[:, 2] + z_offset
+    elif view == "top":
+        o[:, 0], o[:, 1], o[:, 2] = p[:, 0], p[:, 2], p[:, 1] + z_offset
+    else:
+        raise AssertionError(view)
+    return o
+
+
 def sil_backward(verts, faces, K, d_image, size=256, eps=1e-4):
     verts, vp = _f(verts); faces, fp = _i(faces); K, kp = _f(K); d_image, dp = _f(d_image)
     B, NV = verts.shape[:2]

@@ -230,3 +230,19 @@ def test_generator_projection(synth):
         # a step moves a point by |target| <= 1 m along a unit vector: direction errors compound over the steps
         d = np.linalg.norm(surf - g[name + "_surface"], axis=-1)
         assert np.median(d) < 2e-5 and np.quantile(d, 0.97) < 1e-3, (name, np.median(d), d.max())
+
+
+def test_triplane_views():
+    """TriplaneNrRenderer.transform_view (render/render_triplane_nr.py:110-139): the reference's own numpy for the three views."""
+    g = golden("triplane_views")
+    for v in ("right", "back", "top"):
+        assert np.array_equal(O.transform_view(g["pts"], v), g[v]), v
+    # the C rasteriser sees the same views: a tetrahedron off-centre appears where transform_view puts it
+    verts = np.array([[[0.3, 0.2, 0.1], [0.5, 0.2, 0.1], [0.3, 0.5, 0.1], [0.3, 0.2, 0.4]]], np.float32)
+    faces = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], np.int32)
+    m = O.triplane_render(verts, faces, np.zeros((1, 3), np.float32), 128)
+    for i, v in enumerate(("right", "back", "top")):
+        p = O.transform_view(verts[0], v)
+        ys, xs = np.nonzero(m[0, i]); assert len(xs) > 10
+        xn = (2 * xs + 1 - 128) / 128.0; yn = -(2 * ys + 1 - 128) / 128.0          # row 0 = top
+        assert p[:, 0].min() - 0.02 <= xn.min() and xn.max() <= p[:, 0].max() + 0.02 and p[:, 1].min() - 0.02 <= yn.min() and yn.max() <= p[:, 1].max() + 0.02

@@ -29,6 +29,22 @@ __global__ void sil_project_kernel(const float *__restrict__ verts, const float 
     o[0] = 2.0f * (u - 0.5f); o[1] = 2.0f * (w - 0.5f); o[2] = z;
 }
 
+// Orthographic triplane views of a centred mesh (render/render_triplane_nr.py:110-139, TriplaneNrRenderer.transform_view; the
+// renderer is neural_renderer in camera_mode 'look', perspective=False: x, y are used as NDC, z only for near/far).
+// "frame" index of the rasteriser = 3 b + view, view 0 right, 1 back, 2 top.
+__global__ void sil_triplane_project_kernel(const float *__restrict__ verts, const float *__restrict__ center, int NV, float z_offset,
+                                            float *__restrict__ proj)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, bv = blockIdx.y, b = bv / 3, view = bv - 3 * b;
+    if (i >= NV) return;
+    const float *v = verts + ((size_t)b * NV + i) * 3;
+    const float x = v[0] - center[3 * b], y = v[1] - center[3 * b + 1], z = v[2] - center[3 * b + 2];
+    float *o = proj + ((size_t)bv * NV + i) * 3;
+    if (view == 0) { o[0] = z; o[1] = -y; o[2] = -x + z_offset; }
+    else if (view == 1) { o[0] = -x; o[1] = -y; o[2] = -z + z_offset; }
+    else { o[0] = x; o[1] = z; o[2] = y + z_offset; }
+}
+
 __device__ __forceinline__ void load_face(const float *__restrict__ pv, const int *__restrict__ faces, int NF, int f2, float *fc)
 {
     const int f = f2 < NF ? f2 : f2 - NF;
@@ -317,6 +333,26 @@ extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *face
     hipLaunchKernelGGL(sil_scatter_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+extern "C" int vt_triplane_render(const float *verts, const float *center, int B, int NV, const int *faces, int NF, int size, float *masks,
+                                  int *face_index, float *ws, void *stream)
+{
+    VT_REQUIRE(verts && center && faces && masks && face_index && ws && B > 0 && NV > 0 && NF > 0 && size > 0 && size % 64 == 0 && size < 32768,
+               "vt_triplane_render: bad argument (size must be a multiple of 64)");
+    hipStream_t st = vt_stream(stream);
+    const int B3 = 3 * B;
+    const SilWs w = sil_ws(ws, B3, NV, NF, size);
+    hipLaunchKernelGGL(sil_triplane_project_kernel, dim3((NV + 255) / 256, B3), dim3(256), 0, st, verts, center, NV, 10.0f, w.proj);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B3), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
+    VT_LAUNCH_CHECK();
+    VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B3 * size * size, st));
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((2 * NF + 3) / 4, B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B3), dim3(256), 0, st, w.zbuf, NF, size, masks, face_index, w.visible);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
