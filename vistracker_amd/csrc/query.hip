@@ -633,17 +633,23 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             taps_issue(a, b, m2i, c2o, tgb, tp);
         }
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
+        // read this point's tap differences FIRST, then start the DMA of the next slab: hipcc orders an LDS read after an LDS-DMA
+        // with a full vmcnt(0) wait (they may alias), which put the whole DMA latency in front of the epilogue
+        float4 u4[2], v4[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            u4[ct] = *reinterpret_cast<const float4 *>(bu + mypt * TS + 16 * ct + 4 * q);
+            v4[ct] = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
+        }
         if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
         float su = 0.f, sv = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
-            const float4 u4 = *reinterpret_cast<const float4 *>(bu + mypt * TS + 16 * ct + 4 * q);
-            const float4 v4 = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
             float d[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] = __builtin_fmaf(dd[G - 1][ct][r], kscale[G - 1], d[r]); }
-            su = __builtin_fmaf(d[3], u4.w, __builtin_fmaf(d[2], u4.z, __builtin_fmaf(d[1], u4.y, __builtin_fmaf(d[0], u4.x, su))));
-            sv = __builtin_fmaf(d[3], v4.w, __builtin_fmaf(d[2], v4.z, __builtin_fmaf(d[1], v4.y, __builtin_fmaf(d[0], v4.x, sv))));
+            su = __builtin_fmaf(d[3], u4[ct].w, __builtin_fmaf(d[2], u4[ct].z, __builtin_fmaf(d[1], u4[ct].y, __builtin_fmaf(d[0], u4[ct].x, su))));
+            sv = __builtin_fmaf(d[3], v4[ct].w, __builtin_fmaf(d[2], v4[ct].z, __builtin_fmaf(d[1], v4[ct].y, __builtin_fmaf(d[0], v4[ct].x, sv))));
         }
         // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251), branch-free: the chunk's projection picks the
         // coefficients of  gx += su cxu,  gy += sv cyv,  gz += su czu + sv czv
