@@ -165,10 +165,18 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # test hook (tests / dry runs on a 1-GPU box only): all ranks share GPU 0 and the collectives go through gloo on host copies
+    shared_gpu = os.environ.get("VT_BENCH_TEST_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if shared_gpu else dev
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
     model = syn.smplh_model(0); regs = syn.landmark_regressors(model, 1); pri = syn.priors(2); dec = syn.sifnet_decoders(3)
     labels = syn.part_labels(model); ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, N_OBJ, seed=6)
@@ -190,7 +198,7 @@ def main():
     t0 = time.perf_counter()
     results = [fit_batch(ctx, torch, d, prof) for d in batches]
     if world > 1:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch)
-        packed = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(BATCH, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches])
+        packed = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(BATCH, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches]).to(cdev)
         out = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(out, packed)
     torch.cuda.synchronize()
@@ -198,7 +206,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
     if rank == 0:
         frames = world * args.steps * BATCH
@@ -224,7 +232,7 @@ def main():
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps)
         print(json.dumps(line))
     if world > 1:
