@@ -56,8 +56,8 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
 }
 
 // workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
-// x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2)
-struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; float *gproj; };
+// x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2) fp64 (order-insensitive atomics)
+struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; };
 static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
 {
     SilWs w;
@@ -66,12 +66,12 @@ static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
     w.colmask = w.rowmask + (size_t)B * is * (is / 64);                        // (B,is,is/64) bit yi of column xi
     w.proj = reinterpret_cast<float *>(w.colmask + (size_t)B * is * (is / 64));
     w.fc = w.proj + (size_t)B * NV * 3; w.fbox = reinterpret_cast<int2 *>(w.fc + (size_t)B * 2 * NF * 9);
-    w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<float *>(w.visible + (size_t)B * 2 * NF);
+    w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(w.visible + (size_t)B * 2 * NF) + 7) & ~(uintptr_t)7);     // 8-byte aligned
     return w;
 }
 extern "C" long vt_sil_workspace_floats(int B, int NV, int NF, int size)
 {
-    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 2 + 16;
+    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 4 + 16;
 }
 
 // per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void sil_sweep_mask_kernel(const int *__restric
 // the face itself.  Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
 __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
-                                    const unsigned long long *__restrict__ colmask, float eps, float *__restrict__ gproj)
+                                    const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj)
 {
     const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
     if (f2 >= 2 * NF || !visible[(size_t)b * 2 * NF + f2]) return;
@@ -274,17 +274,18 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const float g = wave_sum(acc[k][c]);
-            if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, g);
+            // fp64 accumulation: the per-vertex sum over its faces no longer depends (to fp32 precision) on the order the waves arrive
+            if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, (double)g);
         }
 }
 
-__global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const float *__restrict__ gproj,
+__global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const double *__restrict__ gproj,
                                      float *__restrict__ dverts)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= NV) return;
     const float *v = verts + ((size_t)b * NV + i) * 3, *k = K + 9 * b;
-    const float z = v[2] + 1e-9f, gu = gproj[((size_t)b * NV + i) * 2], gv = gproj[((size_t)b * NV + i) * 2 + 1];
+    const float z = v[2] + 1e-9f, gu = (float)gproj[((size_t)b * NV + i) * 2], gv = (float)gproj[((size_t)b * NV + i) * 2 + 1];
     const float gx_ = 2.f * gu * k[0] - 2.f * gv * k[3], gy_ = 2.f * gu * k[1] - 2.f * gv * k[4];
     float *o = dverts + ((size_t)b * NV + i) * 3;
     o[0] = gx_ / z; o[1] = gy_ / z; o[2] = -(gx_ * v[0] + gy_ * v[1]) / (z * z);
@@ -363,7 +364,7 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
     VT_REQUIRE(verts && faces && K && face_index && d_image && ws && dverts && B > 0, "vt_sil_backward: bad argument");
     hipStream_t st = vt_stream(stream);
     const SilWs w = sil_ws(ws, B, NV, NF, size);
-    VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(float) * (size_t)B * NV * 2, st));
+    VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(double) * (size_t)B * NV * 2, st));
     hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3(size / 64, size, B), dim3(64), 0, st, face_index, d_image, size, w.rowmask, w.colmask);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
