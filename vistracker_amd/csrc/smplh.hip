@@ -423,22 +423,29 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
 {
     __shared__ float red[PT_N], red3[NQ_];
     __shared__ float sdG[J_ * 12], sdJ[J_ * 3], sdR[J_ * 9];
+    __shared__ float sG[J_ * 12], sRm[J_ * 9], sJr[J_ * 3];     // the frame's G, R, J: the serial chain below must not wait on HBM
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *w = ws + (size_t)b * WS_FRAME;
+    for (int i = tid; i < J_ * 12; i += 256) sG[i] = w[WS_G + i];
+    for (int i = tid; i < J_ * 9; i += 256) sRm[i] = w[WS_R + i];
+    for (int i = tid; i < J_ * 3; i += 256) sJr[i] = w[WS_J + i];
+    // all partial loads of an element are independent: issue them in batches of 9 (a rolled loop paid one L2 round trip per partial)
     for (int i = tid; i < PT_N; i += 256) {
         float s = 0.f;
+#pragma unroll 9
         for (int t = 0; t < NVT_; t++) s += part[((size_t)t * B + b) * PT_N + i];
         red[i] = s;
     }
     for (int i = tid; i < NQ_; i += 256) {
         float s = 0.f;
+#pragma unroll 9
         for (int t = 0; t < NKS_; t++) s += part3[((size_t)t * B + b) * NQ_ + i];
         red3[i] = s;
     }
     __syncthreads();
     if (tid < J_) {
         const int j = tid;
-        const float *G = w + WS_G + 12 * j; const float *Jr = w + WS_J;
+        const float *G = sG + 12 * j; const float *Jr = sJr;
         float dj[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 3; r++) {
@@ -452,27 +459,31 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
         for (int e = 0; e < 9; e++) sdR[9 * j + e] = 0.f;
     }
     __syncthreads();
-    if (tid == 0) {
-        const float *Jr = w + WS_J;
-        for (int j = J_ - 1; j >= 1; j--) {
-            const int p = par.p[j];
-            const float *Gp = w + WS_G + 12 * p, *Rj = w + WS_R + 9 * j;
-            const float rel[3] = {Jr[3 * j] - Jr[3 * p], Jr[3 * j + 1] - Jr[3 * p + 1], Jr[3 * j + 2] - Jr[3 * p + 2]};
-            const float *dGj = sdG + 12 * j; float *dGp = sdG + 12 * p;
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++)
-                    dGp[r * 4 + c] += dGj[r * 4] * Rj[3 * c] + dGj[r * 4 + 1] * Rj[3 * c + 1] + dGj[r * 4 + 2] * Rj[3 * c + 2] + dGj[r * 4 + 3] * rel[c];
-                dGp[r * 4 + 3] += dGj[r * 4 + 3];
-            }
-            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
-                sdR[9 * j + 3 * r + c] += Gp[r] * dGj[c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
-            for (int c = 0; c < 3; c++) {
-                const float s = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
-                sdJ[3 * j + c] += s; sdJ[3 * p + c] -= s;
-            }
+    // reverse kinematic chain: joints strictly in order (a parent collects all its children), but the 24 outputs of one joint --
+    // 12 of d G_parent, 9 of d R_j, 3 of d J -- are independent: one thread each, one barrier per joint
+    for (int j = J_ - 1; j >= 1; j--) {
+        const int p = par.p[j];
+        const float *Gp = sG + 12 * p, *Rj = sRm + 9 * j, *dGj = sdG + 12 * j;
+        float upd = 0.f; float *dst = nullptr; float upd2 = 0.f; float *dst2 = nullptr;
+        if (tid < 12) {
+            const int r = tid >> 2, c = tid & 3;
+            dst = sdG + 12 * p + tid;
+            if (c < 3) upd = dGj[r * 4] * Rj[3 * c] + dGj[r * 4 + 1] * Rj[3 * c + 1] + dGj[r * 4 + 2] * Rj[3 * c + 2] + dGj[r * 4 + 3] * (sJr[3 * j + c] - sJr[3 * p + c]);
+            else upd = dGj[r * 4 + 3];
+        } else if (tid < 21) {
+            const int e = tid - 12, r = e / 3, c = e - 3 * r;
+            dst = sdR + 9 * j + e;
+            upd = Gp[r] * dGj[c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
+        } else if (tid < 24) {
+            const int c = tid - 21;
+            upd = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
+            dst = sdJ + 3 * j + c; dst2 = sdJ + 3 * p + c; upd2 = -upd;
         }
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sdR[3 * r + c] += sdG[r * 4 + c]; sdJ[r] += sdG[r * 4 + 3]; }
+        if (dst) *dst += upd;
+        if (dst2) *dst2 += upd2;
+        __syncthreads();
     }
+    if (tid < 3) { for (int c = 0; c < 3; c++) sdR[3 * tid + c] += sdG[tid * 4 + c]; sdJ[tid] += sdG[tid * 4 + 3]; }
     __syncthreads();
     if (tid < J_) {
         const int j = tid;
