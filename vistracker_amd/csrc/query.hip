@@ -78,16 +78,15 @@ struct QArgs {
     int df_idx; float *pts_out, *dft_out;
 };
 
-__device__ __forceinline__ int map_channels(int mi) { return mi == 0 ? 256 : (mi == 1 ? 64 : (mi < 5 ? 32 : 64)); }
-__device__ __forceinline__ int map_proj(int mi) { return mi < 2 ? 0 : (mi < 5 ? mi - 1 : mi - 4); }
-// chunk i (32 channels) -> map index and channel offset inside the map
-__device__ __forceinline__ void chunk_info(int i, int &mi, int &co)
-{
-    if (i < 8) { mi = 0; co = 32 * i; }
-    else if (i < 10) { mi = 1; co = 32 * (i - 8); }
-    else if (i < 13) { mi = i - 8; co = 0; }
-    else { mi = 5 + (i - 13) / 2; co = 32 * ((i - 13) & 1); }
-}
+// chunk i (32 channels) -> map index, channel offset inside the map; map -> channels, projection.  Tables in constant memory: the
+// uniform lookups are scalar loads instead of compare-and-branch chains (a taken branch restarts the instruction fetch).
+//   chunks 0-7 im_feat (256 ch), 8-9 tmpx (64), 10-12 tri_tmpx right/back/top (32 each), 13-18 tri_feat right/back/top (64 each)
+__constant__ int2 kChunk[NCHUNK + 1] = {{0, 0}, {0, 32}, {0, 64}, {0, 96}, {0, 128}, {0, 160}, {0, 192}, {0, 224}, {1, 0}, {1, 32}, {2, 0}, {3, 0}, {4, 0},
+                                        {5, 0}, {5, 32}, {6, 0}, {6, 32}, {7, 0}, {7, 32}, {0, 0}};
+__constant__ int2 kMap[8] = {{256, 0}, {64, 0}, {32, 1}, {32, 2}, {32, 3}, {64, 1}, {64, 2}, {64, 3}};      // {channels, projection}
+__device__ __forceinline__ int map_channels(int mi) { return kMap[mi].x; }
+__device__ __forceinline__ int map_proj(int mi) { return kMap[mi].y; }
+__device__ __forceinline__ void chunk_info(int i, int &mi, int &co) { const int2 c = kChunk[i]; mi = c.x; co = c.y; }
 
 __device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
 // x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32.  Two elements cost 4 VALU instructions: one packed
