@@ -232,6 +232,12 @@ int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, co
 int vt_triplane_render(const float *verts, const float *center, int B, int NV, const int *faces, int NF, int size,
                        float *masks, int *face_index, float *ws, void *stream);
 
+/* Hourglass up-path of the image encoder: out = skip + bicubic x2 upsampling of low, NHWC fp32.  Replaces
+ * `up1 + F.interpolate(low3, scale_factor=2, mode='bicubic', align_corners=True)` (model/HGFilters.py:45-47): cubic convolution with
+ * A = -0.75, source coordinate dst * (h-1)/(2h-1), taps clamped to the border.  low (B,h,w,C), skip (B,2h,2w,C) or NULL, out (B,2h,2w,C);
+ * C must be a multiple of 4.  (The convolutions and group norms of the encoder run on MIOpen through PyTorch.) */
+int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Adam.  Replaces torch.optim.Adam(...).step() (defaults betas=(.9,.999), eps=1e-8) on one parameter tensor.
  * `stop_flag` (device int, may be NULL): when *stop_flag != 0 the update is skipped (device-side early stop).

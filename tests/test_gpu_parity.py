@@ -352,3 +352,39 @@ def test_triplane_renderer(hip, synth):
     masks = r.render_3views(torch.tensor(faces.astype(np.int64)).unsqueeze(0), npy(verts[0] - center[0]))
     assert len(masks) == 3 and masks[0].dtype == bool and np.array_equal(masks[2], m[0, 2] > 0.5)
     assert np.array_equal(TriplaneNrRenderer.transform_view(golden("triplane_views")["pts"], "top"), golden("triplane_views")["top"])
+
+
+def test_encoder_vs_reference(hip):
+    """HGFilter encoders (model/HGFilters.py:54-203, config tri-vis-l2) on MIOpen, channels-last, against the reference modules run on
+    CPU with the same synthetic weights; then filter() -> query() end to end."""
+    from vistracker_amd import synthetic as syn
+    from vistracker_amd.encoder import SIFNetEncoder
+    g = golden("encoder")
+    ks = [(str(n), tuple(int(x) for x in s[:d])) for n, s, d in zip(g["names"], g["shapes"], g["ndims"])]
+    sd = syn.encoder_weights(ks)
+    enc = SIFNetEncoder.from_state_dict(sd)
+    maps = enc(cu(g["images"]))
+    for name, t in zip(hip["ops"].MAP_ORDER, maps.t):
+        ref = g[name].transpose(0, 2, 3, 1)                       # reference NCHW -> the NHWC the query kernel reads
+        e = np.abs(npy(t) - ref).max() / max(1.0, np.abs(ref).max())
+        assert t.shape == ref.shape and e < 2e-4, (name, e)       # fp32 convolutions, different summation orders (MIOpen vs CPU)
+    # filter() -> query(): the maps the encoder leaves behind are what the fused kernel samples
+    from vistracker_amd.sifnet import SIFNetQuery
+    net = SIFNetQuery(syn.sifnet_decoders(3)); net.encoder = enc
+    net.filter(cu(g["images"]))
+    pts = (torch.randn(1, 70, 3, device="cuda") * 0.3 + torch.tensor([0, 0, 2.2], device="cuda")).contiguous()
+    net.query(pts, crop_center=torch.tensor([[1018.952, 779.486]], device="cuda"), body_center=torch.tensor([[0, 0, 2.2]], device="cuda"))
+    assert all(bool(torch.isfinite(p).all()) for p in net.get_preds()) and net.get_preds()[1].shape == (1, 3, 3, 70)
+
+
+def test_upsample2x_bicubic_add(hip):
+    """vt_upsample2x_bicubic_add == skip + F.interpolate(low, scale_factor=2, mode='bicubic', align_corners=True) (fp32 torch reference)"""
+    import torch.nn.functional as F
+    from vistracker_amd.encoder import upsample2x_bicubic_add
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for (B, C, h, w) in ((2, 64, 5, 7), (1, 256, 16, 16), (3, 32, 1, 9)):
+        low = torch.randn(B, C, h, w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        skip = torch.randn(B, C, 2 * h, 2 * w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        ref = skip.cpu() + F.interpolate(low.cpu(), scale_factor=2, mode="bicubic", align_corners=True)
+        out = upsample2x_bicubic_add(low, skip)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 5e-6, (B, C, h, w)

@@ -399,6 +399,60 @@ __global__ __launch_bounds__(256) void velocity_loss_kernel(const float *__restr
     term_add(acc / ((double)(B - 1) * D), term, red);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// x2 bicubic upsampling (align_corners = True, A = -0.75, clamped taps: torch.nn.functional.interpolate semantics) of an NHWC tensor,
+// fused with the skip connection of the hourglass: out = skip + up(low)   (model/HGFilters.py:45-47).
+// thread = one output pixel x 4 channels (16-B accesses; the 16 taps of neighbouring threads hit the same cache lines).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_w(float t, float *w)
+{
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__global__ __launch_bounds__(256) void upsample2x_bicubic_add_kernel(const float *__restrict__ low, const float *__restrict__ skip, int B, int h, int w, int C,
+                                                                     float *__restrict__ out)
+{
+    const int C4 = C >> 2, H = 2 * h, W = 2 * w;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * H * W * C4;
+    if (t >= total) return;
+    const int c4 = (int)(t % C4); long r = t / C4;
+    const int ox = (int)(r % W); r /= W;
+    const int oy = (int)(r % H); const int b = (int)(r / H);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fy = sy * oy, fx = sx * ox;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - iy, wy); cubic_w(fx - ix, wx);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int yy = min(max(iy - 1 + i, 0), h - 1);
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xx = min(max(ix - 1 + k, 0), w - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(low + (((size_t)b * h + yy) * w + xx) * C + 4 * c4);
+            row.x += wx[k] * v.x; row.y += wx[k] * v.y; row.z += wx[k] * v.z; row.w += wx[k] * v.w;
+        }
+        acc.x += wy[i] * row.x; acc.y += wy[i] * row.y; acc.z += wy[i] * row.z; acc.w += wy[i] * row.w;
+    }
+    const size_t o = (((size_t)b * H + oy) * W + ox) * C + 4 * c4;
+    if (skip) { const float4 s = *reinterpret_cast<const float4 *>(skip + o); acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w; }
+    *reinterpret_cast<float4 *>(out + o) = acc;
+}
+extern "C" int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream)
+{
+    VT_REQUIRE(low && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "vt_upsample2x_bicubic_add: bad argument (C must be a multiple of 4)");
+    const long total = (long)B * 4 * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample2x_bicubic_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, vt_stream(stream), low, skip, B, h, w, C, out);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
 extern "C" int vt_accel_loss(const float *v, int B, int D, const float *elem_w, float gscale, double *term, float *dv, void *stream)
 {
     VT_REQUIRE(v && B >= 3 && D > 0, "vt_accel_loss: needs B >= 3 (the reference returns NaN for empty stencils)");

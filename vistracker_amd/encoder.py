@@ -1,0 +1,132 @@
+"""Image encoders of the SIF-Net (encoder half): inference-only mirror of ``model.HGFilters.HGFilter``
+(HGFilters.py:4-203) and of the encoder part of ``CHORETriplane.filter`` (chore.py:128-144, chore_triplane.py:60-95).
+
+The encoder is dense 2-D convolution work that runs ONCE per frame (613 GFLOP/frame); following the survey's plan it
+is expressed on the vendor convolution library (MIOpen through ``torch.nn.functional``: PyTorch-ROCm is the plumbing), in
+channels-last memory format so that the outputs ARE the NHWC feature maps the fused query kernel gathers from -- no NCHW->NHWC pass.
+Weights are addressed by the reference's ``state_dict`` names, so a VisTracker checkpoint loads unchanged:
+
+    enc = SIFNetEncoder.from_state_dict(torch.load(ckpt)["model_state_dict"])
+    maps = enc(images)                       # images (B,8,512,512): RGB*mask, mask_h, mask_o, tri-right, tri-back, tri-top
+    net.set_feature_maps(maps)               # == CHORETriplane.filter(images)
+
+Architecture restated from the reference (stacked hourglass, group norm):
+    conv1 7x7/2 -> GN -> ReLU = tmpx ; ConvBlock(tmpx,128) -> avgpool/2 = normx ; ConvBlock(128,128) ; ConvBlock(128,256) = previous
+    per stack i: HourGlass(depth) -> ConvBlock(256,256) -> conv_last 1x1 -> GN -> ReLU = ll ; out_i = l_i 1x1 (ll) ;
+                 previous += bl_i(ll) + al_i(out_i)            (all but the last stack)
+    ConvBlock(cin,cout): three pre-activated 3x3 convs (cout/2, cout/4, cout/4) concatenated + (1x1-projected) residual
+    HourGlass level n:   up = b1_n(x) ; low = b3_n( inner(b2_n(avgpool(x))) ) ; up + bicubic-upsample(low) ; inner = level n-1 or b2_plus_1
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+
+
+def upsample2x_bicubic_add(low, skip):
+    """skip + bicubic x2 (align_corners=True) of ``low``; both NCHW-shaped channels-last tensors on the GPU -> same format
+    (``vt_upsample2x_bicubic_add``; torch's channels-last bicubic kernel took 78 % of the encoder time)."""
+    B, C, h, w = low.shape
+    low = low.contiguous(memory_format=torch.channels_last); skip = skip.contiguous(memory_format=torch.channels_last)
+    out = torch.empty_like(skip, memory_format=torch.channels_last)
+    L.check(L.lib().vt_upsample2x_bicubic_add(low.data_ptr(), skip.data_ptr(), B, h, w, C, out.data_ptr(), L.stream_ptr()))
+    return out
+
+
+def _gn(x, sd, p, groups=32):
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+class HGFilterEncoder:
+    def __init__(self, sd: dict, prefix: str, num_stack=3, num_hourglass=2, norm="group", hg_down="ave_pool", device="cuda:0"):
+        """``sd``: state dict (tensors or arrays); ``prefix`` e.g. 'image_filter.' or 'triplane_encoder.' (a leading 'module.' is stripped)"""
+        if norm != "group" or hg_down != "ave_pool":
+            raise NotImplementedError("only the configuration VisTracker ships (config/*.json: norm=group, hg_down=ave_pool) is mirrored")
+        self.device = torch.device(device)
+        self.num_stack, self.depth = num_stack, num_hourglass
+        self.sd = {}
+        for k, v in sd.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k.startswith(prefix):
+                t = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v).detach().float().to(self.device)
+                self.sd[k[len(prefix):]] = t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+        if "conv1.weight" not in self.sd:
+            raise KeyError(f"no encoder weights under prefix '{prefix}'")
+        self.in_channels = self.sd["conv1.weight"].shape[1]
+
+    # ---- blocks ------------------------------------------------------------------------------------------------
+    def _conv_block(self, x, p):
+        sd = self.sd
+        o1 = F.conv2d(F.relu(_gn(x, sd, p + "bn1")), sd[p + "conv1.weight"], None, 1, 1)
+        o2 = F.conv2d(F.relu(_gn(o1, sd, p + "bn2")), sd[p + "conv2.weight"], None, 1, 1)
+        o3 = F.conv2d(F.relu(_gn(o2, sd, p + "bn3")), sd[p + "conv3.weight"], None, 1, 1)
+        out = torch.cat((o1, o2, o3), 1)
+        if p + "downsample.2.weight" in sd:
+            # downsample = Sequential(bn4, ReLU, conv1x1): the norm is the module the state dict also lists as "bn4" (same tensors in a
+            # real checkpoint); "downsample.0" is the name that is loaded last, i.e. the one the reference ends up using
+            x = F.conv2d(F.relu(_gn(x, sd, p + "downsample.0")), sd[p + "downsample.2.weight"])
+        return out + x
+
+    def _hourglass(self, level, x, p):
+        up1 = self._conv_block(x, f"{p}b1_{level}.")
+        low = self._conv_block(F.avg_pool2d(x, 2, stride=2), f"{p}b2_{level}.")
+        low = self._hourglass(level - 1, low, p) if level > 1 else self._conv_block(low, f"{p}b2_plus_{level}.")
+        low = self._conv_block(low, f"{p}b3_{level}.")
+        if low.is_cuda and low.shape[1] % 4 == 0:
+            return upsample2x_bicubic_add(low, up1)
+        return up1 + F.interpolate(low, scale_factor=2, mode="bicubic", align_corners=True)       # host tensors (tools / debugging only)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        """x (B,C,H,W) -> (outputs [num_stack x (B,hourglass_dim,H/4,W/4)], tmpx (B,tmpx_dim,H/2,W/2), normx (B,128,H/4,W/4)); channels-last"""
+        sd = self.sd
+        x = x.to(self.device).float().contiguous(memory_format=torch.channels_last)
+        x = F.relu(_gn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1"))
+        tmpx = x
+        x = F.avg_pool2d(self._conv_block(x, "conv2."), 2, stride=2)
+        normx = x
+        previous = self._conv_block(self._conv_block(x, "conv3."), "conv4.")
+        outputs = []
+        for i in range(self.num_stack):
+            ll = self._conv_block(self._hourglass(self.depth, previous, f"m{i}."), f"top_m_{i}.")
+            ll = F.relu(_gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}"))
+            out = F.conv2d(ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
+            outputs.append(out)
+            if i < self.num_stack - 1:
+                previous = previous + F.conv2d(ll, sd[f"bl{i}.weight"], sd[f"bl{i}.bias"]) + F.conv2d(out, sd[f"al{i}.weight"], sd[f"al{i}.bias"])
+        return outputs, tmpx, normx
+
+
+class SIFNetEncoder:
+    """``CHORETriplane.filter`` (chore_triplane.py:60-95): image encoder on channels 0..4, the (shared or per-view) triplane encoder on
+    channels 5, 6, 7; returns the eight feature maps of the query as an ``ops.FeatureMaps`` (NHWC, resident on the device)."""
+
+    def __init__(self, sd: dict, num_stack=3, num_hourglass=2, triplane_stack=3, shared_encoder=True, device="cuda:0"):
+        self.device = device
+        self.image = HGFilterEncoder(sd, "image_filter.", num_stack, num_hourglass, device=device)
+        if shared_encoder:
+            t = HGFilterEncoder(sd, "triplane_encoder.", triplane_stack, num_hourglass, device=device)
+            self.tri = [t, t, t]
+        else:
+            self.tri = [HGFilterEncoder(sd, f"triplane_encoder_{x}.", triplane_stack, num_hourglass, device=device) for x in range(3)]
+
+    @classmethod
+    def from_state_dict(cls, sd, **kw):
+        keys = [k[7:] if k.startswith("module.") else k for k in sd]
+        return cls(sd, shared_encoder=any(k.startswith("triplane_encoder.") for k in keys), **kw)
+
+    @torch.no_grad()
+    def __call__(self, images):
+        assert images.shape[1] == 8, f"given image shape invalid: {images.shape}"
+        images = images.to(self.device).float()
+        feats, tmpx, _ = self.image(images[:, :5])
+        maps = {"im_feat": feats[-1], "tmpx": tmpx}
+        for x in range(3):
+            f, t, _ = self.tri[x](images[:, 5 + x:6 + x])
+            maps[f"tri_tmpx{x}"] = t; maps[f"tri_feat{x}"] = f[-1]
+        # channels-last NCHW tensors are NHWC in memory: hand the storage to the query kernel as is
+        return ops.FeatureMaps({k: v.permute(0, 2, 3, 1).contiguous() for k, v in maps.items()})

@@ -28,6 +28,7 @@ class SIFNetQuery:
         self.maps = None
         self.preds = None
         self.training = False
+        self.encoder = None         # vistracker_amd.encoder.SIFNetEncoder (set by from_state_dict when the checkpoint holds encoder weights)
 
     @staticmethod
     def decoders_from_state_dict(sd: dict) -> dict:
@@ -47,7 +48,11 @@ class SIFNetQuery:
 
     @classmethod
     def from_state_dict(cls, sd, **kw):
-        return cls(cls.decoders_from_state_dict(sd), **kw)
+        net = cls(cls.decoders_from_state_dict(sd), **kw)
+        if any(k.replace("module.", "", 1).startswith("image_filter.") for k in sd):
+            from .encoder import SIFNetEncoder
+            net.encoder = SIFNetEncoder.from_state_dict(sd, device=net.device)
+        return net
 
     def eval(self):
         return self
@@ -57,7 +62,10 @@ class SIFNetQuery:
         self.maps = maps if isinstance(maps, ops.FeatureMaps) else ops.FeatureMaps.from_nchw(maps, self.device)
 
     def filter(self, images):
-        raise NotImplementedError("the HGFilter image encoder is SURVEY.md 8(f) 'next #1'; feed encoder outputs through set_feature_maps()")
+        """encode (B,8,H,W) images into the eight feature maps (chore_triplane.py:60-95); needs encoder weights (from_state_dict)"""
+        if self.encoder is None:
+            raise RuntimeError("this SIFNetQuery has no encoder weights: build it with from_state_dict(checkpoint) or call set_feature_maps()")
+        self.maps = self.encoder(images)
 
     def query(self, points, crop_center=None, body_center=None, **kwargs):
         assert self.maps is not None, "call set_feature_maps() (or filter()) first"

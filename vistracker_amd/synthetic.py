@@ -348,3 +348,22 @@ def sequence_params(n_frames: int, seed: int = 7, grab_hand_mean: np.ndarray | N
         "obj_R": obj_R.astype(np.float32), "obj_t": obj_t.astype(np.float32),
         "occ_ratios": rng.uniform(0.3, 1.0, n_frames).astype(np.float32),
     }
+
+
+def encoder_weights(keys_shapes, seed: int = 11) -> dict:
+    """Deterministic synthetic weights for the HGFilter encoders, one array per (state_dict name, shape): conv kernels
+    N(0, 1.5/sqrt(fan_in)), group-norm scales 1 + 0.1 N, biases / shifts 0.05 N; each tensor seeded by crc32(name) so that the
+    reference module (tools/gen_golden_encoder.py) and the mirror (tests) can rebuild the same values from the names alone."""
+    import zlib
+    out = {}
+    for name, shape in keys_shapes:
+        shape = tuple(int(x) for x in shape)
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            out[name] = (rng.normal(0, 1.5 / np.sqrt(fan_in), shape)).astype(np.float32)
+        elif name.endswith("weight"):
+            out[name] = (1.0 + 0.1 * rng.normal(size=shape)).astype(np.float32)
+        else:
+            out[name] = (0.05 * rng.normal(size=shape)).astype(np.float32)
+    return out
