@@ -359,15 +359,15 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         __syncthreads();                        // chunk ci visible; the other buffer's readers (MFMAs of chunk ci-1) are done
 #pragma unroll
         for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
-        if (ci + 1 < NCHUNK) {
-            taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid);
-            if (ci + 2 < NCHUNK) {
-                int mi, co; chunk_info(ci + 2, mi, co);
-                if (co == 0) taps_geom(a, mi, sUV, tid, tg);        // a new map: new texel offsets / coefficients (uniform branch)
-                taps_issue(a, b, mi, co, tg, tp);
-            }
-        }
+        // vmcnt retires loads IN ORDER: the weight fragments of the next chunk are requested BEFORE the taps of chunk ci+2, so that
+        // waiting for them (top of the next iteration) does not also wait for the far slower gather
+        if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid);
         LOAD_W1(ci + 1)
+        if (ci + 2 < NCHUNK) {
+            int mi, co; chunk_info(ci + 2, mi, co);
+            if (co == 0) taps_geom(a, mi, sUV, tid, tg);            // a new map: new texel offsets / coefficients (uniform branch)
+            taps_issue(a, b, mi, co, tg, tp);
+        }
     }
     {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (K32 step 19, k = 8 q + t: only q == 0, t < 3 are non-zero)
         uint4 xh[4], xl[4];
@@ -626,11 +626,6 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wl[g][0], xh[g], dd[g][0]); dd[g][1] = MFMAH(wl[g][1], xh[g], dd[g][1]); }
         }
         taps_store_grad(tp, tgb, bu, bv, tid);
-        if (ci + 1 < NCHUNK) {                             // the tap registers are free again: request chunk ci+1 right away
-            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
-            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
-            taps_issue(a, b, m2i, c2o, tgb, tp);
-        }
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
         // read this point's tap differences FIRST, then start the DMA of the next slab: hipcc orders an LDS read after an LDS-DMA
         // with a full vmcnt(0) wait (they may alias), which put the whole DMA latency in front of the epilogue
@@ -640,7 +635,15 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             u4[ct] = *reinterpret_cast<const float4 *>(bu + mypt * TS + 16 * ct + 4 * q);
             v4[ct] = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
         }
-        if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) }
+        if (ci + 1 < NCHUNK) {
+            SLAB_DMA(ci + 1)
+            // taps of chunk ci+1 AFTER the DMA (vmcnt retires in order): the barrier below then waits for the slab only, the gather
+            // stays in flight across it
+            asm volatile("" ::: "memory");
+            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
+            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
+            taps_issue(a, b, m2i, c2o, tgb, tp);
+        }
         float su = 0.f, sv = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
@@ -659,7 +662,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         const float czu = pr == 0 ? j0zu : (pr == 1 ? 1.f : 0.f);
         const float czv = pr == 0 ? j0zv : (pr == 3 ? -1.f : 0.f);
         gx = __builtin_fmaf(su, cxu, gx); gy = __builtin_fmaf(sv, cyv, gy); gz = __builtin_fmaf(sv, czv, __builtin_fmaf(su, czu, gz));
-        __syncthreads();                                   // slab(ci+1) landed (the barrier drains the DMA); tap buffers free again
+        if (ci + 1 < NCHUNK) {
+            // slab(ci+1) landed, tap buffers free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
+            // 8 tap loads just issued; the DMA pieces are older than those, so "at most 8 outstanding" means the slab is in LDS.
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
     }
 #undef SLAB_DMA
     {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
