@@ -388,3 +388,47 @@ def test_upsample2x_bicubic_add(hip):
         ref = skip.cpu() + F.interpolate(low.cpu(), scale_factor=2, mode="bicubic", align_corners=True)
         out = upsample2x_bicubic_add(low, skip)
         assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 5e-6, (B, C, h, w)
+
+
+def test_full_size_properties(hip, synth):
+    """BASELINE sizes (B = 96, V = 6890 / N = 3000, full-resolution maps): properties that need no reference values --
+    bit-reproducibility of the fused kernels (this is the check that exposed the packed-f32 hazard), linearity of the
+    backward in the upstream gradient, translation equivariance of SMPL-H."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vistracker_amd import synthetic as syn, _lib as L
+    ops = hip["ops"]; B, N = 96, 6890
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    maps = {}
+    for name, c, res, _ in syn.MAP_SPECS:
+        lo = torch.randn(B, c, res // 8, res // 8, device="cuda", generator=g)
+        maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    fm = ops.FeatureMaps(maps); net = hip["net"]
+    pts = (torch.randn(B, N, 3, device="cuda", generator=g) * 0.3 + torch.tensor([0, 0, 2.2], device="cuda")).contiguous()
+    cc = torch.tensor([[1018.952, 779.486]] * B, device="cuda"); bc = torch.tensor([[0, 0, 2.2]] * B, device="cuda")
+    labels = torch.randint(0, 14, (N,), device="cuda", dtype=torch.int32, generator=g)
+    outs = []
+    for _ in range(3):
+        dp = torch.empty(B, N, 3, device="cuda"); terms = torch.zeros(2, dtype=torch.float64, device="cuda")
+        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), L.dptr(pts), L.dptr(cc), L.dptr(bc), B, N, L.dptr(labels), 100.0, 0.0025,
+                                            L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+        outs.append((dp, terms.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])          # gradients: bit identical
+    assert abs(float(outs[0][1][0] - outs[1][1][0])) < 1e-12 * abs(float(outs[0][1][0])) + 1e-15  # terms: fp64 atomics, order only
+    assert bool(torch.isfinite(outs[0][0]).all())
+    # linearity of the backward (object-sized cloud): bwd(g1 + 2 g2) == bwd(g1) + 2 bwd(g2)
+    No = 3000; po = pts[:, :No].contiguous()
+    g1 = torch.randn(B, 2, No, device="cuda", generator=g); g2 = torch.randn(B, 2, No, device="cuda", generator=g)
+    def bwd(gd):
+        d = torch.empty(B, No, 3, device="cuda")
+        L.check(L.lib().vt_query_backward(net.h, C.byref(fm.c), L.dptr(po), L.dptr(cc), L.dptr(bc), B, No, L.dptr(gd), None, None, None, None, L.dptr(d), L.stream_ptr()))
+        return d
+    a, b_, c_ = bwd(g1), bwd(g2), bwd((g1 + 2 * g2).contiguous())
+    assert float((c_ - (a + 2 * b_)).abs().max()) < 2e-5 * float(c_.abs().max())
+    # SMPL-H: a translation moves every vertex and joint by the same vector
+    seq = syn.sequence_params(B, seed=9)
+    pose, betas, trans = cu(seq["pose"]), cu(seq["betas"]), cu(seq["trans"])
+    v0, j0, _ = ops.smplh_forward(hip["smpl"], pose, betas, trans)
+    d = torch.tensor([0.25, -0.5, 1.0], device="cuda")
+    v1, j1, _ = ops.smplh_forward(hip["smpl"], pose, betas, (trans + d).contiguous())
+    assert float((v1 - v0 - d).abs().max()) < 2e-6 and float((j1 - j0 - d).abs().max()) < 2e-6
