@@ -167,3 +167,14 @@ def test_early_stop_on_device(synth):
     assert np.allclose(r2.losses[:res.steps], res.losses[:res.steps], rtol=1e-5)
     if k == 10:
         assert torch.equal(p2, pose) and torch.equal(t2, trans)
+
+
+def test_non_finite_loss_fails_loudly(synth):
+    """a NaN anywhere in a step (here: in the input pose) must not end up silently in the fitted parameters"""
+    from vistracker_amd import ops, synthetic as syn
+    g = golden("smplfit")
+    ctx = make_ctx(synth, np.zeros((8, 3), np.float32))
+    maps = ops.FeatureMaps.from_nchw(syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+    pose = cu(g["pose"]); pose[1, 10] = float("nan")
+    with pytest.raises(FloatingPointError):
+        ctx.optimize_smpl(maps, pose, cu(g["betas"]), cu(g["trans"]), cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))

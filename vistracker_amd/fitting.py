@@ -95,6 +95,16 @@ class AdamState:
                                         self.t, lr, 0.9, 0.999, 1e-8, self.stop_flag.data_ptr(), L.stream_ptr()))
 
 
+def _check_finite(res, what):
+    """A non-finite loss among the executed steps means a non-finite intermediate somewhere in the step -- e.g. a decoder activation
+    beyond the range of the split-f16 operands (|x| >= 1023) or NaN inputs.  The reference would carry the NaN
+    silently into the saved parameters; here the fit fails loudly."""
+    executed = res.losses[:res.steps]      # after an early stop res.steps already counts the finite prefix only (unwritten slots are NaN)
+    if executed.size and not np.isfinite(executed).all():
+        bad = int(np.flatnonzero(~np.isfinite(executed))[0])
+        raise FloatingPointError(f"{what}: non-finite loss at Adam step {bad} (non-finite input or decoder activation out of range)")
+
+
 @dataclass
 class FitResult:
     steps: int = 0
@@ -199,6 +209,7 @@ class FitContext:
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+        _check_finite(res, "fit")
         return res
 
     # ---- fit, SMPL stage (recon_fit_behave.py:393-513) ----------------------------------------------------
@@ -262,6 +273,7 @@ class FitContext:
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+        _check_finite(res, "fit")
         return res
 
     # ---- fit, object stage (recon_fit_trivis_full.py:283-377) ----------------------------------------------
@@ -358,6 +370,7 @@ class FitContext:
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+        _check_finite(res, "fit")
         return res
 
     def _contacts_once(self, maps, smpl_verts, X, crop_center, body_center, thres=0.08):
