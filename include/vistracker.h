@@ -238,6 +238,12 @@ int vt_triplane_render(const float *verts, const float *center, int B, int NV, c
  * C must be a multiple of 4.  (The convolutions and group norms of the encoder run on MIOpen through PyTorch.) */
 int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream);
 
+/* GroupNorm (+ ReLU) of an NHWC fp32 tensor, the `bnK -> F.relu` prologue of every pre-activated convolution of the encoder
+ * (model/net_util.py:374-388, model/HGFilters.py:176,192-193): y = [relu]((x - mean_g) / sqrt(var_g + eps) * gamma + beta) with the
+ * biased variance over (H, W, C/groups), exactly torch.nn.functional.group_norm.  x, y (B,HW,C); gamma, beta (C); ws >= 2*B*C + B*groups doubles. */
+int vt_groupnorm_nhwc(const float *x, const float *gamma, const float *beta, int B, int HW, int C, int groups, float eps,
+                      int relu, double *ws, float *y, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Adam.  Replaces torch.optim.Adam(...).step() (defaults betas=(.9,.999), eps=1e-8) on one parameter tensor.
  * `stop_flag` (device int, may be NULL): when *stop_flag != 0 the update is skipped (device-side early stop).

@@ -432,3 +432,18 @@ def test_full_size_properties(hip, synth):
     d = torch.tensor([0.25, -0.5, 1.0], device="cuda")
     v1, j1, _ = ops.smplh_forward(hip["smpl"], pose, betas, (trans + d).contiguous())
     assert float((v1 - v0 - d).abs().max()) < 2e-6 and float((j1 - j0 - d).abs().max()) < 2e-6
+
+
+def test_groupnorm_relu_nhwc(hip):
+    """vt_groupnorm_nhwc == relu(F.group_norm(x, 32, gamma, beta)) (fp32 torch reference on CPU), channels-last storage"""
+    import torch.nn.functional as F
+    from vistracker_amd.encoder import _gn
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for (B, C, H, W) in ((2, 64, 9, 7), (1, 256, 16, 16), (3, 32, 5, 5), (2, 128, 33, 17)):
+        x = (torch.randn(B, C, H, W, device="cuda", generator=g) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
+        sd = {"n.weight": torch.randn(C, device="cuda", generator=g), "n.bias": torch.randn(C, device="cuda", generator=g)}
+        ref = F.relu(F.group_norm(x.cpu(), 32, sd["n.weight"].cpu(), sd["n.bias"].cpu(), 1e-5))
+        out = _gn(x, sd, "n", relu=True)
+        assert (out.cpu() - ref).abs().max().item() < 2e-5, (B, C, H, W)
+        out2 = _gn(x, sd, "n", relu=False)
+        assert (out2.cpu() - F.group_norm(x.cpu(), 32, sd["n.weight"].cpu(), sd["n.bias"].cpu(), 1e-5)).abs().max().item() < 2e-5

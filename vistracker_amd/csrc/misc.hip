@@ -444,6 +444,89 @@ __global__ __launch_bounds__(256) void upsample2x_bicubic_add_kernel(const float
     if (skip) { const float4 s = *reinterpret_cast<const float4 *>(skip + o); acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w; }
     *reinterpret_cast<float4 *>(out + o) = acc;
 }
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm (+ ReLU) on an NHWC tensor in two passes over x instead of torch's five (moments; normalise + affine; ReLU as a
+// separate element-wise kernel): pass 1 accumulates per-(frame, channel) sum / sum of squares in fp64, pass 2 normalises with the
+// group statistics and clamps.  The pre-activated blocks of the encoder are GN -> ReLU -> conv (model/net_util.py:374-388).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int HW, int C, int rows_per_block, double *__restrict__ sums)
+{
+    // thread = (pixel row slot, float4 of channels): C/4 float4 per pixel, 256 / (C/4) pixels per sweep
+    const int C4 = C >> 2, b = blockIdx.y, c4 = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(HW, p0 + rows_per_block);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (slot < nslot)
+        for (int p = p0 + slot; p < p1; p += nslot) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)b * HW + p) * C + 4 * c4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+        }
+    // combine the pixel slots of a channel through LDS, one fp64 atomic per (channel, statistic) and block
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        for (int sl = 0; sl < nslot; sl++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ds[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + k]; dq[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + 4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(sums + ((size_t)b * C + 4 * threadIdx.x + k) * 2, ds[k]);
+            atomicAdd(sums + ((size_t)b * C + 4 * threadIdx.x + k) * 2 + 1, dq[k]);
+        }
+    }
+}
+// per (frame, group): mean and 1/sqrt(var + eps) from the channel sums (fp64), written as two floats over the first channel pair's slot
+__global__ void gn_finalize_kernel(const double *__restrict__ sums, int B, int HW, int C, int groups, float eps, float2 *__restrict__ stats)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * groups) return;
+    const int b = i / groups, g = i - b * groups, cg = C / groups;
+    double sm = 0, sq = 0;
+    for (int k = 0; k < cg; k++) { sm += sums[((size_t)b * C + g * cg + k) * 2]; sq += sums[((size_t)b * C + g * cg + k) * 2 + 1]; }
+    const double n = (double)HW * cg, mean = sm / n, var = fmax(sq / n - mean * mean, 0.0);
+    stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       const float2 *__restrict__ stats, int B, int HW, int C, int groups, int relu,
+                                                       float *__restrict__ y)
+{
+    const int C4 = C >> 2, cg = C / groups;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * HW * C4;
+    if (t >= total) return;
+    const int c4 = (int)(t % C4); const long pix = t / C4; const int b = (int)(pix / HW);
+    const float4 v = *reinterpret_cast<const float4 *>(x + pix * C + 4 * c4);
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + 4 * c4), be = *reinterpret_cast<const float4 *>(beta + 4 * c4);
+    const float in[4] = {v.x, v.y, v.z, v.w}, gm[4] = {ga.x, ga.y, ga.z, ga.w}, bt[4] = {be.x, be.y, be.z, be.w}; float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float2 st = stats[b * groups + (4 * c4 + k) / cg];
+        const float o = (in[k] - st.x) * st.y * gm[k] + bt[k];
+        out[k] = relu ? fmaxf(o, 0.f) : o;
+    }
+    *reinterpret_cast<float4 *>(y + pix * C + 4 * c4) = make_float4(out[0], out[1], out[2], out[3]);
+}
+extern "C" int vt_groupnorm_nhwc(const float *x, const float *gamma, const float *beta, int B, int HW, int C, int groups, float eps, int relu,
+                                 double *ws, float *y, void *stream)
+{
+    VT_REQUIRE(x && gamma && beta && ws && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0,
+               "vt_groupnorm_nhwc: bad argument (C must be a multiple of 4 and of groups, C <= 1024)");
+    hipStream_t st = vt_stream(stream);
+    VT_HIP(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)B * C * 2, st));
+    const int nblk = min(max(HW / 256, 1), 128), rows = (HW + nblk - 1) / nblk;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x, HW, C, rows, ws);
+    VT_LAUNCH_CHECK();
+    float2 *stats = reinterpret_cast<float2 *>(ws + (size_t)B * C * 2);      // (B, groups) after the channel sums
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, ws, B, HW, C, groups, eps, stats);
+    VT_LAUNCH_CHECK();
+    const long total = (long)B * HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, gamma, beta, stats, B, HW, C, groups, relu, y);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
 extern "C" int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream)
 {
     VT_REQUIRE(low && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "vt_upsample2x_bicubic_add: bad argument (C must be a multiple of 4)");

@@ -37,8 +37,18 @@ def upsample2x_bicubic_add(low, skip):
     return out
 
 
-def _gn(x, sd, p, groups=32):
-    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+def _gn(x, sd, p, groups=32, relu=False):
+    """GroupNorm(32) [+ ReLU]; on the GPU one fused two-pass HIP kernel pair on the channels-last storage (vt_groupnorm_nhwc)"""
+    if x.is_cuda and x.shape[1] % 4 == 0:
+        B, C, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
+        L.check(L.lib().vt_groupnorm_nhwc(x.data_ptr(), sd[p + ".weight"].data_ptr(), sd[p + ".bias"].data_ptr(), B, H * W, C, groups, 1e-5, int(relu),
+                                          ws.data_ptr(), y.data_ptr(), L.stream_ptr()))
+        return y
+    y = F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+    return F.relu(y) if relu else y
 
 
 class HGFilterEncoder:
@@ -61,14 +71,14 @@ class HGFilterEncoder:
     # ---- blocks ------------------------------------------------------------------------------------------------
     def _conv_block(self, x, p):
         sd = self.sd
-        o1 = F.conv2d(F.relu(_gn(x, sd, p + "bn1")), sd[p + "conv1.weight"], None, 1, 1)
-        o2 = F.conv2d(F.relu(_gn(o1, sd, p + "bn2")), sd[p + "conv2.weight"], None, 1, 1)
-        o3 = F.conv2d(F.relu(_gn(o2, sd, p + "bn3")), sd[p + "conv3.weight"], None, 1, 1)
+        o1 = F.conv2d(_gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
+        o2 = F.conv2d(_gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
+        o3 = F.conv2d(_gn(o2, sd, p + "bn3", relu=True), sd[p + "conv3.weight"], None, 1, 1)
         out = torch.cat((o1, o2, o3), 1)
         if p + "downsample.2.weight" in sd:
             # downsample = Sequential(bn4, ReLU, conv1x1): the norm is the module the state dict also lists as "bn4" (same tensors in a
             # real checkpoint); "downsample.0" is the name that is loaded last, i.e. the one the reference ends up using
-            x = F.conv2d(F.relu(_gn(x, sd, p + "downsample.0")), sd[p + "downsample.2.weight"])
+            x = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"])
         return out + x
 
     def _hourglass(self, level, x, p):
@@ -85,7 +95,7 @@ class HGFilterEncoder:
         """x (B,C,H,W) -> (outputs [num_stack x (B,hourglass_dim,H/4,W/4)], tmpx (B,tmpx_dim,H/2,W/2), normx (B,128,H/4,W/4)); channels-last"""
         sd = self.sd
         x = x.to(self.device).float().contiguous(memory_format=torch.channels_last)
-        x = F.relu(_gn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1"))
+        x = _gn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1", relu=True)
         tmpx = x
         x = F.avg_pool2d(self._conv_block(x, "conv2."), 2, stride=2)
         normx = x
@@ -93,7 +103,7 @@ class HGFilterEncoder:
         outputs = []
         for i in range(self.num_stack):
             ll = self._conv_block(self._hourglass(self.depth, previous, f"m{i}."), f"top_m_{i}.")
-            ll = F.relu(_gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}"))
+            ll = _gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}", relu=True)
             out = F.conv2d(ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
             outputs.append(out)
             if i < self.num_stack - 1:
