@@ -97,3 +97,34 @@ def test_object_stage_without_contacts(synth):
     res = ctx.optimize_smpl_object(maps, verts, obj_R, obj_t, torch.ones(B, device="cuda"), cc, bc, torch.ones(B, device="cuda"), sil=sil,
                                    iter_for_obj=1, iter_for_sil=1, joint_iter=1, max_iter=1, seed=0)
     assert res.steps > 20 and np.isfinite(res.losses[:res.steps]).all()          # got into the 'joint' phase (outer iteration 2)
+
+
+def test_single_frame_fit(synth):
+    """BASELINE.json configs[1]: one frame through the SMPL stage and the object stage (temporal terms are skipped for B < 4 as in the
+    reference: recon_fit_trivis_full.py:172,382) and through the SMPL-T pre-fit (configs[0]: one frame, 25 keypoints)."""
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext, SilSetup
+    B = 1
+    ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, 300, seed=6)
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], ov, of, opts)
+    maps = ops.FeatureMaps.from_nchw(syn.feature_maps(B, 4, res_scale=1 / 8))
+    seq = syn.sequence_params(B, seed=4)
+    pose, betas, trans = cu(seq["pose"]), cu(seq["betas"]), cu(seq["trans"])
+    cc = torch.tensor([[1018.952, 779.486]], device="cuda"); bc = trans.clone()
+    verts0, jtr, _ = ops.smplh_forward(ctx.smpl, pose, betas, trans)
+    J = ops.landmarks(ctx.b25, verts0)
+    kp_full = torch.stack([979.7844 * J[..., 0] / J[..., 2] + 1018.952, 979.840 * J[..., 1] / J[..., 2] + 779.486, torch.ones_like(J[..., 0])], -1).contiguous()
+    # SMPL-T pre-fit from a perturbed start: the keypoint term must go down
+    p2 = (pose + 0.05).contiguous(); t2 = (trans + 0.03).contiguous(); b2 = betas.clone()
+    r0 = ctx.fit_smplt(p2, b2, t2, kp_full, max_iter=3, temporal=True)
+    assert r0.steps >= 10 and np.isfinite(r0.losses[:r0.steps]).all() and r0.losses[r0.steps - 1] < r0.losses[0]
+    # joint optimisation, one frame
+    kp_crop = torch.cat([torch.rand(1, 25, 2, device="cuda") * 300 + 100, torch.ones(1, 25, 1, device="cuda")], -1)
+    r1 = ctx.optimize_smpl(maps, pose, betas, trans, cc, bc, kp_crop, max_iter=1)
+    assert r1.steps >= 30 and np.isfinite(r1.losses[:r1.steps]).all()
+    verts, _, _ = ops.smplh_forward(ctx.smpl, pose, betas, trans)
+    obj_R = torch.eye(3, device="cuda").repeat(B, 1, 1).contiguous(); obj_t = (trans + torch.tensor([0.3, 0.0, 0.1], device="cuda")).contiguous()
+    sil = SilSetup(torch.tensor([[1.6, 0, 0.5, 0, 1.6, 0.5, 0, 0, 1]], device="cuda"), torch.ones(B, 256, 256, device="cuda"), torch.zeros(B, 256, 256, device="cuda"))
+    r2 = ctx.optimize_smpl_object(maps, verts, obj_R, obj_t, torch.ones(B, device="cuda"), cc, bc, torch.ones(B, device="cuda"), sil=sil,
+                                  iter_for_obj=1, iter_for_sil=1, joint_iter=1, max_iter=1, seed=0)
+    assert r2.steps > 20 and np.isfinite(r2.losses[:r2.steps]).all() and torch.isfinite(obj_R).all() and torch.isfinite(obj_t).all()
