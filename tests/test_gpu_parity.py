@@ -447,3 +447,28 @@ def test_groupnorm_relu_nhwc(hip):
         assert (out.cpu() - ref).abs().max().item() < 2e-5, (B, C, H, W)
         out2 = _gn(x, sd, "n", relu=False)
         assert (out2.cpu() - F.group_norm(x.cpu(), 32, sd["n.weight"].cpu(), sd["n.bias"].cpu(), 1e-5)).abs().max().item() < 2e-5
+
+
+def test_smoothnet_postprocessor_vs_reference(hip):
+    """SMPLTSmoother (smoothnet/smooth_smplt.py) + SmoothNetSMPL + window averaging + rotation conversions against the reference run
+    on CPU with the same name-seeded weights (tools/gen_golden_smooth.py)."""
+    import zlib
+    from vistracker_amd import smoothing as S
+    g = golden("smooth")
+    sd = {}
+    for n, s, d in zip(g["names"], g["shapes"], g["ndims"]):
+        n = str(n); shape = tuple(int(x) for x in s[:d]); rng = np.random.default_rng([21, zlib.crc32(n.encode())])
+        sd[n] = rng.normal(0, 1.0 / np.sqrt(shape[-1]), shape).astype(np.float32) if d == 2 else (0.02 * rng.normal(size=shape)).astype(np.float32)
+    # rotation conversions (incl. the identity and two near-pi rotations)
+    assert np.abs(S.numpy_axis_to_rot6D(g["aa"]).reshape(-1, 6) - g["r6"]).max() < 1e-12
+    back = S.rot6D_to_axis(cu(g["r6"].astype(np.float32)))
+    assert np.abs(npy(back) - g["aa_back"]).max() < 2e-5
+    sm = S.SMPLTSmoother(S.SmoothNetSMPL(sd), slide_window_size=64, slide_window_step=1)
+    raw = {"poses": g["poses"], "betas": g["betas"], "trans": g["trans"], "frames": [str(f) for f in g["frames"]]}
+    data, den, inp = sm.model_forward(raw)
+    assert den.shape[0] == int(g["n_clips"]) and np.abs(npy(inp[0]) - g["input_data0"]).max() < 1e-6
+    assert np.abs(npy(den[0]) - g["denoised0"]).max() < 2e-5 * max(1.0, np.abs(g["denoised0"]).max())
+    out = sm.post_processing(data, den, inp)
+    assert out["frames"] == [str(f) for f in g["out_frames"]] and np.isnan(out["obj_trans"]).all()
+    assert np.abs(out["poses"] - g["out_poses"]).max() < 5e-5 and np.abs(out["betas"] - g["out_betas"]).max() < 1e-5
+    assert np.abs(out["trans"] - g["out_trans"]).max() < 1e-5
