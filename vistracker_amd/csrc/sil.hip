@@ -105,14 +105,16 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
 __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
                                                           unsigned long long *__restrict__ zbuf)
 {
-    const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+    // the face index is wave-uniform: say so (readfirstlane), and the box + corner record become scalar loads that are all in flight
+    // together -- one memory round trip per wave instead of box -> branch -> corners
+    const int f2 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;
     if (f2 >= 2 * NF) return;
-    const int2 bb = fbox[(size_t)b * 2 * NF + f2];
-    const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
-    if (x0 > x1) return;
     float fc[9];
 #pragma unroll
     for (int e = 0; e < 9; e++) fc[e] = fcbuf[((size_t)b * 2 * NF + f2) * 9 + e];
+    const int2 bb = fbox[(size_t)b * 2 * NF + f2];
+    const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
+    if (x0 > x1) return;
     const float den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
     if (den == 0.f) return;
     const int w = x1 - x0 + 1, npx = w * (y1 - y0 + 1);
@@ -174,20 +176,23 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
                                     const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj)
 {
-    const int f2 = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
-    if (f2 >= 2 * NF || !visible[(size_t)b * 2 * NF + f2]) return;
-    const int *fim = face_index + (size_t)b * is * is;
-    const float *gal = d_image + (size_t)b * is * is;
-    const int wpl = is / 64;
+    const int f2 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;   // wave-uniform
+    if (f2 >= 2 * NF) return;
+    // visibility flag, vertex ids and corners: independent scalar loads, requested before the first branch
+    const int vis = visible[(size_t)b * 2 * NF + f2];
     const int f = f2 < NF ? f2 : f2 - NF;
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-    if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
     float P[3][2];          // corners in pixel units
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         P[k][0] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k] * is + is - 1);
         P[k][1] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k + 1] * is + is - 1);
     }
+    if (!vis) return;
+    if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
+    const int *fim = face_index + (size_t)b * is * is;
+    const float *gal = d_image + (size_t)b * is * is;
+    const int wpl = is / 64;
     // walk w = 2 edge + axis covers d0 in [from[w], from[w] + cnt[w]) along the axis; start[] = exclusive prefix of cnt[]
     int from[6], start[7];
     start[0] = 0;
@@ -301,12 +306,16 @@ __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restr
     const int b = blockIdx.y;
     const float ob = occ[b];
     double acc = 0;
-    const int per_slice = (npx + gridDim.x - 1) / gridDim.x, i_end = min(npx, (int)(blockIdx.x + 1) * per_slice);
+    // 16-byte accesses (npx = size^2 is a multiple of 4096, frames start 16-byte aligned): a handful of wide loads per thread instead of
+    // a 64-deep chain of dependent-latency scalar ones
+    const int nq = npx >> 2, per_slice = (nq + gridDim.x - 1) / gridDim.x, i_end = min(nq, (int)(blockIdx.x + 1) * per_slice);
+    const float4 *im4 = (const float4 *)(image + (size_t)b * npx), *kp4 = (const float4 *)(keep + (size_t)b * npx), *rf4 = (const float4 *)(ref + (size_t)b * npx);
+    float4 *di4 = d_image ? (float4 *)(d_image + (size_t)b * npx) : nullptr;
     for (int i = blockIdx.x * per_slice + threadIdx.x; i < i_end; i += 256) {
-        const size_t o = (size_t)b * npx + i;
-        const float d = keep[o] * image[o] - ref[o];
-        acc += (double)(d * d);
-        if (d_image) d_image[o] = 2.f * d * keep[o] * ob * gs;
+        const float4 im = im4[i], kp = kp4[i], rf = rf4[i];
+        const float d0 = kp.x * im.x - rf.x, d1 = kp.y * im.y - rf.y, d2 = kp.z * im.z - rf.z, d3 = kp.w * im.w - rf.w;
+        acc += (double)(d0 * d0) + (double)(d1 * d1) + (double)(d2 * d2) + (double)(d3 * d3);
+        if (di4) di4[i] = make_float4(2.f * d0 * kp.x * ob * gs, 2.f * d1 * kp.y * ob * gs, 2.f * d2 * kp.z * ob * gs, 2.f * d3 * kp.w * ob * gs);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -378,8 +387,9 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
 extern "C" int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size, float gscale,
                                 double *term, float *per_frame, float *d_image, void *stream)
 {
-    VT_REQUIRE(image && keep && ref && occ && B > 0 && size > 0, "vt_sil_mask_loss: bad argument");
-    hipLaunchKernelGGL(sil_mask_loss_kernel, dim3(per_frame ? 1 : 4, B), dim3(256), 0, vt_stream(stream), image, keep, ref, occ, B, size * size, gscale / (float)B,
+    VT_REQUIRE(image && keep && ref && occ && B > 0 && size > 0 && size % 2 == 0, "vt_sil_mask_loss: bad argument (size must be even)");
+    VT_REQUIRE((((uintptr_t)image | (uintptr_t)keep | (uintptr_t)ref | (uintptr_t)d_image) & 15) == 0, "vt_sil_mask_loss: images must be 16-byte aligned");
+    hipLaunchKernelGGL(sil_mask_loss_kernel, dim3(per_frame ? 1 : 16, B), dim3(256), 0, vt_stream(stream), image, keep, ref, occ, B, size * size, gscale / (float)B,
                        term, per_frame, d_image);
     VT_LAUNCH_CHECK();
     return VT_OK;
