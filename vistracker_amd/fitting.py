@@ -117,15 +117,16 @@ class FitContext:
     """Device-resident constants shared by all batches of a sequence: SMPL-H model, body25 regressor, priors,
     SIF-Net decoders, part labels, object template / surface samples."""
 
-    def __init__(self, smpl_model, regressors, priors, decoders, part_labels, obj_verts, obj_faces, obj_points,
+    def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
         self.device = torch.device(device)
         dev = self.device
         self.smpl = ops.SmplhHandle(smpl_model, dev)
         self.b25 = ops.LandmarkHandle(regressors["body25"], dev)
-        self.net = ops.SifNetHandle(decoders, cam, dev)
+        # the SMPL-T pre-fit (fit_smplt) needs neither the SIF-Net nor an object: decoders / part_labels / obj_* may be None there
+        self.net = ops.SifNetHandle(decoders, cam, dev) if decoders is not None else None
         self.cam = np.ascontiguousarray(cam, np.float32)
-        t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+        t = lambda a, dt=torch.float32: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         self.pri = {k: t(v) for k, v in priors.items()}
         self.labels = t(part_labels, torch.int32)
         self.obj_verts = t(obj_verts); self.obj_faces = t(obj_faces, torch.int32); self.obj_points = t(obj_points)
