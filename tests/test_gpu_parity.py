@@ -472,3 +472,34 @@ def test_smoothnet_postprocessor_vs_reference(hip):
     assert out["frames"] == [str(f) for f in g["out_frames"]] and np.isnan(out["obj_trans"]).all()
     assert np.abs(out["poses"] - g["out_poses"]).max() < 5e-5 and np.abs(out["betas"] - g["out_betas"]).max() < 1e-5
     assert np.abs(out["trans"] - g["out_trans"]).max() < 1e-5
+
+
+def test_objrot_smoother_vs_reference(hip):
+    """ObjrotSmoother (smoothnet/smooth_objrot.py): rot -> 6-D -> SmoothNet -> window mean -> Gram-Schmidt -> stored transposed, and the
+    neural-PCA route (PCAUtil.init_object_orientation) against the reference run with the same name-seeded weights."""
+    import zlib
+    from vistracker_amd import smoothing as S
+    g = golden("smooth_objrot")
+    sd = {}
+    for n, s, d in zip(g["names"], g["shapes"], g["ndims"]):
+        n = str(n); shape = tuple(int(x) for x in s[:d]); rng = np.random.default_rng([22, zlib.crc32(n.encode())])
+        sd[n] = rng.normal(0, 1.0 / np.sqrt(shape[-1]), shape).astype(np.float32) if d == 2 else (0.02 * rng.normal(size=shape)).astype(np.float32)
+    sm = S.ObjrotSmoother(S.SmoothNet(sd), slide_window_size=64, slide_window_step=1)
+    frames = [str(f) for f in g["frames"]]
+    raw = sm.load_inputs({"obj_angles": g["obj_angles"], "neural_visibility": g["vis"], "gender": "male", "frames": frames})
+    data, den, inp = sm.model_forward(raw)
+    assert np.abs(npy(inp[0]) - g["input_data0"]).max() < 1e-6
+    assert np.abs(npy(den[0]) - g["denoised0"]).max() < 2e-5 * max(1.0, np.abs(g["denoised0"]).max())
+    out = sm.post_processing(data, den, inp)
+    assert out["frames"] == [str(f) for f in g["out_frames"]] and np.isnan(out["poses"]).all() and np.isnan(out["obj_trans"]).all()
+    assert np.array_equal(out["obj_scales"], g["out_scales"]) and np.array_equal(out["neural_visibility"], g["vis"])
+    assert np.abs(out["obj_angles"] - g["out_obj_angles"]).max() < 2e-5
+    R = out["obj_angles"]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5 and np.abs(np.linalg.det(R) - 1).max() < 1e-5
+    # predicted PCA axes -> rotation relative to the template axes
+    raw2 = sm.load_inputs({"neural_pca": list(g["pca_pred"]), "frames": frames[:12]}, pca_init=g["pca_init"], neural_pca=True)
+    assert np.abs(raw2["obj_rot"] - g["rot_pca"]).max() < 2e-5 and np.isnan(raw2["neural_visibility"]).all()
+    # a stride-8 window walk appends the clip that ends flush with the sequence (smooth_base.py:66-70)
+    sm8 = S.ObjrotSmoother(S.SmoothNet(sd), slide_window_size=64, slide_window_step=8)
+    d8 = sm8.preprocess_input(raw)
+    assert d8["input_data"].shape == (4, 64, 6) and d8["paths"][-1] == frames[-64:]

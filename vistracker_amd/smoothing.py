@@ -187,3 +187,51 @@ class SMPLTSmoother:
 
     def smooth(self, raw_data):
         return self.post_processing(*self.model_forward(raw_data))
+
+
+def rotmat_to_6d(poses):
+    """(T,3,3) -> (T,1,6): the first two COLUMNS of each matrix, row-major (geometry_utils.py:80-90)"""
+    R = torch.as_tensor(np.asarray(poses) if not torch.is_tensor(poses) else poses).float().reshape(-1, 3, 3)
+    return R[:, :, :2].reshape(-1, 6).view(R.shape[0], -1, 6)
+
+
+class ObjrotSmoother(SMPLTSmoother):
+    """``smoothnet.smooth_objrot.ObjrotSmoother`` without the file IO (smooth_objrot.py:31-139): the per-frame object rotations left by the
+    SIF-Net pass -- either as the predicted PCA axes (``neural_pca`` (T,3,3), turned into rotations relative to the template's axes with
+    ``PCAUtil.init_object_orientation``, recon/pca_util.py:57-71) or as ``obj_angles`` (T,3,3) stored transposed -- are smoothed in the 6-D
+    representation by a plain ``SmoothNet`` and written back transposed."""
+
+    @staticmethod
+    def rotations_from_pca(pca_pred, pca_init):
+        """rot = project_so3(pinv(src) tgt) of every frame, returned as 'real' rotation matrices (transposed), smooth_objrot.py:47-57"""
+        from . import ops
+        tgt = torch.as_tensor(np.stack(pca_pred, 0) if isinstance(pca_pred, list) else np.asarray(pca_pred)).float()
+        src = torch.as_tensor(np.asarray(pca_init)).float()[None].repeat(len(tgt), 1, 1)
+        st = src.transpose(2, 1)
+        rot = torch.bmm(torch.bmm(torch.inverse(torch.bmm(st, src)), st), tgt)
+        R = ops.so3_project(rot.cuda().contiguous()).cpu()
+        return R.numpy().transpose(0, 2, 1)
+
+    def load_inputs(self, dat, pca_init=None, neural_pca=False):
+        """the dict ``load_inputs_raw`` builds from a packed recon file ``dat`` (smooth_objrot.py:36-72)"""
+        if neural_pca:
+            assert len(dat["neural_pca"]) > 0, "no pca data"
+            rot_real = self.rotations_from_pca(dat["neural_pca"], pca_init)
+        else:
+            rot_real = np.asarray(dat["obj_angles"]).transpose(0, 2, 1)
+        vis = dat["neural_visibility"] if "neural_visibility" in dat else np.zeros((rot_real.shape[0],)) + float("nan")
+        return {"obj_rot": rot_real, "neural_visibility": vis, "gender": dat.get("gender"), "frames": dat["frames"]}
+
+    def preprocess_input(self, raw_data):
+        rot6d = rotmat_to_6d(torch.as_tensor(np.asarray(raw_data["obj_rot"]))).reshape(-1, 6)
+        input_data, paths = self.seq2batches(rot6d, raw_data)
+        return {"input_data": input_data, "paths": paths, "neural_visibility": raw_data["neural_visibility"]}
+
+    def post_processing(self, data, denoised, input_pred):
+        seq = slide_window_to_sequence(denoised, self.slide_window_step, self.slide_window_size)
+        pose = rot6d_to_rotmat(seq).cpu().numpy()
+        frames = self.merge_paths(data["paths"]); L = len(frames)
+        nan = float("nan")
+        return {"obj_trans": np.zeros((L, 3)) + nan, "obj_scales": np.zeros((L,)), "obj_angles": pose.transpose(0, 2, 1),
+                "neural_visibility": data["neural_visibility"], "frames": frames, "poses": np.zeros((L, 72)) + nan,
+                "betas": np.zeros((L, 10)) + nan, "trans": np.zeros((L, 3)) + nan}
