@@ -503,3 +503,47 @@ def test_objrot_smoother_vs_reference(hip):
     sm8 = S.ObjrotSmoother(S.SmoothNet(sd), slide_window_size=64, slide_window_step=8)
     d8 = sm8.preprocess_input(raw)
     assert d8["input_data"].shape == (4, 64, 6) and d8["paths"][-1] == frames[-64:]
+
+
+def _hvop_opt():
+    from types import SimpleNamespace
+    # the model keys of the reference's config/cmf-k4-lrot.json (data)
+    return SimpleNamespace(clip_len=180, obj_repre="6d", dim_smpl=147, dim_obj=6, out_dim=6, num_layers_smpl=2, d_model_smpl=128, num_heads_smpl=4,
+                           dim_forward_smpl=256, pre_norm_smpl=False, activation_smpl="gelu", num_layers_obj=2, d_model_obj=32, num_heads_obj=2,
+                           dim_forward_obj=64, pre_norm_obj=False, activation_obj="gelu", num_layers_joint=4, num_heads_joint=1, dim_forward_joint=256,
+                           pre_norm_joint=False, activation_joint="gelu", hidden_dims=[32])
+
+
+def test_hvop_infiller_vs_reference(hip):
+    """ConditionalMInfiller (three pre-norm transformer encoders + MLP head) on one clip and the autoregressive whole-sequence driver
+    (interp/test_infill_autoreg.py) against the reference run with the same name-seeded weights (tools/gen_golden_infill.py)."""
+    import zlib
+    from vistracker_amd import infill as I
+    g = golden("infill")
+    sd = {}
+    for n, s, d in zip(g["names"], g["shapes"], g["ndims"]):
+        n = str(n); shape = tuple(int(x) for x in s[:d]); rng = np.random.default_rng([31, zlib.crc32(n.encode())])
+        if d == 2: a = rng.normal(0, 1.0 / np.sqrt(shape[-1]), shape)
+        elif n.endswith(("norm1.weight", "norm2.weight", "norm.weight")): a = 1.0 + 0.05 * rng.normal(size=shape)
+        else: a = 0.02 * rng.normal(size=shape)
+        sd[n] = a.astype(np.float32)
+    opt = _hvop_opt()
+    model = I.ConditionalMInfiller(sd, opt)
+    T = opt.clip_len
+    xs = np.concatenate([I.prep_smpl_rot6d(g["poses"][:T]), g["trans"][:T]], 1); xo = I.prep_obj_rot6d(g["obj_angles"][:T]); mask = g["vis"][:T] < 0.5
+    pred = model(torch.tensor(xs[None]).float(), torch.zeros(1, T, dtype=torch.bool), torch.tensor(xo[None] * (1 - mask[None, :, None])).float(), torch.tensor(mask[None]))
+    assert np.abs(npy(pred[0]) - g["clip_pred"]).max() < 2e-5 * max(1.0, np.abs(g["clip_pred"]).max())
+    # positional table: endpoints 0 and 2 pi, sin / cos interleaved
+    pe = I.position_embedding_sine_1d(180, 64, 128)
+    assert pe.shape == (180, 128) and abs(pe[0, 0].item()) < 1e-7 and abs(pe[0, 1].item() - 1) < 1e-7 and abs(pe[-1, 1].item() - 1) < 1e-5
+    drv = I.MotionInfillAutoreg(model, clip_len=180, window=30, occ_thres=0.5, exp_name="cmf-k4-lrot")
+    dat = {"poses": g["poses"], "trans": g["trans"], "obj_trans": g["obj_trans"], "frames": [str(f) for f in g["frames"]], "betas": np.zeros((275, 10))}
+    out, done = drv.infill(dat, g["obj_angles"], g["vis"])
+    assert done and out["exp_name"] == "cmf-k4-lrot" and np.array_equal(out["obj_scales"], np.ones(275))
+    assert np.abs(out["obj_angles"] - g["out_obj_angles"]).max() < 5e-5
+    assert np.array_equal(out["obj_trans"], g["out_obj_trans"])                       # 6-D model: the translation is copied through
+    assert dat["poses"] is g["poses"] and "obj_angles" not in dat                     # the input dict is not modified
+    R = out["obj_angles"]; assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    # not enough visible seed frames in the first clip -> the sequence is passed through unchanged
+    out2, done2 = drv.infill(dict(dat, obj_angles=g["obj_angles"]), g["obj_angles"], g["vis_bad"])
+    assert not done2 and np.array_equal(out2["obj_angles"], g["obj_angles"]) and np.array_equal(out2["obj_scales"], np.ones(275))
