@@ -237,3 +237,37 @@ def test_smplt_fitter_driver_api(synth, dropin):
     assert r.steps == 10 and np.isfinite(r.losses[:10]).all()
     with pytest.raises(NotImplementedError):
         BaseFitter(args=args, smpl_model=synth["model"], regressors=synth["regs"], priors=synth["priors"]).fit_one_batch("/seq", 1, 0, B, False)
+
+
+def test_packed_file_schemas(synth, tmp_path):
+    """pack_recon / pack_smplt / -neural_only dict schemas (preprocess/pack_recon.py:113-150, pack_smplt.py:44-58) built from the gathered
+    (T,182) rows; root joints == joint 0 of the reference's SMPL-H forward (golden), rotations projected like save_outputs does."""
+    from vistracker_amd import ops, packing as P
+    g = golden("smplh")
+    T = 4
+    rng = np.random.default_rng(5)
+    obj_R = (np.eye(3)[None] + 0.2 * rng.normal(size=(T, 3, 3))).astype(np.float32)             # un-projected optimisation variable
+    obj_t = rng.normal(size=(T, 3)).astype(np.float32); obj_s = np.ones(T, np.float32)
+    cu = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rows = P.to_rows(cu(g["pose"]), cu(g["betas"]), cu(g["trans"]), cu(obj_R), cu(obj_t), cu(obj_s))
+    assert rows.shape == (T, P.ROW_WIDTH)
+    h = ops.SmplhHandle(synth["model"])
+    frames = [f"/seq/t{i:04d}.000" for i in range(T)]
+    neural = {"pca_axis": rng.normal(size=(T, 3, 3)), "centers": rng.normal(size=(T, 6)), "visibility": rng.uniform(size=(T, 1))}
+    out = P.pack_recon(rows, frames, "male", "tri-vis-l2", h, neural=neural)
+    assert list(out) == ["poses", "betas", "trans", "root_joints", "obj_angles", "obj_trans", "obj_scales", "neural_pca", "neural_trans", "neural_visibility",
+                         "recon_exist", "recon_name", "frames", "gender"]
+    assert out["poses"].shape == (T, 156) and out["obj_angles"].shape == (T, 3, 3) and out["obj_scales"].shape == (T,) and out["recon_exist"].all()
+    assert np.abs(out["root_joints"] - g["jtr"][:, 0]).max() < 1e-5
+    U, _, Vt = np.linalg.svd(obj_R.astype(np.float64))
+    Rref = U @ (np.eye(3)[None] * np.stack([np.ones(T), np.ones(T), np.linalg.det(U @ Vt)], 1)[:, None, :]) @ Vt
+    assert np.abs(out["obj_angles"] - Rref).max() < 1e-5
+    assert np.allclose(out["neural_trans"][2], neural["centers"][2][3:]) and len(out["neural_pca"]) == T
+    p = str(tmp_path / "recon_x" / "seq_k1.pkl")
+    P.dump(out, p); back = P.load(p)
+    assert np.array_equal(back["poses"], out["poses"]) and back["frames"] == frames and back["recon_name"] == "tri-vis-l2"
+    nn_ = P.pack_neural(neural, frames, "male", "tri-vis-l2")
+    assert list(nn_) == ["neural_pca", "neural_trans", "neural_visibility", "recon_exist", "recon_name", "frames", "gender"]
+    st = P.pack_smplt(cu(g["pose"]), g["betas"], g["trans"], frames, "female")
+    assert list(st) == ["poses", "betas", "trans", "obj_angles", "obj_trans", "obj_scales", "gender", "frames"] and np.array_equal(st["obj_angles"][3], np.eye(3))
+    assert not st["obj_scales"].any()
