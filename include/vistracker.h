@@ -203,6 +203,11 @@ int vt_sqdiff_loss(const float *a, int a_stride, const float *b, int b_stride, i
 int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int *offy, int P, float gscale,
                       double *term, float *dx, float *dy, void *stream);
 
+/* Evaluation Chamfer, one direction (recon/eval/chamfer_distance.py:10-52, sklearn NearestNeighbors(k=1, metric='l2')): for each of
+ * the nq points of cloud pair p the Euclidean distance to the nearest of the ns points of `search`; query (P,nq,3), search (P,ns,3),
+ * dist (P,nq).  The bidirectional Chamfer of the reference is mean(dist(x->y)) + mean(dist(y->x)). */
+int vt_nn_distance(const float *query, int nq, const float *search, int ns, int P, float *dist, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Silhouette.  Replaces neural_renderer.Renderer(K, R=I, t=0, orig_size=1, anti_aliasing=False)(verts, faces,
  * mode='silhouettes') and its backward as used by SilLossROI.forward (recon/obj_pose_roi.py:77-94,183-207).

@@ -547,3 +547,44 @@ def test_hvop_infiller_vs_reference(hip):
     # not enough visible seed frames in the first clip -> the sequence is passed through unchanged
     out2, done2 = drv.infill(dict(dat, obj_angles=g["obj_angles"]), g["obj_angles"], g["vis_bad"])
     assert not done2 and np.array_equal(out2["obj_angles"], g["obj_angles"]) and np.array_equal(out2["obj_scales"], np.ones(275))
+
+
+def test_evaluation_vs_reference(hip, monkeypatch):
+    """VideoPackedEvaluator.eva_seq (window Procrustes alignment with the reference's counter quirk, Chamfer / v2v / acceleration errors in
+    cm) and its primitives against the reference run (tools/gen_golden_evaluation.py; Chamfer on the vertex sets on both sides)."""
+    from vistracker_amd import evaluation as E
+    g = golden("evaluation")
+    R, t, s = E.compute_transform(np.concatenate(g["sverts_recon"][:3], 0), np.concatenate(g["sverts_gt"][:3], 0))
+    assert np.abs(R - g["R"]).max() < 1e-5 and np.abs(t - g["t"]).max() < 1e-5 and abs(s - float(g["s"])) < 1e-5
+    for d, ref in zip(("bi", "x_to_y", "y_to_x"), g["ch"]):
+        assert abs(E.chamfer_distance(g["x"], g["y"], direction=d) - ref) < 2e-6 * max(1.0, abs(ref)), d
+    with pytest.raises(ValueError):
+        E.chamfer_distance(g["x"], g["y"], direction="both")
+    assert abs(E.compute_accel_err(g["sverts_gt"][:6], g["sverts_recon"][:6]) - float(g["acc"])) < 1e-4
+    assert abs(float(E.v2v_err(g["sverts_gt"][2], g["sverts_recon"][2])) - float(g["v2v"])) < 1e-6
+    # nearest-neighbour kernel: ragged tail (n not a multiple of the tile), several pairs per launch, against brute force
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=(3, 1000, 3)).astype(np.float32); sp = rng.normal(size=(3, 2500, 3)).astype(np.float32)
+    ref = np.sqrt(((q[:, :, None].astype(np.float64) - sp[:, None].astype(np.float64)) ** 2).sum(-1)).min(-1)
+    assert np.abs(npy(E.nn_distance(cu(q), cu(sp))) - ref).max() < 1e-5
+    # the sequence driver
+    monkeypatch.setattr(E, "surface_sampling", lambda verts, faces, n=0, generator=None: verts)
+    ev = E.VideoPackedEvaluator(g["sfaces"], g["ofaces"], window=int(g["window"]))
+    err = ev.eva_seq(g["sverts_gt"], g["overts_gt"], g["sverts_recon"], g["overts_recon"], recon_exist=g["recon_exist"])
+    assert err.shape == g["errors"].shape == (20, 6)
+    assert np.abs(err - g["errors"]).max() < 2e-3, np.abs(err - g["errors"]).max(0)             # cm
+
+
+def test_surface_sampling_is_area_weighted_and_seeded(hip):
+    from vistracker_amd import evaluation as E
+    # two triangles, areas 1 : 3 -> sample counts 1 : 3; samples lie inside their triangle; same seed = same draws
+    v = np.array([[0, 0, 0], [2, 0, 0], [0, 1, 0], [10, 0, 0], [13, 0, 0], [10, 2, 0]], np.float32); f = np.array([[0, 1, 2], [3, 4, 5]])
+    ga = torch.Generator(device="cuda"); ga.manual_seed(3); gb = torch.Generator(device="cuda"); gb.manual_seed(3)
+    p = npy(E.surface_sampling(v, f, 40000, ga)); p2 = npy(E.surface_sampling(v, f, 40000, gb))
+    assert np.array_equal(p, p2) and p.shape == (40000, 3)
+    first = p[:, 0] < 5
+    assert abs(first.mean() - 0.25) < 0.01
+    a = p[first]; assert (a[:, 0] >= 0).all() and (a[:, 1] >= 0).all() and (a[:, 0] / 2 + a[:, 1] <= 1 + 1e-5).all()
+    assert abs(a[:, 0].mean() - 2 / 3) < 0.02 and abs(a[:, 1].mean() - 1 / 3) < 0.01               # centroid of the first triangle
+    batch = E.surface_sampling(np.stack([v, v + 1]), f, 100, ga)
+    assert batch.shape == (2, 100, 3) and np.abs(npy(batch[1] - batch[0]) - 1).max() < 1e-5

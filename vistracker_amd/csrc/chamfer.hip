@@ -66,3 +66,37 @@ extern "C" int vt_chamfer_ragged(const float *x, const int *offx, const float *y
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
+
+// ---- evaluation Chamfer (recon/eval/chamfer_distance.py:10-52): per point the Euclidean (NOT squared) distance to the nearest
+// point of the other cloud; P equal-sized cloud pairs at once.  grid = (tiles of 256 query points, P); the searched cloud streams
+// through LDS as float4 (x, y, z, |p|^2 unused) in 2048-point chunks, every thread keeps its query point in registers.
+#define NN_CHUNK 2048
+__global__ __launch_bounds__(256) void nn_distance_kernel(const float *__restrict__ q, int nq, const float *__restrict__ s, int ns, float *__restrict__ dist)
+{
+    __shared__ float sx[NN_CHUNK], sy[NN_CHUNK], sz[NN_CHUNK];
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const float *qp = q + (size_t)p * nq * 3, *sp = s + (size_t)p * ns * 3;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < nq) { ax = qp[3 * i]; ay = qp[3 * i + 1]; az = qp[3 * i + 2]; }
+    float best = INFINITY;
+    for (int c0 = 0; c0 < ns; c0 += NN_CHUNK) {
+        const int cn = min(NN_CHUNK, ns - c0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cn; t += 256) { sx[t] = sp[3 * (c0 + t)]; sy[t] = sp[3 * (c0 + t) + 1]; sz[t] = sp[3 * (c0 + t) + 2]; }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < cn; j++) {
+            const float d0 = ax - sx[j], d1 = ay - sy[j], d2 = az - sz[j];
+            best = fminf(best, d0 * d0 + d1 * d1 + d2 * d2);
+        }
+    }
+    if (i < nq) dist[(size_t)p * nq + i] = sqrtf(best);
+}
+
+extern "C" int vt_nn_distance(const float *query, int nq, const float *search, int ns, int P, float *dist, void *stream)
+{
+    VT_REQUIRE(query && search && dist && nq > 0 && ns > 0 && P > 0 && P < 65536, "vt_nn_distance: bad argument");
+    hipLaunchKernelGGL(nn_distance_kernel, dim3((nq + 255) / 256, P), dim3(256), 0, vt_stream(stream), query, nq, search, ns, dist);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
