@@ -129,14 +129,31 @@ class SIFNetEncoder:
         keys = [k[7:] if k.startswith("module.") else k for k in sd]
         return cls(sd, shared_encoder=any(k.startswith("triplane_encoder.") for k in keys), **kw)
 
+    chunk = 16      # frames per encoder pass
+    _full_chunk_seen = False
+
     @torch.no_grad()
     def __call__(self, images):
+        """The batch is encoded ``chunk`` frames at a time (every op of the encoder is per-frame, so the result does not depend on the split;
+        the last chunk is zero-padded): ONE set of convolution shapes for MIOpen to pick kernels for whatever the batch size, and
+        activation memory bounded by the chunk, while the outputs land in maps preallocated for the whole batch."""
         assert images.shape[1] == 8, f"given image shape invalid: {images.shape}"
         images = images.to(self.device).float()
-        feats, tmpx, _ = self.image(images[:, :5])
-        maps = {"im_feat": feats[-1], "tmpx": tmpx}
-        for x in range(3):
-            f, t, _ = self.tri[x](images[:, 5 + x:6 + x])
-            maps[f"tri_tmpx{x}"] = t; maps[f"tri_feat{x}"] = f[-1]
-        # channels-last NCHW tensors are NHWC in memory: hand the storage to the query kernel as is
-        return ops.FeatureMaps({k: v.permute(0, 2, 3, 1).contiguous() for k, v in maps.items()})
+        B = images.shape[0]
+        out = None
+        for s0 in range(0, B, self.chunk):
+            x = images[s0:s0 + self.chunk]; n = x.shape[0]
+            if n < self.chunk and (B > self.chunk or self._full_chunk_seen):     # reuse the shapes MIOpen already has kernels for
+                x = torch.cat([x, torch.zeros(self.chunk - n, *x.shape[1:], device=x.device)], 0)
+            self._full_chunk_seen = self._full_chunk_seen or x.shape[0] == self.chunk
+            feats, tmpx, _ = self.image(x[:, :5])
+            maps = {"im_feat": feats[-1], "tmpx": tmpx}
+            for v in range(3):
+                f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
+                maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
+            if out is None:
+                # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from
+                out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}
+            for k, m in maps.items():
+                out[k][s0:s0 + n] = m[:n].permute(0, 2, 3, 1)
+        return ops.FeatureMaps(out)

@@ -1,0 +1,162 @@
+"""The whole tracking pipeline of ``scripts/demo.sh`` (steps 1-6) on tensors that are already in memory -- the glue between the mirrored
+stages, so that a sequence goes from 2-D keypoints + image crops to packed SMPL-H + object parameters without touching the disk:
+
+    1  SMPL-T pre-fit                         preprocess/fit_SMPLH_30fps.py            -> FitContext.fit_smplt (batches of ``smplt_bs``)
+    2  SmoothNet on SMPL-T, re-fit, pack      smoothnet/smooth_smplt.py, preprocess/fit_SMPLH_smoothed.py, pack_smplt.py
+    3  triplane renders of the SMPL-T mesh    render/render_triplane_nr.py             -> channels 5..7 of the network input
+    4  SIF-Net pass (neural only), pack       recon/recon_fit_trivis_full.py -neural_only, pack_recon.py -neural_only
+    5  SmoothNet on object rotation, HVOP-Net smoothnet/smooth_objrot.py -neural_pca, interp/test_cinfill_autoreg.py
+    6  joint optimisation, pack               recon/recon_fit_trivis_full.py, pack_recon.py
+
+Frames are sharded over ranks in whole batches (``sharding.shard_batches``) in the per-batch stages 1, 2b, 3, 4, 6; the whole-sequence
+stages 2a and 5 run on the gathered rows (one RCCL all-gather per barrier, ``sharding.gather_params``).  Dataset IO (image crops, openpose
+json, mocap initialisation) is the caller's: ``seq`` holds the tensors the reference's readers would produce.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+import time
+
+import numpy as np
+import torch
+
+from . import ops, packing, sharding
+from .fitting import FitContext
+from .generator import GeneratorTriplaneVis
+from .infill import MotionInfillAutoreg
+from .recon_fit import ReconFitterTriVisFull
+from .smoothing import ObjrotSmoother, SMPLTSmoother
+from .smpl import SMPLHGenerator
+from .triplane import TriplaneNrRenderer
+
+
+@dataclass
+class PipelineConfig:
+    smplt_bs: int = 512                 # scripts/demo.sh:13
+    neural_bs: int = 64                 # scripts/demo.sh:27
+    fit_bs: int = 96                    # recon_fit_triplane.py:257
+    smplt_max_iter: int = 100; refit_max_iter: int = 30
+    smooth_window: int = 64; smooth_step: int = 1
+    hvop_clip_len: int = 180; hvop_window: int = 30; occ_thres: float = 0.5
+    save_name: str = "test-releasev2"; neural_name: str = "test-release"
+    args: SimpleNamespace = field(default_factory=lambda: SimpleNamespace(net_img_size=[512, 512], loadSize=1200, camera_params=None))
+
+
+class SequencePipeline:
+    def __init__(self, smpl_model, regressors, priors, net, part_labels, scan, obj_points, pca_init, smoothnet_smpl, smoothnet_obj, infiller,
+                 cfg: PipelineConfig | None = None, device="cuda:0"):
+        """``net``: SIFNetQuery built with ``from_state_dict`` (encoder + decoders); ``smoothnet_smpl`` / ``smoothnet_obj``: SmoothNetSMPL / SmoothNet;
+        ``infiller``: ConditionalMInfiller; ``pca_init`` (3,3): PCA axes of the object template (PCAUtil.compute_pca, setup-only input)."""
+        self.cfg = cfg or PipelineConfig(); self.device = device
+        self.net, self.pca_init = net, np.asarray(pca_init, np.float32)
+        self.model_dict = smpl_model
+        self.fitter = ReconFitterTriVisFull(None, False, None, self.cfg.args, smpl_model=smpl_model, regressors=regressors, priors=priors, decoders=net.decoders,
+                                            part_labels=part_labels, scan=scan, obj_points=obj_points, device=device)
+        self.ctx: FitContext = self.fitter.ctx
+        self.generator = GeneratorTriplaneVis(net, "tri-vis-l2", threshold=2.0, device=device)
+        self.renderer = TriplaneNrRenderer(image_size=512, device=device)
+        self.smoother = SMPLTSmoother(smoothnet_smpl, self.cfg.smooth_window, self.cfg.smooth_step, device)
+        self.obj_smoother = ObjrotSmoother(smoothnet_obj, self.cfg.smooth_window, self.cfg.smooth_step, device)
+        self.infill = MotionInfillAutoreg(infiller, self.cfg.hvop_clip_len, self.cfg.hvop_window, self.cfg.occ_thres, device=device)
+        self.log = {}
+
+    # ---- helpers ---------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
+
+    def _shard(self, T, bs):
+        world, rank = self._world()
+        return sharding.shard_batches(T, bs, world, rank)
+
+    def _gather(self, rows, T, bs):
+        return sharding.gather_params(rows, T, bs)
+
+    def _t(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device).contiguous()
+
+    def _fit_smplt(self, poses, betas, trans, kpts, bs, max_iter, iter_for_global, lr_global):
+        """stages 1 / 2b: per-batch fused SMPL-T fit of this rank's batches, gathered to the full sequence"""
+        T = len(poses); rows = []
+        for s, e in self._shard(T, bs):
+            p, b, t = self._t(poses[s:e]), self._t(betas[s:e]), self._t(trans[s:e])
+            res = self.ctx.fit_smplt(p, b, t, self._t(kpts[s:e]), max_iter=max_iter, iter_for_global=iter_for_global, temporal=True, pinit_w=900.0, lr_global=lr_global)
+            self.log.setdefault("smplt_steps", []).append(res.steps)
+            b_out = self._t(betas[s:e]); b_out[:, :2] = b[:, :2]                      # copy_smpl_params keeps betas[2:]
+            rows.append(torch.cat([p, b_out, t], 1))
+        local = torch.cat(rows, 0) if rows else torch.zeros(0, 169, device=self.device)
+        full = self._gather(local, T, bs).cpu().numpy()
+        return full[:, :156], full[:, 156:166], full[:, 166:169]
+
+    # ---- the pipeline ------------------------------------------------------------------------------------------------------------
+    def run(self, seq: dict) -> dict:
+        """``seq``: mocap_poses (T,72|156), trans_init (T,3), kpts (T,25,3) full-image pixels, kpts_crop (T,25,3) network-input pixels, images5
+        (T,5,512,512) = RGB*mask, person mask, object mask, crop_center (T,2), frames (T,), gender.  Returns the packed dicts of every stage."""
+        cfg = self.cfg; T = len(seq["frames"]); frames = [str(f) for f in seq["frames"]]; gender = seq.get("gender", "male")
+        out = {}
+        sec = self.log.setdefault("seconds", {}); t_last = [time.perf_counter()]
+
+        def lap(name):
+            torch.cuda.synchronize(); now = time.perf_counter(); sec[name] = sec.get(name, 0.0) + now - t_last[0]; t_last[0] = now
+        # 1  SMPL-T pre-fit from the mocap initialisation (betas[:, 0] = 2.2, fit_SMPLH_30fps.py:128-130)
+        betas0 = np.zeros((T, 10), np.float32); betas0[:, 0] = 2.2
+        smpl0 = SMPLHGenerator.get_smplh(seq["mocap_poses"], betas0, seq["trans_init"], gender, self.device, model_root=self.model_dict)
+        poses, betas, trans = self._fit_smplt(smpl0.pose.data.cpu().numpy(), betas0, np.asarray(seq["trans_init"], np.float32), seq["kpts"], cfg.smplt_bs,
+                                              cfg.smplt_max_iter, 8, 0.01)
+        out["smplt"] = packing.pack_smplt(poses, betas, trans, frames, gender)
+        lap("1_smplt_fit")
+        # 2  SmoothNet on the whole sequence, re-fit to the keypoints from the smoothed start, pack
+        sm = self.smoother.smooth({"poses": poses, "betas": betas, "trans": trans, "frames": frames})
+        sp = np.asarray(sm["poses"], np.float32)
+        if sp.shape[1] == 72:                                                          # SmoothNet works on the 24 SMPL joints: keep the SMPL-H hands
+            full = poses.copy(); full[:, :66] = sp[:, :66]; sp = full
+        poses, betas, trans = self._fit_smplt(sp, np.asarray(sm["betas"], np.float32), np.asarray(sm["trans"], np.float32), seq["kpts"], cfg.smplt_bs,
+                                              cfg.refit_max_iter, 0, 0.005)
+        out["smplt_smoothed_fit"] = packing.pack_smplt(poses, betas, trans, frames, gender)
+        lap("2_smooth_refit")
+        # 3  triplane renders + body centres of the SMPL-T meshes
+        images = torch.zeros(T, 8, 512, 512, device=self.device); images[:, :5] = self._t(seq["images5"])
+        body_center = torch.zeros(T, 3, device=self.device)
+        faces = torch.as_tensor(np.asarray(self.model_dict["f"]).astype(np.int32), device=self.device)
+        for s in range(0, T, 64):
+            e = min(T, s + 64)
+            verts, _, _ = ops.smplh_forward(self.ctx.smpl, self._t(poses[s:e]), self._t(betas[s:e]), self._t(trans[s:e]))
+            bc = ops.landmarks(self.ctx.b25, verts)[:, 8]
+            body_center[s:e] = bc
+            images[s:e, 5:8] = self.renderer.render_batch(verts, faces, bc)
+        data = {"images": images, "crop_center": self._t(seq["crop_center"]), "body_center": body_center}
+        lap("3_triplane")
+        # 4  SIF-Net neural-only pass over this rank's batches: PCA axes, relative object centre, visibility per frame
+        rows = []
+        for s, e in self._shard(T, cfg.neural_bs):
+            pc, *_ = self.fitter.fit_recon_batch(cfg.args, {k: v[s:e] for k, v in data.items()}, self.generator, None, None, neural_only=True)
+            o = pc["object"]
+            rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
+        local = torch.cat(rows, 0) if rows else torch.zeros(0, 16, device=self.device)
+        neural = self._gather(local, T, cfg.neural_bs).cpu().numpy()
+        neural_dict = {"pca_axis": neural[:, :9].reshape(T, 3, 3), "centers": neural[:, 9:15], "visibility": neural[:, 15:16]}
+        out["neural"] = packing.pack_neural(neural_dict, frames, gender, cfg.neural_name)
+        lap("4_sifnet_neural")
+        # 5  whole-sequence: smooth the object rotations (6-D SmoothNet), then visibility-aware infill (HVOP-Net)
+        raw = self.obj_smoother.load_inputs(out["neural"], pca_init=self.pca_init, neural_pca=True)
+        out["obj_smooth"] = self.obj_smoother.smooth(raw)
+        smplt_pack = dict(out["smplt_smoothed_fit"]); smplt_pack["obj_trans"] = np.zeros((T, 3))
+        out["hvop"], out["hvop_applied"] = self.infill.infill(smplt_pack, out["obj_smooth"]["obj_angles"], neural[:, 15])
+        obj_rots = out["hvop"]["obj_angles"] if out["hvop_applied"] else out["obj_smooth"]["obj_angles"]
+        lap("5_objrot_smooth_infill")
+        # 6  joint optimisation of this rank's batches, gather, pack
+        rows = []
+        for s, e in self._shard(T, cfg.fit_bs):
+            smpl = SMPLHGenerator.get_smplh(poses[s:e], betas[s:e], trans[s:e], gender, self.device, model_root=self.model_dict)
+            pc, smpl, oR, ot, osc = self.fitter.fit_recon_batch(cfg.args, {k: v[s:e] for k, v in data.items()}, self.generator, smpl, self._t(seq["kpts_crop"][s:e]),
+                                                               obj_rots=np.asarray(obj_rots[s:e], np.float32))
+            self.log.setdefault("fit_steps", []).append((self.fitter.last["smpl"].steps, self.fitter.last["object"].steps))
+            rows.append(packing.to_rows(smpl.pose.data, smpl.betas.data, smpl.trans.data, oR.data, ot.data, osc))
+        local = torch.cat(rows, 0) if rows else torch.zeros(0, packing.ROW_WIDTH, device=self.device)
+        full = self._gather(local, T, cfg.fit_bs)
+        out["recon"] = packing.pack_recon(full, frames, gender, cfg.save_name, self.ctx.smpl, neural=neural_dict)
+        lap("6_joint_fit")
+        return out

@@ -115,6 +115,92 @@ class ReconFitterTriVisFull(ReconFitterBase):
         bmin, bmax = self.get_smpl_bbox(smpl)
         return (bmax - bmin)[:, 1]
 
+    # ---- batch-level orchestration of fit_recon (recon_fit_triplane.py:29-111), compute steps only --------------------------
+    MINI_BATCH = 16             # recon_fit_behave.py:123-124
+
+    def generate_all(self, args, data, generator, num_points=4000):
+        """surface points + neural predictions of a whole batch, 16 frames at a time, cut to the common sample count
+        (recon_fit_behave.py:121-150); per-mini-batch results are NOT written to disk here (save_neural_recon is IO)"""
+        outs = []
+        samples_count = 100000
+        batch_size = data["images"].shape[0]
+        for s0 in range(0, batch_size, self.MINI_BATCH):
+            mini = {k: (v[s0:s0 + self.MINI_BATCH] if hasattr(v, "__getitem__") and not isinstance(v, (str, bytes, dict)) else v) for k, v in data.items()}
+            pc = generator.generate_pclouds_batch(mini, num_points=num_points, num_steps=10, mute=True)
+            samples_count = int(min(pc["human"]["points"].shape[1], pc["object"]["points"].shape[1], samples_count))
+            outs.append(pc)
+        return self.combine_mini_batches(outs, samples_count)
+
+    @staticmethod
+    def combine_mini_batches(pc_generated_all, samples_count):
+        """recon_fit_behave.py:152-183: points / parts cut to ``samples_count`` and concatenated over the mini batches, the rest concatenated"""
+        comb = {"human": {}, "object": {}}
+        for pc in pc_generated_all:
+            for target in comb:
+                for k, v in pc[target].items():
+                    v = v[:, :samples_count] if k in ("points", "parts") else v
+                    comb[target][k] = v if k not in comb[target] else torch.cat([comb[target][k], v], 0)
+        return comb
+
+    def get_smpl_translation(self, data, pc_generated):
+        """the triplane fitters do not use the predicted human centre (NaN in the vis generator's output) but the pre-fit body centre
+        (recon_fit_triplane.py:210-220)"""
+        return data["body_center"]
+
+    def scale_body_kpts(self, kpts, resize_scale, crop_scale, crop_center, crop_size=1200.0, net_in_size=512.0):
+        """openpose keypoints of the original image -> network-input pixels (recon_fit_base.py:397-409)"""
+        pxy = kpts[:, :, :2] * resize_scale.unsqueeze(1).unsqueeze(1)
+        crop_size_org = crop_scale * crop_size
+        pxy = pxy - crop_center.unsqueeze(1) + crop_size_org.unsqueeze(1).unsqueeze(1) / 2
+        pxy = pxy * net_in_size / crop_size_org.unsqueeze(1).unsqueeze(1)
+        return torch.cat([pxy, kpts[:, :, 2:3]], -1)
+
+    def init_obj_fit_data(self, batch_size, human_t, pc_generated, scale, obj_rots=None, pca_init=None):
+        """recon_fit_trivis_full.py:78-104: obj_t = predicted relative centre + human centre; obj_R from the predicted PCA axes
+        (``-or neural``: pass ``pca_init`` (3,3) of the template) or from an earlier stage's rotations (``obj_rots`` (B,3,3), e.g. HVOP-Net)"""
+        obj_t = (pc_generated["object"]["centers"][:, 3:].to(self.device) + human_t.to(self.device)).clone().detach()
+        if obj_rots is None:
+            assert pca_init is not None, "neural object rotations need the PCA axes of the template"
+            axis_init = torch.as_tensor(np.asarray(pca_init), dtype=torch.float32, device=self.device)[None].repeat(batch_size, 1, 1)
+            obj_R = self.init_object_orientation(pc_generated["object"]["pca_axis"].to(self.device).float(), axis_init)
+        else:
+            obj_R = torch.as_tensor(np.asarray(obj_rots) if not torch.is_tensor(obj_rots) else obj_rots).to(self.device).float()
+        obj_s = scale.clone().detach().to(self.device)
+        object_init = self.ctx.obj_points[None].repeat(batch_size, 1, 1)
+        return obj_R.contiguous(), obj_s, obj_t.contiguous(), object_init
+
+    def fit_recon_batch(self, args, data, generator, smpl, body_kpts, obj_rots=None, pca_init=None, neural_only=False):
+        """one iteration of the ``fit_recon`` loop on an in-memory batch: ``data`` = the dataloader's dict (images (B,8,H,W), crop_center,
+        body_center, ...), ``smpl`` = the SMPL-T initialisation of the batch (get_smpl_init), ``body_kpts`` (B,25,3) already in
+        network-input pixels.  Returns ``(pc_generated, smpl, obj_R, obj_t, obj_s)``; with ``neural_only`` the fit is skipped."""
+        import time
+        sec = self.last.setdefault("seconds", {}); t_last = [time.perf_counter()]
+
+        def lap(name):
+            torch.cuda.synchronize(); now = time.perf_counter(); sec[name] = sec.get(name, 0.0) + now - t_last[0]; t_last[0] = now
+        pc = self.generate_all(args, data, generator)
+        lap("generate_all")
+        if neural_only:
+            return pc, None, None, None, None
+        with torch.no_grad():
+            generator.filter(data)
+        lap("filter")
+        human_t = self.get_smpl_translation(data, pc)
+        B = data["images"].shape[0]
+        query_dict = {"crop_center": data["crop_center"].to(self.device).float(), "body_center": data["body_center"].to(self.device).float()}
+        betas_dict = {"images": data["images"], "body_kpts": body_kpts.to(self.device).float(), "query_dict": query_dict, "net": generator.model}
+        smpl, _ = self.optimize_smpl(smpl, betas_dict, iter_for_kpts=1, iter_for_pose=1, iter_for_betas=1)
+        lap("optimize_smpl")
+        scale = torch.ones(B, device=self.device)                                   # "use single scale", recon_fit_triplane.py:78
+        obj_R, obj_s, obj_t, _ = self.init_obj_fit_data(B, human_t, pc, scale, obj_rots=obj_rots, pca_init=pca_init)
+        vis = pc["object"]["visibility"]
+        data_dict = {"obj_R": obj_R, "obj_t": obj_t, "obj_s": obj_s, "smpl": smpl, "images": data["images"].to(self.device), "body_kpts": betas_dict["body_kpts"],
+                     "query_dict": query_dict, "net_input_size": getattr(args, "net_img_size", [512])[0], "crop_size": getattr(args, "loadSize", 1200),
+                     "camera_params": getattr(args, "camera_params", None), "occ_ratios": vis.reshape(B, -1)[:, 0].to(self.device).float()}
+        smpl, obj_R, obj_t = self.optimize_smpl_object(generator.model, data_dict)
+        lap("optimize_smpl_object")
+        return pc, smpl, obj_R, obj_t, obj_s
+
     # ---- the two optimisation loops -------------------------------------------------------------------------
     @staticmethod
     def _maps(model):

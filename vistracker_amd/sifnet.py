@@ -24,6 +24,7 @@ class SIFNetQuery:
     def __init__(self, decoders: dict, camera: KinectColorCamera | None = None, device="cuda:0"):
         self.camera = camera or KinectColorCamera(1200)
         self.handle = ops.SifNetHandle(decoders, self.camera.as_cam5(), device)
+        self.decoders = decoders            # host copy (name -> layers), reused by fitters that build their own handle
         self.device = device
         self.maps = None
         self.preds = None

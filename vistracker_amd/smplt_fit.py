@@ -28,6 +28,7 @@ ICAP_CAM = (918.457763671875, 918.4373779296875, 956.9661865234375, 555.94458007
 
 class BaseFitter:
     temporal = False
+    lr_global, lr_all = 0.01, 0.001       # init_globalpose_optimizer / init_allpose_optimizer (fit_SMPLH_kpts.py:182-192)
 
     def __init__(self, device="cuda:0", debug=False, init_type="mocap", args=None, *, smpl_model, regressors, priors, source=None):
         """``device / debug / init_type / args`` as in fit_SMPLH_kpts.py:31-53 (``args.icap`` selects the InterCap camera).  Keyword-only:
@@ -140,7 +141,7 @@ class BaseFitter:
         with torch.no_grad():
             pose = smpl.pose.data.contiguous().clone(); betas = smpl.betas.data.contiguous().clone(); trans = smpl.trans.data.contiguous().clone()
             res = self.ctx.fit_smplt(pose, betas, trans, kpts, max_iter=self.get_max_iters(), iter_for_global=self.get_globalopt_iters(),
-                                     temporal=self.temporal, pinit_w=w["pinit"])
+                                     temporal=self.temporal, pinit_w=w["pinit"], lr_global=self.lr_global, lr_all=self.lr_all)
             smpl.pose.data.copy_(pose); smpl.trans.data.copy_(trans); smpl.betas.data[:, :2] = betas[:, :2]      # copy_smpl_params
         self.last = res
         self.save_results(smpl, seq_folder, kid, start, end, kpts[:, :, 2], image_files)
@@ -178,3 +179,15 @@ class SMPLHFitter30fps(BaseFitter):
         self.compute_prior_loss(loss_dict, smpl)
         loss_dict["pinit"] = torch.mean((pose_init[:, 3:66] - smpl.body_pose) ** 2)
         return loss_dict
+
+
+class SMPLHFitterSmoothed(SMPLHFitter30fps):
+    """preprocess.fit_SMPLH_smoothed.SMPLHFitterSmoothed (fit_SMPLH_smoothed.py:25-113): re-fit starting from the SmoothNet output -- no
+    global-pose warm-up, 30 outer iterations; ``init_smpl`` / ``load_kpts`` read packed files in the reference (hooks here)."""
+    lr_global = 0.005           # only reached when a subclass raises get_globalopt_iters again
+
+    def get_globalopt_iters(self):
+        return 0
+
+    def get_max_iters(self):
+        return 30
