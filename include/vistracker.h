@@ -117,6 +117,13 @@ int vt_nchw_to_nhwc(const float *src, int B, int C, int H, int W, float *dst, vo
 typedef struct {
     const float *maps[8];
     int res[8];
+    /* optional: hoisted layer-1 projection of im_feat, (B, res[0], res[0], proj_cols) floats written by vt_query_build_projection for THESE
+     * maps and THIS network (NULL = not available).  Layer 1 of the decoders (Conv1d(611,128), chore.py:113-126) is linear in the features
+     * and the features are bilinear blends of texels (geometry.py:4-14), so its im_feat part can be applied to the texels once per batch
+     * instead of to every query point at every optimisation step; the fused objective / projection-step entry points then blend rows of
+     * this array instead of gathering the 256 im_feat channels and multiplying them by W1.  Results agree to fp32 round-off. */
+    const float *proj;
+    int proj_cols;
 } vt_maps;
 
 /* pts (B,N,3), crop_center (B,2), body_center (B,3).  Outputs may be NULL (head skipped); layout as the
@@ -129,6 +136,10 @@ int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const float *pts,
                       const float *body_center, int B, int N,
                       const float *d_df, const float *d_pca, const float *d_parts, const float *d_centers,
                       const float *d_vis, float *dpts, void *stream);
+
+/* floats of the projection array for a batch of B frames, and its construction (one fp32 GEMM over all im_feat texels; heads df | parts) */
+long vt_query_projection_floats(const vt_maps *maps, int B);
+int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps, int B, float *proj, void *stream);
 
 /* Fused objective kernels of the two fit loops (no autograd tape, one launch per step):
  *  human:  loss += w_dfh * mean_{B,N} clamp(df[:,0], max=.1) + w_part * mean_B sum_N CE(parts, labels)

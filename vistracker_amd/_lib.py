@@ -21,7 +21,7 @@ cd = C.c_double
 
 
 class VtMaps(C.Structure):
-    _fields_ = [("maps", C.c_void_p * 8), ("res", C.c_int * 8)]
+    _fields_ = [("maps", C.c_void_p * 8), ("res", C.c_int * 8), ("proj", C.c_void_p), ("proj_cols", C.c_int)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against the header
@@ -54,6 +54,8 @@ SIGNATURES = {
     "vt_upsample2x_bicubic_add": (ci, [fp, fp, ci, ci, ci, ci, fp, vp]),
     "vt_triplane_render": (ci, [fp, fp, ci, ci, fp, ci, ci, fp, fp, fp, vp]),
     "vt_query_project_step": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, ci, cf, fp, fp, vp]),
+    "vt_query_projection_floats": (C.c_long, [C.POINTER(VtMaps), ci]),
+    "vt_query_build_projection": (ci, [vp, C.POINTER(VtMaps), ci, fp, vp]),
     "vt_so3_project_forward": (ci, [fp, fp, ci, fp, vp]),
     "vt_so3_project_backward": (ci, [fp, fp, ci, fp, fp, vp]),
     "vt_rigid_forward": (ci, [fp, ci, fp, fp, fp, ci, ci, fp, vp]),

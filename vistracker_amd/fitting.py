@@ -116,6 +116,8 @@ class FitResult:
 class FitContext:
     """Device-resident constants shared by all batches of a sequence: SMPL-H model, body25 regressor, priors,
     SIF-Net decoders, part labels, object template / surface samples."""
+    # hoist the im_feat part of the decoders' first layer out of the Adam loops (ops.FeatureMaps.build_projection, DESIGN.md 4.1)
+    use_projection = True
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -217,6 +219,8 @@ class FitContext:
     def optimize_smpl(self, maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter=100, iter_for_betas=1,
                       iter_for_pose=1, iter_for_kpts=1, it_range=None, net_size=512.0, check_every=1, prof=None):
         dev = pose.device; B = pose.shape[0]; V = 6890
+        if self.use_projection:
+            maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale
         names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
         terms = Terms(names, dev)
         verts = torch.empty(B, V, 3, device=dev); jtr = torch.empty(B, 52, 3, device=dev); vposed = torch.empty_like(verts)
@@ -283,6 +287,8 @@ class FitContext:
         """obj_R (B,3,3), obj_t (B,3) are updated in place.  ``smpl_verts`` (B,6890,3): the frozen body (contacts).
         ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``)."""
         dev = obj_R.device; B = obj_R.shape[0]; N = self.obj_points.shape[0]; NV = self.obj_verts.shape[0]
+        if self.use_projection:
+            maps.build_projection(self.net)
         names = ["object", "otemp", "ovtemp", "mask", "trans", "contact"]
         terms = Terms(names, dev)
         total = joint_iter + iter_for_obj + max_iter + iter_for_sil

@@ -210,9 +210,26 @@ class FeatureMaps:
         for t, c in zip(self.t, MAP_CHANNELS):
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape[-1] == c and t.shape[1] == t.shape[2]
         self.B = self.t[0].shape[0]
+        self.proj = None
         self.c = L.VtMaps()
         for i, t in enumerate(self.t):
             self.c.maps[i] = t.data_ptr(); self.c.res[i] = t.shape[1]
+
+    def build_projection(self, net):
+        """Hoist the im_feat part of the decoders' first layer out of the optimisation loop (vt_query_build_projection): one fp32 GEMM over
+        all im_feat texels of the batch -> (B, res, res, 256) array the fused objective kernels blend instead of gathering 256 channels and
+        multiplying by W1 at every step.  Valid for these maps and the network ``net`` only; the fit loops call it once per batch."""
+        h = net.h if hasattr(net, "h") else net.handle.h
+        n = L.lib().vt_query_projection_floats(C.byref(self.c), self.B)
+        self.proj = torch.empty(n, device=self.t[0].device)
+        self.c.proj = None; self.c.proj_cols = 0
+        L.check(L.lib().vt_query_build_projection(h, C.byref(self.c), self.B, self.proj.data_ptr(), L.stream_ptr()))
+        self.c.proj = self.proj.data_ptr(); self.c.proj_cols = n // (self.B * self.t[0].shape[1] * self.t[0].shape[2])
+        return self
+
+    def drop_projection(self):
+        self.proj = None; self.c.proj = None; self.c.proj_cols = 0
+        return self
 
     @staticmethod
     def from_nchw(maps: dict, device="cuda:0"):
