@@ -142,8 +142,10 @@ def test_query_vs_golden(hip):
     assert rel(npy(pts.grad), g["dpts_df"] + g["dpts_parts"]) < 5e-6
 
 
-def test_query_fused_objectives_vs_oracle(hip, synth):
-    """vt_query_human_loss / vt_query_object_loss == oracle forward + loss + backward (N not a multiple of 64)."""
+@pytest.mark.parametrize("proj", [False, True])
+def test_query_fused_objectives_vs_oracle(hip, synth, proj):
+    """vt_query_human_loss / vt_query_object_loss == oracle forward + loss + backward (N not a multiple of 64), on the direct path and
+    with the hoisted im_feat projection (vt_query_build_projection; the array itself is checked against a float64 product)."""
     import ctypes as C
     from oracle import oracle as O
     from vistracker_amd import synthetic as syn, _lib as L
@@ -172,6 +174,16 @@ def test_query_fused_objectives_vs_oracle(hip, synth):
     dpts_o = net_o.query_bwd(pts, cc, bc, d_df=d_df2.astype(np.float32))
 
     maps = hip["ops"].FeatureMaps.from_nchw(mp)
+    if proj:
+        maps.build_projection(hip["net"])
+        assert maps.c.proj_cols == 256 and maps.proj.numel() == B * mp["im_feat"].shape[2] * mp["im_feat"].shape[3] * 256
+        P = npy(maps.proj).reshape(B, mp["im_feat"].shape[2], mp["im_feat"].shape[3], 256)
+        tex = np.transpose(np.asarray(mp["im_feat"], np.float64), (0, 2, 3, 1))
+        for col, head in ((0, "df"), (128, "parts")):
+            W1 = np.asarray(synth["decoders"][head][0][0], np.float64)           # (128, 611), im_feat = reference channels 0..255
+            s1 = 2.0 ** (14 - np.frexp(np.abs(W1).max())[1])                     # the kernel's power-of-two weight scale
+            ref = tex @ (64.0 * s1 * W1[:, :256]).T
+            assert np.abs(P[..., col:col + 128] - ref).max() < 2e-6 * np.abs(ref).max(), head
     terms = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, N, 3, device="cuda")
     pts_t, cc_t, bc_t, lab_t, occ_t = cu(pts), cu(cc), cu(bc), cu(labels), cu(occ)
     L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,

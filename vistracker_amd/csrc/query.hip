@@ -381,18 +381,32 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         const int R = a.res[0];
         const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            unsigned o[4]; float w[4], unused[4];
-            proj_geom(sUV, 16 * p + j, R, a.pw, o, w, unused, false);
+        for (int p2 = 0; p2 < 4; p2 += 2) {
+            // two points per round: 32 independent 16-byte loads in flight before the first blend (the phase is latency-bound)
+            unsigned o[2][4]; float w[2][4], unused[4];
+            float4 t[2][G][2][4];
 #pragma unroll
-            for (int g = 0; g < G; g++)
+            for (int pp = 0; pp < 2; pp++) {
+                proj_geom(sUV, 16 * (p2 + pp) + j, R, a.pw, o[pp], w[pp], unused, false);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
-                    const unsigned col = (unsigned)(a.hw[g].pcol + 32 * wave + 16 * nt + 4 * q);
-                    const float4 nw = *reinterpret_cast<const float4 *>(Pb + o[0] + col), ne = *reinterpret_cast<const float4 *>(Pb + o[1] + col);
-                    const float4 sw = *reinterpret_cast<const float4 *>(Pb + o[2] + col), se = *reinterpret_cast<const float4 *>(Pb + o[3] + col);
-                    acc1[g].v[nt][p] = (f32x4){TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w)};
-                }
+                for (int g = 0; g < G; g++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const unsigned col = (unsigned)(a.hw[g].pcol + 32 * wave + 16 * nt + 4 * q);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) t[pp][g][nt][k] = *reinterpret_cast<const float4 *>(Pb + o[pp][k] + col);
+                    }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++)
+#pragma unroll
+                for (int g = 0; g < G; g++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const float4 nw = t[pp][g][nt][0], ne = t[pp][g][nt][1], sw = t[pp][g][nt][2], se = t[pp][g][nt][3];
+                        const float *wq = w[pp];
+                        acc1[g].v[nt][p2 + pp] = (f32x4){TAPSUM_(x, wq), TAPSUM_(y, wq), TAPSUM_(z, wq), TAPSUM_(w, wq)};
+                    }
         }
     }
 #endif
@@ -673,17 +687,29 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         for (int g = 0; g < G; g++) {
             float dg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const h8 hh = as_h8(dh[g][s][0]), hl = as_h8(dh[g][s][1]);
-                float x[8];
+            for (int s2 = 0; s2 < 4; s2 += 2) {
+                // two K32 steps per round: 16 independent 16-byte loads in flight, then 64 multiply-adds
+                float4 pr[2][4][2];
 #pragma unroll
-                for (int t = 0; t < 8; t++) x[t] = (float)hh[t] + (float)hl[t];
-                const unsigned col = (unsigned)(a.hw[g].pcol + 32 * s + 8 * q);
+                for (int ss = 0; ss < 2; ss++) {
+                    const unsigned col = (unsigned)(a.hw[g].pcol + 32 * (s2 + ss) + 8 * q);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float4 p0 = *reinterpret_cast<const float4 *>(Pb + o[k] + col), p1 = *reinterpret_cast<const float4 *>(Pb + o[k] + col + 4);
-                    dg[k] = __builtin_fmaf(x[7], p1.w, __builtin_fmaf(x[6], p1.z, __builtin_fmaf(x[5], p1.y, __builtin_fmaf(x[4], p1.x,
-                            __builtin_fmaf(x[3], p0.w, __builtin_fmaf(x[2], p0.z, __builtin_fmaf(x[1], p0.y, __builtin_fmaf(x[0], p0.x, dg[k]))))))));
+                    for (int k = 0; k < 4; k++) {
+                        pr[ss][k][0] = *reinterpret_cast<const float4 *>(Pb + o[k] + col); pr[ss][k][1] = *reinterpret_cast<const float4 *>(Pb + o[k] + col + 4);
+                    }
+                }
+#pragma unroll
+                for (int ss = 0; ss < 2; ss++) {
+                    const h8 hh = as_h8(dh[g][s2 + ss][0]), hl = as_h8(dh[g][s2 + ss][1]);
+                    float x[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x[t] = (float)hh[t] + (float)hl[t];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float4 p0 = pr[ss][k][0], p1 = pr[ss][k][1];
+                        dg[k] = __builtin_fmaf(x[7], p1.w, __builtin_fmaf(x[6], p1.z, __builtin_fmaf(x[5], p1.y, __builtin_fmaf(x[4], p1.x,
+                                __builtin_fmaf(x[3], p0.w, __builtin_fmaf(x[2], p0.z, __builtin_fmaf(x[1], p0.y, __builtin_fmaf(x[0], p0.x, dg[k]))))))));
+                    }
                 }
             }
             const float ks = kscale[g] * (1.0f / ACT_SCALE);

@@ -20,6 +20,8 @@ from . import ops
 
 
 class Generator:
+    use_projection = True
+
     def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,
                  filter_val=0.03, seed=0, **kwargs):
         """``model``: a ``vistracker_amd.sifnet.SIFNetQuery`` (weights already loaded: ``SIFNetQuery.from_state_dict``);
@@ -46,6 +48,10 @@ class Generator:
             raise ValueError("the triplane SIF-Net needs body_center in the query input (generator_triplane.py:15-31)")
         samples = samples.detach().contiguous().clone()
         preds = None
+        if self.use_projection and model.maps.proj is None:
+            # the maps of one filter() call serve hundreds of projection steps: hoist the im_feat part of layer 1 (FeatureMaps.build_projection);
+            # filter() / set_feature_maps() create a new FeatureMaps object, so a projection never outlives its maps
+            model.maps.build_projection(model.handle)
         for j in range(num_steps):
             query_input = self.update_query_dict(samples, query_input)
             if j == num_steps - 1:
