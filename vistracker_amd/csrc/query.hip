@@ -322,6 +322,13 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
 }
 
+// per-phase shader-clock breakdown (debug builds with -DPHASE_CLK only; tools/bench_scripts/qphase.py)
+#ifdef PHASE_CLK
+__device__ unsigned long long g_phase[8];
+#define PCLK(i_) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_phase[i_], t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define PCLK(i_)
+#endif
 template <int G, int MODE, bool USEP>
 __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArgs a)
 {
@@ -349,6 +356,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         else { b = L / tiles; tile = L % tiles; }
     }
     const int n0 = tile * 64;
+#ifdef PHASE_CLK
+    unsigned long long tprev_ = clock64();
+#endif
 
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
     if (tid < 64) {
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         }
     }
 #endif
+    PCLK(0);
     Taps tp;
     TapGeom<1> tg;
     { int mi, co; chunk_info(C0, mi, co); taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
@@ -465,6 +476,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         }
     }
 #undef LOAD_W1
+    PCLK(1);
     __syncthreads();        // region 0 changes role: chunk buffers -> hidden-activation planes
     // hidden-1 activations of ALL heads go to their planes right away: no head's layer-1 accumulators stay live in registers
     // while another head runs its layers 2..4 and backward
@@ -624,6 +636,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         __syncthreads();
     }
 
+    PCLK(2);
     if (MODE == MODE_HUMAN || MODE == MODE_OBJECT) {
         // block-reduce the loss partials into the fp64 term accumulators
 #pragma unroll
@@ -721,6 +734,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         gx = su * j0x; gy = sv * j0y; gz = __builtin_fmaf(sv, j0zv, su * j0zu);
     }
 #endif
+    PCLK(3);
     for (int ci = C0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);
         f32x4 dd[G][2];
@@ -790,6 +804,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         }
     }
 #undef SLAB_DMA
+    PCLK(4);
     {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
         f32x4 dz[G];
 #pragma unroll
@@ -987,6 +1002,14 @@ __global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict_
         }
 }
 
+#ifdef PHASE_CLK
+extern "C" int vt_phase_clk(unsigned long long *out, int reset)
+{
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+    return 0;
+}
+#endif
 extern "C" long vt_query_projection_floats(const vt_maps *maps, int B)
 {
     if (!maps || B <= 0 || maps->res[0] < 2) return 0;
