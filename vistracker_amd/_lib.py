@@ -92,6 +92,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VtError(f"{LIB_PATH} is missing: build it with `make -C vistracker_amd/csrc` "
                           f"(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        # PyTorch-ROCm ships its own libamdhip64 and must be the FIRST to load one: if this library pulled in /opt/rocm's copy before
+        # torch was imported the process would hold two HIP runtimes, and the second one finds no device ("no ROCm-capable device is
+        # detected" at the first hipMalloc).  With torch loaded first the dynamic linker resolves our dependency to the same runtime
+        # object, which is also what makes torch's device pointers and streams valid inside the library.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
