@@ -133,14 +133,14 @@ class SIFNetEncoder:
     _full_chunk_seen = False
 
     @torch.no_grad()
-    def __call__(self, images):
-        """The batch is encoded ``chunk`` frames at a time (every op of the encoder is per-frame, so the result does not depend on the split;
+    def __call__(self, images, out=None):
+        """``out``: optional dict of preallocated NHWC tensors (B,H,W,C) per map name to write into (e.g. slices of whole-sequence buffers).
+        The batch is encoded ``chunk`` frames at a time (every op of the encoder is per-frame, so the result does not depend on the split;
         the last chunk is zero-padded): ONE set of convolution shapes for MIOpen to pick kernels for whatever the batch size, and
         activation memory bounded by the chunk, while the outputs land in maps preallocated for the whole batch."""
         assert images.shape[1] == 8, f"given image shape invalid: {images.shape}"
         images = images.to(self.device).float()
         B = images.shape[0]
-        out = None
         for s0 in range(0, B, self.chunk):
             x = images[s0:s0 + self.chunk]; n = x.shape[0]
             if n < self.chunk and (B > self.chunk or self._full_chunk_seen):     # reuse the shapes MIOpen already has kernels for
@@ -152,7 +152,7 @@ class SIFNetEncoder:
                 f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
                 maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
             if out is None:
-                # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from
+                # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from; written per chunk
                 out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}
             for k, m in maps.items():
                 out[k][s0:s0 + n] = m[:n].permute(0, 2, 3, 1)

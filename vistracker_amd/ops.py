@@ -215,6 +215,10 @@ class FeatureMaps:
         for i, t in enumerate(self.t):
             self.c.maps[i] = t.data_ptr(); self.c.res[i] = t.shape[1]
 
+    def slice(self, start, end):
+        """frames [start, end) as a FeatureMaps of views (no copy; the projection, if any, is not carried over)"""
+        return FeatureMaps({k: t[start:end] for k, t in zip(MAP_ORDER, self.t)})
+
     def build_projection(self, net):
         """Hoist the im_feat part of the decoders' first layer out of the optimisation loop (vt_query_build_projection): one fp32 GEMM over
         all im_feat texels of the batch -> (B, res, res, 256) array the fused objective kernels blend instead of gathering 256 channels and

@@ -62,11 +62,12 @@ class SIFNetQuery:
         """maps: dict name -> (B,C,H,W) tensors/arrays in the reference layout, or an ``ops.FeatureMaps`` (already NHWC)."""
         self.maps = maps if isinstance(maps, ops.FeatureMaps) else ops.FeatureMaps.from_nchw(maps, self.device)
 
-    def filter(self, images):
-        """encode (B,8,H,W) images into the eight feature maps (chore_triplane.py:60-95); needs encoder weights (from_state_dict)"""
+    def filter(self, images, out=None):
+        """encode (B,8,H,W) images into the eight feature maps (chore_triplane.py:60-95); needs encoder weights (from_state_dict).
+        ``out``: optional preallocated NHWC tensors per map name (see SIFNetEncoder.__call__)."""
         if self.encoder is None:
             raise RuntimeError("this SIFNetQuery has no encoder weights: build it with from_state_dict(checkpoint) or call set_feature_maps()")
-        self.maps = self.encoder(images)
+        self.maps = self.encoder(images, out=out)
 
     def query(self, points, crop_center=None, body_center=None, **kwargs):
         assert self.maps is not None, "call set_feature_maps() (or filter()) first"
