@@ -178,3 +178,30 @@ def test_non_finite_loss_fails_loudly(synth):
     pose = cu(g["pose"]); pose[1, 10] = float("nan")
     with pytest.raises(FloatingPointError):
         ctx.optimize_smpl(maps, pose, cu(g["betas"]), cu(g["trans"]), cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
+
+
+def test_hoisted_projection_trajectory_matches_direct_path(synth):
+    """The hoisted im_feat projection (FitContext.use_projection) changes only rounding: 20 Adam steps of the SMPL stage end at
+    the same parameters with and without it (1e-4); the object stage on this random-weight field amplifies round-off like it does between
+    two runs of the reference itself, so its 20 steps are held to the bar of the oracle trajectory test above (3e-3 m mean on the object vertices; measured 1.2e-3, one frame
+    drifting 4 mm through Adam's g / sqrt(v) on a near-zero translation gradient)."""
+    from vistracker_amd import ops, synthetic as syn
+    g = golden("smplfit")
+    ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, 600, seed=6)
+    outs = []
+    for use in (True, False):
+        ctx = make_ctx(synth, opts, (ov, of)); ctx.use_projection = use
+        maps = ops.FeatureMaps.from_nchw(syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+        pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+        cc, bc = cu(g["crop_center"]), cu(g["body_center"])
+        r1 = ctx.optimize_smpl(maps, pose, betas, trans, cc, bc, cu(g["body_kpts"]), it_range=(0, 2))
+        assert (maps.proj is not None) == use
+        verts, _, _ = ops.smplh_forward(ctx.smpl, pose, betas, trans)
+        oR = torch.eye(3, device="cuda").repeat(4, 1, 1).contiguous(); ot = (bc + torch.tensor([0.3, 0.0, 0.1], device="cuda")).contiguous()
+        one = torch.ones(4, device="cuda")
+        r2 = ctx.optimize_smpl_object(maps, verts.detach().contiguous(), oR, ot, one, cc, bc, one, it_range=(0, 2), seed=3)
+        X = ops.rigid_transform(cu(ov), ops.so3_project(oR), ot, one)
+        outs.append((pose.cpu().numpy(), trans.cpu().numpy(), X.cpu().numpy(), r1.losses[:20], r2.losses[:20]))
+    a, b = outs
+    assert np.abs(a[0] - b[0]).max() < 1e-4 and np.abs(a[1] - b[1]).max() < 1e-4 and rel(a[3], b[3]) < 1e-5
+    assert np.linalg.norm(a[2] - b[2], axis=-1).mean() < 3e-3 and rel(a[4][:3], b[4][:3]) < 1e-5

@@ -56,7 +56,7 @@ def test_demo_pipeline_end_to_end(synth):
     seq = {"mocap_poses": sp["pose"][:, :72] + 0.05 * rng.normal(size=(T, 72)), "trans_init": sp["trans"] + 0.05 * rng.normal(size=(T, 3)), "kpts": kp, "kpts_crop": kp_crop,
            "images5": images5, "crop_center": crop_center, "frames": [f"t{i:04d}.000" for i in range(T)], "gender": "male"}
     out = pipe.run(seq)
-    print("stage seconds:", {k: round(v, 2) for k, v in pipe.log["seconds"].items()}, pipe.log.get("fit_steps"), {k: round(v, 2) for k, v in pipe.fitter.last["seconds"].items()})
+    print("stage seconds:", {k: round(v, 2) for k, v in pipe.log["seconds"].items()}, pipe.log.get("fit_steps"))
 
     assert set(out) == {"smplt", "smplt_smoothed_fit", "neural", "obj_smooth", "hvop", "hvop_applied", "recon"}
     st, sf, rc = out["smplt"], out["smplt_smoothed_fit"], out["recon"]

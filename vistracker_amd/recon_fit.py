@@ -75,6 +75,7 @@ class ReconFitterTriVisFull(ReconFitterBase):
         self.scan = (np.asarray(verts, np.float32), np.asarray(faces))
         self.ctx = FitContext(smpl_model, regressors, priors, decoders, part_labels, self.scan[0], self.scan[1], obj_points, device=device)
         self.last = {}          # FitResult of the last optimize_* call (loss history, step counts, early-stop flag)
+        self.profile = False    # True: fit_recon_batch records synchronised wall-clock per part in self.last["seconds"]
 
     # ---- schedules / weights (Appendix A.2 of SURVEY.md) ---------------------------------------------------
     def get_loss_weights(self):
@@ -180,7 +181,8 @@ class ReconFitterTriVisFull(ReconFitterBase):
         sec = self.last.setdefault("seconds", {}); t_last = [time.perf_counter()]
 
         def lap(name):
-            torch.cuda.synchronize(); now = time.perf_counter(); sec[name] = sec.get(name, 0.0) + now - t_last[0]; t_last[0] = now
+            if self.profile:          # wall-clock per part needs a device synchronisation: only when asked for (pipeline bench)
+                torch.cuda.synchronize(); now = time.perf_counter(); sec[name] = sec.get(name, 0.0) + now - t_last[0]; t_last[0] = now
         # in-memory extras: ``maps`` = resident feature maps of this batch (skips both encoder passes), ``pc_generated`` = neural predictions
         # of an earlier pass over the same frames (skips the second surface-point generation the reference does in its separate process)
         pc = pc_generated if pc_generated is not None else self.generate_all(args, data, generator, maps=maps)
