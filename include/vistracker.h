@@ -147,8 +147,11 @@ int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps, int B, fl
  *  object: loss += w_obj * mean_B( mean_N clamp(df[:,1], max=.8) * occ[b] )   (recon_fit_trivis_full.py:155-162)
  * dpts (B,N,3) is overwritten with the weighted gradient; terms[0..1] (device fp64) receive the UNWEIGHTED term
  * values (df_h, part) or (object, -) accumulated with atomics -- zero them before the call. */
+/* order (N) int32 or NULL: a permutation of the point indices -- workgroup slot n processes point order[n] (inputs read, labels looked
+ * up and dpts written at the ORIGINAL index, so results do not depend on it); a locality-preserving order (e.g. the Morton order of the
+ * template vertices) makes the 64 points of a workgroup gather from neighbouring texels. */
 int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
-                        const float *body_center, int B, int N, const int *labels, float w_dfh, float w_part,
+                        const float *body_center, int B, int N, const int *labels, const int *order, float w_dfh, float w_part,
                         float *dpts, double *terms, void *stream);
 int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center,
                          const float *body_center, int B, int N, const float *occ, float w_obj,

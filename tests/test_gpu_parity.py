@@ -186,11 +186,14 @@ def test_query_fused_objectives_vs_oracle(hip, synth, proj):
             assert np.abs(P[..., col:col + 128] - ref).max() < 2e-6 * np.abs(ref).max(), head
     terms = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, N, 3, device="cuda")
     pts_t, cc_t, bc_t, lab_t, occ_t = cu(pts), cu(cc), cu(bc), cu(labels), cu(occ)
-    L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,
-                                        L.dptr(lab_t), w_dfh, w_part, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
-    t = npy(terms)
-    assert abs(t[0] - t_dfh) < 1e-5 * abs(t_dfh) + 1e-7 and abs(t[1] - t_part) < 1e-4 * abs(t_part)
-    assert rel(npy(dp), dpts_h) < 3e-4
+    order = cu(rng.permutation(N).astype(np.int32))         # any processing order of the points gives the same result at the original indices
+    for od in (None, order):
+        terms.zero_(); dp.fill_(float("nan"))
+        L.check(L.lib().vt_query_human_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,
+                                            L.dptr(lab_t), L.dptr(od), w_dfh, w_part, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
+        t = npy(terms)
+        assert abs(t[0] - t_dfh) < 1e-5 * abs(t_dfh) + 1e-7 and abs(t[1] - t_part) < 1e-4 * abs(t_part)
+        assert rel(npy(dp), dpts_h) < 3e-4
     terms.zero_()
     L.check(L.lib().vt_query_object_loss(hip["net"].h, C.byref(maps.c), L.dptr(pts_t), L.dptr(cc_t), L.dptr(bc_t), B, N,
                                          L.dptr(occ_t), w_obj, L.dptr(dp), L.dptr(terms), L.stream_ptr()))
@@ -422,7 +425,7 @@ def test_full_size_properties(hip, synth):
     outs = []
     for _ in range(3):
         dp = torch.empty(B, N, 3, device="cuda"); terms = torch.zeros(2, dtype=torch.float64, device="cuda")
-        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), L.dptr(pts), L.dptr(cc), L.dptr(bc), B, N, L.dptr(labels), 100.0, 0.0025,
+        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), L.dptr(pts), L.dptr(cc), L.dptr(bc), B, N, L.dptr(labels), None, 100.0, 0.0025,
                                             L.dptr(dp), L.dptr(terms), L.stream_ptr()))
         outs.append((dp, terms.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])          # gradients: bit identical

@@ -23,7 +23,7 @@ labels = torch.randint(0, 14, (N,), device=dev, dtype=torch.int32); occ = torch.
 dp = torch.empty(B, N, 3, device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
 def run():
     if mode == "human":
-        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, labels.data_ptr(), 100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, labels.data_ptr(), None, 100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
     else:
         L.check(L.lib().vt_query_object_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, occ.data_ptr(), 900.0, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
 run(); torch.cuda.synchronize()

@@ -38,7 +38,7 @@ for mode, n in (("human", N), ("object", 3000)):
     dp = torch.empty(B, n, 3, device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
     def run():
         if mode == "human":
-            L.check(lib.vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, n, labels.data_ptr(), 100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+            L.check(lib.vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, n, labels.data_ptr(), None, 100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
         else:
             L.check(lib.vt_query_object_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, n, occ.data_ptr(), 900.0, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
     run(); torch.cuda.synchronize(); lib.vt_phase_clk(None, 1)

@@ -79,6 +79,7 @@ struct QArgs {
     float *dpts;
     // fused objectives
     const int *labels; const float *occ; float w0, w1; double *terms;
+    const int *order;       // optional processing order of the points: workgroup slot n handles point order[n] (NULL = identity)
     // surface projection step (MODE_PROJECT): w0 = clamp threshold
     int df_idx; float *pts_out, *dft_out;
 };
@@ -363,12 +364,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
     if (tid < 64) {
         const int n = min(n0 + tid, a.N - 1);
-        const float *p = a.pts + ((size_t)b * a.N + n) * 3;
+        const int pn = a.order ? a.order[n] : n;        // a locality-preserving order (FitContext: Morton order of the template) keeps the gathers of a tile in few texels
+        const float *p = a.pts + ((size_t)b * a.N + pn) * 3;
         const float x = p[0], y = p[1], z = p[2];
         float px = a.fx * x / z + a.cx, py = a.fy * y / z + a.cy;
         px = a.crop / 2 + px - a.crop_center[2 * b]; py = a.crop / 2 + py - a.crop_center[2 * b + 1];
         const float nx = 2 * px / a.crop - 1, ny = 2 * py / a.crop - 1;
-        sIn[tid] = (nx >= -1.0f) && (nx <= 1.0f) && (ny >= -1.0f) && (ny <= 1.0f);
+        sIn[tid] = (pn << 1) | (int)((nx >= -1.0f) && (nx <= 1.0f) && (ny >= -1.0f) && (ny <= 1.0f));     // point index | in-image flag
         const float c0 = x - a.body_center[3 * b], c1 = y - a.body_center[3 * b + 1], c2 = z - a.body_center[3 * b + 2];
         sPt[tid * 3] = x; sPt[tid * 3 + 1] = y; sPt[tid * 3 + 2] = z;
         sUV[(0 * 64 + tid) * 2] = nx;  sUV[(0 * 64 + tid) * 2 + 1] = ny;   // perspective
@@ -524,15 +526,16 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         for (int r = 0; r < 4; r++) {
             const int pt = wave * 16 + q * 4 + r, n = n0 + pt;
             const bool valid = n < a.N, live = j < hw.kout;
-            const bool inimg = sIn[pt] != 0;
+            const bool inimg = (sIn[pt] & 1) != 0;
+            const int pn = sIn[pt] >> 1;
             float val = o4[r] * hw.cf[3] + bias4;
             go[r] = 0.f;
             if (MODE == MODE_FWD) {
                 if (hw.id == 0 && !inimg) val = OUT_DIST;                       // df[~in_img] = 5.0 (chore_triplane.py:156-159)
                 if (hw.id == 4) val = 1.0f / (1.0f + expf(-val));                // sigmoid on visibility (chore_tri_vis.py:22-27)
-                if (valid && live) a.out[g][((size_t)b * hw.kout + j) * a.N + n] = val;
+                if (valid && live) a.out[g][((size_t)b * hw.kout + j) * a.N + pn] = val;
             } else if (MODE == MODE_BWD) {
-                float gg = (valid && live) ? a.gout[g][((size_t)b * hw.kout + j) * a.N + n] : 0.f;
+                float gg = (valid && live) ? a.gout[g][((size_t)b * hw.kout + j) * a.N + pn] : 0.f;
                 if (hw.id == 0 && !inimg) gg = 0.f;
                 if (hw.id == 4) { const float s = 1.0f / (1.0f + expf(-val)); gg *= s * (1.0f - s); }
                 go[r] = gg;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     float se = e;
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o, 64);
-                    const int lab = a.labels[min(n, a.N - 1)];
+                    const int lab = a.labels[pn];
                     if (valid && live) {
                         go[r] = (e / se - (j == lab ? 1.f : 0.f)) * a.w1 / (float)a.B;
                         if (j == lab) loss_acc[1] += (double)(logf(se) - (val - mx));
@@ -829,14 +832,15 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     if (q == 0) {
         const int n = n0 + mypt;
         if (n < a.N) {
+            const int pn = sIn[mypt] >> 1;
             if (MODE == MODE_PROJECT) {
                 // samples <- samples - normalize(gradient) * target  (F.normalize: g / max(|g|, 1e-12); generator.py:97)
                 const float dft = sDf[mypt], s = dft / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
-                float *o = a.pts_out + ((size_t)b * a.N + n) * 3;
+                float *o = a.pts_out + ((size_t)b * a.N + pn) * 3;
                 o[0] = px_ - gx * s; o[1] = py_ - gy * s; o[2] = sPt[mypt * 3 + 2] - gz * s;
-                if (a.dft_out) a.dft_out[(size_t)b * a.N + n] = dft;
+                if (a.dft_out) a.dft_out[(size_t)b * a.N + pn] = dft;
             } else {
-                float *o = a.dpts + ((size_t)b * a.N + n) * 3;
+                float *o = a.dpts + ((size_t)b * a.N + pn) * 3;
                 o[0] = gx; o[1] = gy; o[2] = gz;
             }
         }
@@ -1099,11 +1103,11 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
 }
 
 extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
-                                   int B, int N, const int *labels, float w_dfh, float w_part, float *dpts, double *terms, void *stream)
+                                   int B, int N, const int *labels, const int *order, float w_dfh, float w_part, float *dpts, double *terms, void *stream)
 {
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(labels && dpts && terms, "vt_query_human_loss: null argument");
-    a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
+    a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
     return launch<2, MODE_HUMAN>(a, vt_stream(stream));
 }
 

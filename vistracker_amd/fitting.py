@@ -130,6 +130,7 @@ class FitContext:
     # hoist the im_feat part of the decoders' first layer out of the Adam loops (ops.FeatureMaps.build_projection)
     use_projection = True
     sort_object_points = True
+    sort_query_points = True
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -143,6 +144,9 @@ class FitContext:
         t = lambda a, dt=torch.float32: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
         self.pri = {k: t(v) for k, v in priors.items()}
         self.labels = t(part_labels, torch.int32)
+        # processing order of the SMPL vertices in the fused SMPL-stage query: Morton order of the template (results are written back at the
+        # original vertex index; the order only decides which 64 vertices share a workgroup, i.e. how local its gathers are)
+        self.vert_order = t(morton_order(np.asarray(smpl_model["v_template"])), torch.int32) if self.sort_query_points else None
         if obj_points is not None and self.sort_object_points:
             # the surface samples are an unordered set (trimesh.sample order, recon_fit_base.py:144) and every term that uses them is a sum
             # over points: put them in Morton order so that the 64 consecutive points of a query workgroup project to neighbouring texels
@@ -270,7 +274,8 @@ class FitContext:
                 self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
                 ev = _ev_begin(prof)
                 _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
-                                                self.labels.data_ptr(), float(w[0]), float(w[1]), dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
+                                                self.labels.data_ptr(), self.vert_order.data_ptr() if self.vert_order is not None else None, float(w[0]), float(w[1]),
+                                                dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
                 _ev_end(prof, "human", ev)
                 if phase == "kpts":
                     _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
