@@ -86,6 +86,23 @@ def test_silhouette_setup_math():
     assert np.allclose(K[0], [979.7844 / 500, 0, (1018.952 - 900) / 500]) and np.allclose(K[1], [0, 979.840 / 500, (779.486 - 600) / 500])
     with pytest.raises(AssertionError):
         compute_K_roi([0, 0, 10, 11])
+    # the batched forms (all frames of a batch at once) == the per-frame ones, incl. boxes larger than the output (2 samples per bin),
+    # boxes hanging over the image border and the uint8 threshold of the bbox
+    from vistracker_amd.silhouette import masks2bbox, roi_align_masks
+    rng = np.random.default_rng(0)
+    masks = torch.zeros(5, 300, 320)
+    for i, (y0, y1, x0, x1) in enumerate([(10, 60, 20, 90), (0, 300, 0, 320), (100, 101, 200, 201), (250, 300, 5, 50), (40, 260, 30, 310)]):
+        masks[i, y0:y1, x0:x1] = torch.rand(y1 - y0, x1 - x0) * 0.4 + 0.6
+    masks[0, 5, 5] = 0.4                                   # below 127 / 255: not part of the box
+    bb = masks2bbox(masks)
+    ref = np.stack([mask2bbox((m.numpy() * 255).astype(np.uint8)) for m in masks])
+    assert np.array_equal(bb, ref)
+    boxes = np.array([[0.0, 0.0, 100.0, 100.0], [-30.5, -20.25, 400.0, 380.0], [150.0, 50.0, 250.5, 151.25], [-10.0, 200.0, 90.0, 310.0], [10.0, 10.0, 300.0, 290.0]])
+    got = roi_align_masks(masks, boxes, 128)
+    for i in range(5):
+        assert torch.allclose(got[i], roi_align_mask(masks[i], boxes[i], 128), atol=1e-6), i
+    with pytest.raises(ValueError):
+        masks2bbox(torch.zeros(2, 8, 8))
 
 
 def test_smplh_model_loader_without_chumpy(tmp_path, synth):

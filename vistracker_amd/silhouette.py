@@ -26,6 +26,20 @@ def mask2bbox(mask: np.ndarray) -> np.ndarray:
     return np.array([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1], dtype=np.float64)
 
 
+def masks2bbox(masks: torch.Tensor) -> np.ndarray:
+    """``mask2bbox`` of a batch (B,H,W) of [0,1] masks without moving them to the host: uint8 threshold (m * 255 truncated > 127) like the
+    reference's loader, tight xyxy box with +1 on the max edge"""
+    fg = (masks.float() * 255).to(torch.uint8) > 127
+    cols, rows = fg.any(1), fg.any(2)                           # (B,W), (B,H)
+    if not bool(cols.any(1).all()):
+        raise ValueError("empty object mask: the reference would produce an invalid bbox here")
+    W, H = cols.shape[1], rows.shape[1]
+    ax = torch.arange(W, device=masks.device); ay = torch.arange(H, device=masks.device)
+    x0 = torch.where(cols, ax, W).min(1)[0]; x1 = torch.where(cols, ax, -1).max(1)[0] + 1
+    y0 = torch.where(rows, ay, H).min(1)[0]; y1 = torch.where(rows, ay, -1).max(1)[0] + 1
+    return torch.stack([x0, y0, x1, y1], 1).double().cpu().numpy()
+
+
 def make_bbox_square(bbox_xywh: np.ndarray, expansion: float) -> np.ndarray:
     """recon/bbox.py:26-48"""
     b = np.asarray(bbox_xywh, np.float64).reshape(-1, 4)
@@ -65,6 +79,47 @@ def roi_align_mask(mask: torch.Tensor, box_xyxy, out: int) -> torch.Tensor:
     return v.reshape(out, gh, out, gw).mean((1, 3)).float()
 
 
+def roi_align_masks(masks: torch.Tensor, boxes_xyxy, out: int) -> torch.Tensor:
+    """``roi_align_mask`` of a batch: masks (B,H,W), one box per mask -> (B,out,out).  Frames are grouped by their sampling grid
+    (ceil(box / out) samples per bin and axis, 1 for boxes up to ``out`` pixels) and each group is sampled with two batched gathers."""
+    B, H, W = masks.shape
+    boxes = np.asarray(boxes_xyxy, np.float64).reshape(B, 4)
+    rw, rh = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    gw = np.maximum(np.ceil(rw / out).astype(np.int64), 1); gh = np.maximum(np.ceil(rh / out).astype(np.int64), 1)
+    dev = masks.device
+    res = torch.empty(B, out, out, device=dev)
+    ar = torch.arange(out, device=dev, dtype=torch.float64)
+
+    def prep(v, n):
+        dead = (v < -1.0) | (v > n)
+        v = v.clamp(min=0)
+        lo = v.floor().long()
+        top = lo >= n - 1
+        lo = torch.where(top, torch.full_like(lo, n - 1), lo)
+        hi = torch.where(top, lo, lo + 1)
+        v = torch.where(top, lo.double(), v)
+        return lo, hi, v - lo.double(), dead
+
+    for g_w, g_h in sorted(set(zip(gw.tolist(), gh.tolist()))):
+        idx = np.flatnonzero((gw == g_w) & (gh == g_h)); n = len(idx)
+        bx = torch.as_tensor(boxes[idx], device=dev)
+        bw, bh = (bx[:, 2] - bx[:, 0]) / out, (bx[:, 3] - bx[:, 1]) / out
+        y = ((ar[None, :, None] * bh[:, None, None]) + (bx[:, 1] - 0.5)[:, None, None]
+             + (torch.arange(g_h, device=dev, dtype=torch.float64)[None, None] + 0.5) * bh[:, None, None] / g_h).reshape(n, -1)
+        x = ((ar[None, :, None] * bw[:, None, None]) + (bx[:, 0] - 0.5)[:, None, None]
+             + (torch.arange(g_w, device=dev, dtype=torch.float64)[None, None] + 0.5) * bw[:, None, None] / g_w).reshape(n, -1)
+        ylo, yhi, ly, dy = prep(y, H); xlo, xhi, lx, dx = prep(x, W)
+        m = masks[torch.as_tensor(idx, device=dev)].double()
+        Y, X = y.shape[1], x.shape[1]
+        rlo = m.gather(1, ylo[:, :, None].expand(n, Y, W)); rhi = m.gather(1, yhi[:, :, None].expand(n, Y, W))
+        pick = lambda r, c: r.gather(2, c[:, None, :].expand(n, Y, X))
+        v = (pick(rlo, xlo) * ((1 - ly)[:, :, None] * (1 - lx)[:, None, :]) + pick(rlo, xhi) * ((1 - ly)[:, :, None] * lx[:, None, :])
+             + pick(rhi, xlo) * (ly[:, :, None] * (1 - lx)[:, None, :]) + pick(rhi, xhi) * (ly[:, :, None] * lx[:, None, :]))
+        v = v * (~dy)[:, :, None] * (~dx)[:, None, :]
+        res[torch.as_tensor(idx, device=dev)] = v.reshape(n, out, g_h, out, g_w).mean((2, 4)).float()
+    return res
+
+
 def compute_K_roi(bbox_square, image_width=2048, fx=979.7844, fy=979.840, cx=1018.952, cy=779.486, **kwargs):
     """obj_pose_roi.py:123-155 -> 3x3 list (normalised ROI intrinsics)"""
     x, y, b, w = bbox_square
@@ -84,7 +139,7 @@ class SilLossROI(nn.Module):
         verts, faces = (temp_mesh.v, temp_mesh.f) if hasattr(temp_mesh, "v") else temp_mesh
         B = person_masks.shape[0]
         pm = torch.as_tensor(person_masks).float(); om = torch.as_tensor(obj_masks).float()
-        boxes = np.stack([mask2bbox((m.cpu().numpy() * 255).astype(np.uint8)) for m in om], 0)          # xyxy
+        boxes = masks2bbox(om)                                                                          # xyxy, all frames at once on the device
         xywh = np.concatenate([boxes[:, :2], boxes[:, 2:] - boxes[:, :2]], 1)
         squares = make_bbox_square(xywh, bbox_expansion)                                                # xywh
         sq_xyxy = np.concatenate([squares[:, :2], squares[:, :2] + squares[:, 2:]], 1)
@@ -92,9 +147,10 @@ class SilLossROI(nn.Module):
         scale = crop_size / net_input_size
         Ks, keeps, refs = [], [], []
         cc = torch.as_tensor(crop_centers).float().cpu().numpy()
+        obj_all = roi_align_masks(om, sq_xyxy, rend_size) >= 0.5
+        ps_all = roi_align_masks(pm, sq_xyxy, rend_size) >= 0.5
         for i in range(B):
-            obj = roi_align_mask(om[i], sq_xyxy[i], rend_size) >= 0.5
-            ps = roi_align_mask(pm[i], sq_xyxy[i], rend_size) >= 0.5
+            obj, ps = obj_all[i], ps_all[i]
             refs.append(obj.float())                      # image_ref = (obj > 0)
             keeps.append((~(ps & ~obj)).float())          # cvt_masks: keep foreground and free background, drop person-only pixels
             bb = squares[i].copy() * scale                # to_original_bbox (obj_pose_roi.py:111-121)
@@ -108,7 +164,13 @@ class SilLossROI(nn.Module):
         self.register_buffer("faces", torch.as_tensor(np.asarray(faces).astype(np.int32)).to(dev))
         self.pool = nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
         self.rend_size = rend_size
-        self.register_buffer("edt_ref_edge", self._dist_trans(self.image_ref))
+        self._edt = None        # distance transform of the reference edges: visualisation only, built on first use (0.23 s of scipy per 96 frames)
+
+    @property
+    def edt_ref_edge(self):
+        if self._edt is None:
+            self._edt = self._dist_trans(self.image_ref)
+        return self._edt
 
     def _dist_trans(self, refs, power=0.25):
         """distance transform of the reference edges (visualisation only; obj_pose_roi.py:96-106)"""
