@@ -29,20 +29,20 @@ def _t(a, device="cuda"):
 
 
 def compute_transform(S1, S2):
-    """similarity transform (R (3,3), t (3,1), scale) taking the source points S1 (N,3) onto S2 (N,3) in the least-squares sense
-    (pose_utils.py:153-198).  fp64 reductions on the device, the 3x3 SVD on the host."""
-    X1, X2 = _t(S1).double(), _t(S2).double()
-    assert X1.shape == X2.shape and X1.shape[1] == 3
-    mu1, mu2 = X1.mean(0, keepdim=True), X2.mean(0, keepdim=True)
-    X1, X2 = X1 - mu1, X2 - mu2
-    var1 = (X1 ** 2).sum().item()
-    K = (X1.T @ X2).cpu().numpy()
-    U, s, Vh = np.linalg.svd(K)
-    V = Vh.T
-    Z = np.eye(3); Z[-1, -1] *= np.sign(np.linalg.det(U.dot(V.T)))
-    R = V.dot(Z.dot(U.T))
-    scale = np.trace(R.dot(K)) / var1
-    t = mu2.cpu().numpy().T - scale * (R.dot(mu1.cpu().numpy().T))
+    """Least-squares similarity transform source -> target (pose_utils.py:153-198): returns (R (3,3), t (3,1), scale) with
+    ``target ~ scale * R @ source + t``.  Centroids, source variance and the 3x3 cross-covariance are fp64 reductions on the device; the
+    orthogonal Procrustes step (SVD of the cross-covariance, reflection removed by flipping the last singular direction) runs on the host."""
+    src, dst = _t(S1).double(), _t(S2).double()
+    assert src.shape == dst.shape and src.shape[1] == 3
+    c_src, c_dst = src.mean(0), dst.mean(0)
+    a, b_ = src - c_src, dst - c_dst
+    cov = (a.T @ b_).cpu().numpy()                      # sum_i a_i b_i^T
+    spread = float((a * a).sum())
+    left, _, right_t = np.linalg.svd(cov)
+    flip = np.ones(3); flip[2] = np.sign(np.linalg.det(left @ right_t))
+    R = right_t.T @ np.diag(flip) @ left.T
+    scale = float(np.sum(R * cov.T)) / spread           # trace(R cov)
+    t = c_dst.cpu().numpy()[:, None] - scale * (R @ c_src.cpu().numpy()[:, None])
     return R, t, scale
 
 
