@@ -38,3 +38,23 @@ def test_no_cpu_fallback():
     from vistracker_amd import _lib
     with pytest.raises(_lib.VtError):
         _lib.dptr(torch.zeros(3))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package (Python or HIP/C sources, Makefile) imports, includes, links or runs it."""
+    import re
+    pkg = os.path.join(ROOT, "vistracker_amd")
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)|libvt_oracle|vt_oracle\.h|/oracle/|\boracle\.(oracle|vt_)", re.M)
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
+                src = open(os.path.join(d, f), errors="ignore").read()
+                if pat.search(src):
+                    bad.append(os.path.relpath(os.path.join(d, f), ROOT))
+    assert not bad, bad
+    # and bench.py uses it only inside cpu_baseline
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle|import oracle", b)]
+    lo = b.index("def cpu_baseline"); hi = b.index("\ndef ", lo + 1)
+    assert uses and all(lo < u < hi for u in uses), uses
