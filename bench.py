@@ -277,6 +277,11 @@ def main():
                          "hoisting_note": "the im_feat part of layer 1 (42 % of its FLOPs, 30 % of the kernel's) is hoisted out of the Adam loop: applied to "
                                           "the texels once per batch (fp32 MFMA GEMM inside the timed region, 0.2 TFLOP / 2.5 ms per batch) and blended per "
                                           "point on the VALU; frac counts algorithmic FLOPs, frac_mfma_executed only what the MFMA pipe still executes",
+                         # the other roof of this kernel, for information: SURVEY.md 8(d) counts 608 ch x 4 taps x 4 B = 9728 B/pt "touched" in each
+                         # direction (an upper bound: neighbouring points share texels, the caches serve them; "traffic" above is what reaches HBM)
+                         "gather": {"algorithmic_bytes_per_launch": 2 * 9728 * BATCH * 6890, "unit": "TB/s", "peak": 8.0,
+                                    "achieved": 2 * 9728 * BATCH * 6890 / max(eff, 1e-12) / 1e12, "frac": 2 * 9728 * BATCH * 6890 / max(eff, 1e-12) / 8e12,
+                                    "note": "bytes the gathers request (touched, not unique) / launch time vs the HBM peak; the L2 / MALL serve ~70 % of them"},
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
         }
