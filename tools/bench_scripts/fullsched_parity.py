@@ -50,3 +50,39 @@ print(f"B = {B}: HIP {res.steps} steps (early stop {res.stopped_early}) in {t_hi
 print(f"loss history rel diff (first {n} steps): {np.abs(np.array(losses[:n]) - res.losses[:n]).max() / np.abs(np.array(losses[:n])).max():.2e}; final loss {losses[-1]:.6f} vs {res.losses[res.steps - 1]:.6f}")
 print(f"final vertices: v2v mean {np.linalg.norm(verts_hip - verts_cpu, axis=-1).mean():.2e} m, max {np.linalg.norm(verts_hip - verts_cpu, axis=-1).max():.2e} m; "
       f"max |dpose| {np.abs(p.cpu().numpy() - pose).max():.2e} rad, max |dtrans| {np.abs(t.cpu().numpy() - trans).max():.2e} m")
+
+# ---- SMPL stage of the joint fit (optimize_smpl, recon_fit_behave.py:393-465) on the golden fixture's inputs, full schedule -------------------
+if len(sys.argv) > 2 and sys.argv[2] == "smplfit":
+    g = np.load('/root/repo/tests/golden/smplfit.npz')
+    dec = syn.sifnet_decoders(3); labels = syn.part_labels(model)
+    mp = syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"]))
+    ctx2 = FitContext(model, regs, pri, dec, labels, np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32), np.zeros((8, 3), np.float32))
+    maps = ops.FeatureMaps.from_nchw(mp)
+    p, b_, t = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+    t0 = time.perf_counter()
+    res = ctx2.optimize_smpl(maps, p, b_, t, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"])); torch.cuda.synchronize(); t_hip = time.perf_counter() - t0
+    verts_hip = ops.smplh_forward(ctx2.smpl, p, b_, t)[0].cpu().numpy()
+    net = O.SifNet(dec, mp)
+    pose, betas, trans = g["pose"].copy(), g["betas"].copy(), g["trans"].copy(); pose_init = pose[:, 3:72].copy()
+    gp, bp, tb, ob = pose[:, :3].copy(), pose[:, 3:66].copy(), betas[:, :2].copy(), betas[:, 2:].copy()
+    kw = dict(crop_center=g["crop_center"], body_center=g["body_center"], body_kpts=g["body_kpts"], pose_init=pose_init)
+    opt = O.Adam([tb, trans], 0.02); prev = 300.0; losses = []; stopped = False
+    t0 = time.perf_counter()
+    for it in range(100):
+        phase = "global" if it == 0 else ("smpl all pose" if it == 1 else "kpts")
+        if it == 1: opt = O.Adam([trans, gp, bp, tb, ob], 0.006)
+        for i in range(10):
+            pose[:, :3] = gp; pose[:, 3:66] = bp; betas[:, :2] = tb; betas[:, 2:] = ob
+            total, _, dpose, dbetas, dtrans = O.smplfit_loss_and_grad(m, b25, pri, net, labels, pose, betas, trans, phase=phase, decay=1 if phase != "kpts" else it / 3, **kw)
+            grads = [dbetas[:, :2].copy(), dtrans] if it == 0 else [dtrans, dpose[:, :3].copy(), dpose[:, 3:66].copy(), dbetas[:, :2].copy(), dbetas[:, 2:].copy()]
+            opt.step(grads); losses.append(total)
+            if abs(prev - total) / prev < prev * 1e-3 and it > 27: stopped = True; break
+            prev = total
+        if stopped: break
+    t_cpu = time.perf_counter() - t0
+    pose[:, :3] = gp; pose[:, 3:66] = bp; betas[:, :2] = tb; betas[:, 2:] = ob
+    verts_cpu, _, _ = m.forward(pose, betas, trans)
+    n = min(len(losses), res.steps)
+    print(f"optimize_smpl, B = 4: HIP {res.steps} steps (early stop {res.stopped_early}) in {t_hip:.2f} s; oracle {len(losses)} steps in {t_cpu:.1f} s")
+    print(f"loss history rel diff (first {n} steps): {np.abs(np.array(losses[:n]) - res.losses[:n]).max() / np.abs(np.array(losses[:n])).max():.2e}")
+    print(f"final vertices: v2v mean {np.linalg.norm(verts_hip - verts_cpu, axis=-1).mean():.2e} m, max {np.linalg.norm(verts_hip - verts_cpu, axis=-1).max():.2e} m")
