@@ -211,6 +211,34 @@ class ReconFitterTriVisFull(ReconFitterBase):
         lap("optimize_smpl_object")
         return pc, smpl, obj_R, obj_t, obj_s
 
+    def fit_recon(self, args, loader=None, generator=None, source=None):
+        """The batch loop of ``fit_recon`` (recon_fit_triplane.py:29-111) over an iterable of batch dicts.  Sequence IO stays with the
+        caller, at the places where the reference does it: ``loader`` yields what ``TestDataTriplane`` yields (images (B,8,H,W),
+        crop_center, body_center, path, ...); ``source`` supplies ``is_done(paths) -> bool``, ``get_smpl_init(paths, human_t) -> smpl``,
+        ``get_body_kpts2d(batch) -> (B,25,3)`` in network-input pixels, optionally ``load_old_obj_recon(paths) -> (B,3,3)`` rotations
+        (``-or <name>``; otherwise the neural PCA axes with ``source.pca_init``) and ``save_outputs(smpl, obj_R, obj_t, paths, obj_s)`` /
+        ``save_neural_recon(paths, pc_generated)``.  Returns the number of batches fitted."""
+        assert loader is not None and generator is not None and source is not None, "fit_recon needs loader=, generator= and source= (sequence IO is the caller's)"
+        done = 0
+        for data in loader:
+            paths = data.get("path")
+            if hasattr(source, "is_done") and source.is_done(paths) and not getattr(args, "redo", False):
+                continue
+            neural_only = bool(getattr(args, "neural_only", False))
+            smpl = kpts = None
+            if not neural_only:
+                smpl = source.get_smpl_init(paths, data["body_center"])
+                kpts = torch.as_tensor(np.asarray(source.get_body_kpts2d(data)), dtype=torch.float32, device=self.device)
+            rots = source.load_old_obj_recon(paths) if (not neural_only and getattr(args, "obj_recon_name", "neural") != "neural") else None
+            pc, smpl, obj_R, obj_t, obj_s = self.fit_recon_batch(args, data, generator, smpl, kpts, obj_rots=rots, pca_init=getattr(source, "pca_init", None),
+                                                               neural_only=neural_only)
+            if hasattr(source, "save_neural_recon"):
+                source.save_neural_recon(paths, pc)
+            if not neural_only:
+                source.save_outputs(smpl, obj_R, obj_t, paths, obj_s)
+            done += 1
+        return done
+
     # ---- the two optimisation loops -------------------------------------------------------------------------
     @staticmethod
     def _maps(model):
