@@ -243,6 +243,7 @@ class FitContext:
         if self.use_projection:
             maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale
         names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
+        vert_order = self.vert_order
         terms = Terms(names, dev)
         verts = torch.empty(B, V, 3, device=dev); jtr = torch.empty(B, 52, 3, device=dev); vposed = torch.empty_like(verts)
         ws = torch.empty(_lib().vt_smplh_workspace_floats(B), device=dev); scratch = torch.empty(_lib().vt_smplh_bwd_scratch_floats(B), device=dev)
@@ -252,6 +253,13 @@ class FitContext:
         pose_init = pose.clone()
         stop = torch.zeros(1, dtype=torch.int32, device=dev)
         state = torch.tensor([300.0, 300.0], device=dev)          # prev_loss = 300 (recon_fit_behave.py:408)
+        if self.sort_query_points:
+            # processing order for this batch: Morton order of the IMAGE positions of the initial vertices of the middle frame (the body moves
+            # little inside a batch and during the fit); a little better than the template's 3-D order because the perspective maps -- the
+            # projection rows and tmpx, two thirds of the gathered bytes -- see exactly this neighbourhood structure.  Results do not depend on it.
+            self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+            v0 = verts[B // 2].cpu().numpy()
+            vert_order = torch.as_tensor(morton_order(np.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2], np.zeros(V)], 1)).astype(np.int32), device=dev)
         self.hand_prior_value(pose, terms, "hand", vb)
         total = iter_for_betas + iter_for_kpts + iter_for_pose + max_iter
         start, end = it_range if it_range is not None else (0, total)
@@ -274,7 +282,7 @@ class FitContext:
                 self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
                 ev = _ev_begin(prof)
                 _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
-                                                self.labels.data_ptr(), self.vert_order.data_ptr() if self.vert_order is not None else None, float(w[0]), float(w[1]),
+                                                self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
                                                 dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
                 _ev_end(prof, "human", ev)
                 if phase == "kpts":
