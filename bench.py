@@ -38,7 +38,7 @@ FLOP_PER_POINT_HUMAN_MFMA = FLOP_PER_POINT_HUMAN - 4 * 2 * 256 * 128
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
-PMC_FILE = os.path.join(ROOT, "profiles", "r01q_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+PMC_FILE = os.path.join(ROOT, "profiles", "r01s_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
 
 
 def pmc_traffic_bytes():
@@ -266,7 +266,7 @@ def main():
                        "sharding": f"{world} ranks x {args.steps} batches, no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01q_pmc_query_human.json)",
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01s_pmc_query_human.json)",
                          "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
                          "avg_launch_ms": 1e3 * float(th.mean()), "effective_ms_per_launch": 1e3 * eff, "streams": args.streams,
                          "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "
