@@ -38,7 +38,7 @@ FLOP_PER_POINT_HUMAN_MFMA = FLOP_PER_POINT_HUMAN - 4 * 2 * 256 * 128
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
-PMC_FILE = os.path.join(ROOT, "profiles", "r01s_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
 
 
 def pmc_traffic_bytes():
@@ -102,14 +102,78 @@ def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0):
                 occ=occ, sil=SilSetup(K, keep, ref, 256))
 
 
-def fit_batch(ctx, torch, d, prof=None):
+def fit_batch(ctx, torch, d, prof=None, early_stop=True):
     """The hot path over one batch: SMPL stage then object stage (recon/recon_fit_triplane.py:70-106)."""
     from vistracker_amd import ops
-    r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof)
+    r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof, early_stop=early_stop)
     with torch.no_grad():
         verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
-    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof)
+    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof,
+                                  early_stop=early_stop)
     return r1, r2
+
+
+def solo_kernel_leg(ctx, torch, d, launches=20):
+    """The dominant kernel ALONE on the chip: `launches` back-to-back launches of vt_query_human_loss on one stream (what a single-stream
+    rocprofv3 kernel trace shows as its average duration), timed with HIP events on the launch stream, outside the timed region."""
+    import ctypes as C
+    from vistracker_amd import _lib as L, ops
+    from vistracker_amd.fitting import morton_order_device
+    B = d["pose"].shape[0]; V = 6890
+    with torch.no_grad():
+        verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
+    verts = verts.contiguous(); v0 = verts[B // 2]
+    order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
+    d["maps"].build_projection(ctx.net)
+    terms = torch.zeros(2, dtype=torch.float64, device=verts.device); dv = torch.empty_like(verts)
+    call = lambda: L.check(L.lib().vt_query_human_loss(ctx.net.h, C.byref(d["maps"].c), verts.data_ptr(), d["cc"].data_ptr(), d["bc"].data_ptr(), B, V,
+                                                       ctx.labels.data_ptr(), order.data_ptr(), 50.0, 0.00125, dv.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+    for _ in range(3):
+        call()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    ev[0].record()
+    for i in range(launches):
+        call(); ev[i + 1].record()
+    torch.cuda.synchronize()
+    return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
+
+
+def sifnet_inference_leg(torch, syn):
+    """BASELINE.json configs[3]: SIF-Net (tri-vis-l2) inference, batch 16: the four HGFilter encoders on 512^2 crops + one 5-head query of 50 000
+    samples per frame (+ the 10-step surface projection of the generator); synthetic weights / images."""
+    from vistracker_amd import demo_inputs
+    from vistracker_amd.generator import GeneratorTriplaneVis
+    B, N = 16, 50000
+    net = demo_inputs.sifnet()
+    images = torch.rand(B, 8, 512, 512, device="cuda")
+    bc = torch.tensor([[0, 0, 2.2]] * B, device="cuda"); cc = torch.tensor([[1018.952, 779.486]] * B, device="cuda")
+    gen = GeneratorTriplaneVis(net, "x", seed=1)
+    pts = gen.get_grid_samples(N, B, bc)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+    t_enc = timed(lambda: net.filter(images))
+    t_q = timed(lambda: net.query(pts, crop_center=cc, body_center=bc))
+    t_proj = timed(lambda: gen.approx_surface(net, pts, 10, {"crop_center": cc, "body_center": bc}, "object"))
+    return {"workload": "SIF-Net inference, batch 16 x 512^2, 50 000 samples/frame (BASELINE configs[3])", "frames_per_s": B / (t_enc + t_q),
+            "encoder_ms": 1e3 * t_enc, "query_5_heads_ms": 1e3 * t_q, "query_Mpoints_per_s": B * N / t_q / 1e6, "surface_projection_10_steps_ms": 1e3 * t_proj,
+            "encoder_tflops": 0.613 * B / t_enc}
+
+
+def pipeline_leg(torch, T=1500):
+    """BASELINE.json configs[4] on ONE GPU: the whole scripts/demo.sh chain (steps 1-6) on a synthetic T-frame sequence held in memory."""
+    from vistracker_amd import demo_inputs
+    pipe, assets = demo_inputs.pipeline()
+    seq = demo_inputs.sequence(T, assets)
+    pipe.run({k: (v[:96] if k != "gender" else v) for k, v in seq.items()}); pipe.log.clear()      # warm-up: MIOpen kernel selection, allocator
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pipe.run(seq)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return {"workload": f"scripts/demo.sh steps 1-6 in memory, {T} synthetic frames, one GPU (BASELINE configs[4])", "frames_per_s": T / dt, "seconds": dt,
+            "stage_seconds": {k: round(float(v), 2) for k, v in pipe.log["seconds"].items()}}
 
 
 def cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps, budget_s=20.0):
@@ -159,6 +223,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational legs after the timed region (kernel alone, full schedule, "
+                                                              "SIF-Net inference = configs[3], demo pipeline = configs[4])")
+    ap.add_argument("--pipeline-frames", type=int, default=1500)
     args = ap.parse_args()
 
     import torch
@@ -235,6 +302,29 @@ def main():
     if world > 1:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # informational legs, all OUTSIDE the timed region; a failing leg is reported, never fatal for the headline line
+        def leg(name, fn):
+            try:
+                extras[name] = fn()
+            except Exception as e:          # noqa: BLE001
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+        leg("solo_launch_s", lambda: solo_kernel_leg(ctx, torch, batches[0]))
+
+        def full_schedule():
+            d = run(900); torch.cuda.synchronize(); t1 = time.perf_counter()
+            r1, r2 = fit_batch(ctx, torch, d, early_stop=False); torch.cuda.synchronize(); dt = time.perf_counter() - t1
+            return {"workload": "one 96-frame batch, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
+                                "steps, of which 1100 in phase 'joint' with the contact Chamfer term), one batch in flight",
+                    "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds": dt, "frames_per_s": BATCH / dt,
+                    "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
+        leg("full_schedule", full_schedule)
+        del batches[1:]
+        torch.cuda.empty_cache()
+        leg("sifnet_inference", lambda: sifnet_inference_leg(torch, syn))
+        torch.cuda.empty_cache()
+        leg("demo_pipeline", lambda: pipeline_leg(torch, args.pipeline_frames))
     if rank == 0:
         frames = world * args.steps * BATCH
         smpl_steps = float(np.mean([r[0].steps for r in results])); obj_steps = float(np.mean([r[1].steps for r in results]))
@@ -254,6 +344,7 @@ def main():
         busy += (cur_e - cur_s) if cur_e is not None else 0.0
         eff = busy / max(len(iv), 1)                       # effective time per launch
         ach = flops_h / eff / 1e12 if eff > 0 else 0.0
+        solo = extras.get("solo_launch_s") if isinstance(extras.get("solo_launch_s"), float) else None
         line = {
             "metric": "frames/sec joint SMPL+object fit", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -263,12 +354,18 @@ def main():
                                    f"(res_scale={args.res_scale})",
                        "batch_frames": BATCH, "adam_steps_smpl_stage": smpl_steps, "adam_steps_object_stage": obj_steps,
                        "early_stop": "reference rule, evaluated on device",
+                       # the stop rules make the step count data dependent: the steps-normalised rate lets runs with different counts be compared
+                       "frame_steps_per_s": frames * (smpl_steps + obj_steps) / elapsed,
                        "sharding": f"{world} ranks x {args.steps} batches, no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01s_pmc_query_human.json)",
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_query_human.json)",
                          "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
                          "avg_launch_ms": 1e3 * float(th.mean()), "effective_ms_per_launch": 1e3 * eff, "streams": args.streams,
+                         # the kernel alone on the chip (20 back-to-back launches on one stream after the timed region): the number a single-stream
+                         # rocprofv3 kernel trace reports (profiles/r02_kernel_stats_1stream.csv)
+                         "solo_launch_ms": None if solo is None else 1e3 * solo,
+                         "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
                          "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "
                                           "per-launch HIP events); equals flop_per_launch / avg_launch_ms when --streams 1",
                          "launches": int(len(th)), "flop_per_launch": flops_h,
@@ -285,6 +382,9 @@ def main():
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
         }
+        for k in ("full_schedule", "sifnet_inference", "demo_pipeline"):
+            if k in extras:
+                line[k] = extras[k]
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps)
         print(json.dumps(line))

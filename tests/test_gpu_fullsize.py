@@ -1,0 +1,131 @@
+"""GPU (-m gpu): oracle parity of the fused query kernels AT THE BENCH CONFIGURATION -- B = 96 (XCD-aware block map, taken when B % 8 == 0)
+and B = 95 (plain map), V = 6890 SMPL vertices / N = 3000 object points, full-resolution feature maps (256 x 128^2, 64 x 256^2, ...: the
+32-bit texel offsets of the real sizes), the per-batch 2-D Morton processing order and the hoisted im_feat projection all on -- exactly what
+``bench.py`` launches 290 + 160 times per batch.
+
+The oracle (oracle/vt_oracle.c, test infrastructure) evaluates a SUBSET of the frames that covers both sides of the 8-frame XCD groups
+(frames 0, 1, 7, 8, 9, the middle, the last two): per-frame outputs, coordinate gradients and the per-frame parts of the loss terms are
+compared there; the batch-wide terms are additionally tied to those per-frame values through the unfused forward kernel on ALL frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+W_DFH, W_PART, W_OBJ = 100.0, 0.0025, 900.0
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def grad_close(a, b, tol=3e-4, frac=2e-3):
+    """Coordinate gradients of MANY points: they are piecewise constant in the inputs (ReLU units, bilinear cells, the clamp): a unit whose
+    pre-activation is within round-off of zero may be on in one implementation and off in the other, which changes that point's gradient by a
+    finite amount.  With 5e4 points x 768 units per point a handful of such points is expected (the 150-point tests see none), so the bar is:
+    all but a fraction ``frac`` of the points within ``tol`` of the gradient scale, and no point off by more than the scale itself."""
+    a = np.asarray(a, np.float64).reshape(-1, 3); b = np.asarray(b, np.float64).reshape(-1, 3)
+    err = np.abs(a - b).max(-1) / (np.abs(b).max() + 1e-30)
+    bad = float((err > tol).mean())
+    assert bad <= frac and err.max() < 1.0, (bad, float(np.quantile(err, 0.999)), float(err.max()))
+
+
+def _device_maps(B, seed):
+    """smooth random fields of the true shapes, channel-last, generated on the device (6.8 GB at B = 96)"""
+    import torch.nn.functional as F
+    from vistracker_amd import ops, synthetic as syn
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    maps = {}
+    for name, c, res, _ in syn.MAP_SPECS:
+        lo = torch.randn(B, c, res // 8, res // 8, device="cuda", generator=g)
+        maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    return ops.FeatureMaps(maps)
+
+
+def _host_maps(fm, frames):
+    """the frames of ``fm`` the oracle looks at, NCHW numpy"""
+    from vistracker_amd import ops
+    idx = torch.as_tensor(frames, device="cuda")
+    return {k: t.index_select(0, idx).permute(0, 3, 1, 2).contiguous().cpu().numpy() for k, t in zip(ops.MAP_ORDER, fm.t)}
+
+
+@pytest.mark.parametrize("B", [96, 95])
+def test_fused_query_kernels_vs_oracle_at_bench_size(synth, B):
+    from oracle import oracle as O
+    from vistracker_amd import _lib as L, ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext, morton_order_device
+    V, N = 6890, 3000
+    ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, N, seed=6)
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], ov, of, opts)
+    seq = syn.sequence_params(B, seed=11)
+    cu = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    rng = np.random.default_rng(B)
+    pose, betas, trans = cu(seq["pose"]), cu(seq["betas"]), cu(seq["trans"])
+    cc_np = (np.tile([[1018.952, 779.486]], (B, 1)) + rng.normal(0, 20, (B, 2))).astype(np.float32)
+    bc_np = seq["trans"].astype(np.float32)
+    cc, bc = cu(cc_np), cu(bc_np)
+    occ_np = seq["occ_ratios"].astype(np.float32); occ = cu(occ_np)
+    verts, _, _ = ops.smplh_forward(ctx.smpl, pose, betas, trans)
+    verts = verts.contiguous()
+    # a few vertices of frame 0 outside the image: df = 5 there, no gradient (chore_triplane.py:156-159)
+    verts[0, :5, 0] += 3.0
+    X = ops.rigid_transform(ctx.obj_points, ops.so3_project(cu(seq["obj_R"])), cu(seq["obj_t"]), torch.ones(B, device="cuda")).contiguous()
+    fm = _device_maps(B, seed=5)
+    fm.build_projection(ctx.net)
+    v0 = verts[B // 2]
+    order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))       # what FitContext.optimize_smpl passes
+    labels = ctx.labels
+
+    # ---- HIP: the two fused launches of the bench + the unfused forward on all frames
+    t_h = torch.zeros(2, dtype=torch.float64, device="cuda"); dp_h = torch.full((B, V, 3), float("nan"), device="cuda")
+    L.check(L.lib().vt_query_human_loss(ctx.net.h, C.byref(fm.c), L.dptr(verts), L.dptr(cc), L.dptr(bc), B, V, L.dptr(labels), L.dptr(order),
+                                        W_DFH, W_PART, L.dptr(dp_h), L.dptr(t_h), L.stream_ptr()))
+    t_o = torch.zeros(1, dtype=torch.float64, device="cuda"); dp_o = torch.full((B, N, 3), float("nan"), device="cuda")
+    L.check(L.lib().vt_query_object_loss(ctx.net.h, C.byref(fm.c), L.dptr(X), L.dptr(cc), L.dptr(bc), B, N, L.dptr(occ), W_OBJ,
+                                         L.dptr(dp_o), L.dptr(t_o), L.stream_ptr()))
+    with torch.no_grad():
+        df_all, _, parts_all, _, _ = ops.sifnet_query(ctx.net, fm, verts, cc, bc, head_mask=0b00101)
+        dfo_all = ops.sifnet_query(ctx.net, fm, X, cc, bc, head_mask=0b00001)[0]
+    assert torch.isfinite(dp_h).all() and torch.isfinite(dp_o).all()
+    dp_h, dp_o = dp_h.cpu().numpy(), dp_o.cpu().numpy()
+    df_all, parts_all, dfo_all = df_all.cpu().numpy(), parts_all.cpu().numpy(), dfo_all.cpu().numpy()
+
+    # ---- oracle on the frame subset
+    frames = sorted({0, 1, 7, 8, 9, B // 2, B - 2, B - 1})
+    net_o = O.SifNet(synth["decoders"], _host_maps(fm, frames))
+    vs = verts[frames].cpu().numpy(); Xs = X[frames].cpu().numpy(); ccs, bcs, occs = cc_np[frames], bc_np[frames], occ_np[frames]
+    lab = np.broadcast_to(np.asarray(synth["labels"]).reshape(1, -1), (len(frames), V))
+    df, _, parts, _, _ = net_o.query(vs, ccs, bcs, head_mask=0b00101)
+    # (i) forward outputs of the unfused kernel at full size
+    assert np.abs(df_all[frames] - df).max() < 5e-6 * max(1.0, np.abs(df).max())
+    assert np.abs(parts_all[frames] - parts).max() < 5e-6 * max(1.0, np.abs(parts).max())
+    assert (df_all[0, 0, :5] == 5.0).all()
+    # (ii) coordinate gradient of the SMPL-stage objective, normalised by the FULL batch like the kernel (w / (B V), w / B)
+    dfh = df[:, 0].astype(np.float64)
+    d_df = np.zeros_like(df); d_df[:, 0] = (dfh <= 0.1) * (W_DFH / (B * V))
+    lg = parts.astype(np.float64); lg -= lg.max(1, keepdims=True); logp = lg - np.log(np.exp(lg).sum(1, keepdims=True))
+    ce = -np.take_along_axis(logp, lab[:, None], 1)[:, 0]
+    sm = np.exp(logp); np.put_along_axis(sm, lab[:, None], np.take_along_axis(sm, lab[:, None], 1) - 1, 1)
+    g_h = net_o.query_bwd(vs, ccs, bcs, d_df=d_df.astype(np.float32), d_parts=(sm * W_PART / B).astype(np.float32))
+    grad_close(dp_h[frames], g_h)
+    # (iii) batch-wide terms: oracle per-frame parts == unfused HIP per-frame parts on the subset, and the fused terms == the unfused
+    #       forward reduced over ALL frames in float64
+    pf_dfh = np.minimum(df_all[:, 0].astype(np.float64), 0.1).mean(-1)                       # (B,)
+    lga = parts_all.astype(np.float64); lga -= lga.max(1, keepdims=True); lpa = lga - np.log(np.exp(lga).sum(1, keepdims=True))
+    laba = np.broadcast_to(np.asarray(synth["labels"]).reshape(1, -1), (B, V))
+    pf_part = (-np.take_along_axis(lpa, laba[:, None], 1)[:, 0]).sum(-1)                     # (B,)
+    assert rel(pf_dfh[frames], np.minimum(dfh, 0.1).mean(-1)) < 1e-5 and rel(pf_part[frames], ce.sum(-1)) < 1e-4
+    th = t_h.cpu().numpy()
+    assert abs(th[0] - pf_dfh.mean()) < 1e-6 * abs(pf_dfh.mean()) + 1e-9 and abs(th[1] - pf_part.mean()) < 1e-5 * abs(pf_part.mean())
+    # (iv) object-stage objective
+    dfo = net_o.query(Xs, ccs, bcs, head_mask=1)[0]
+    d1 = dfo[:, 1].astype(np.float64)
+    d_df2 = np.zeros_like(dfo); d_df2[:, 1] = (d1 <= 0.8) * (occs[:, None] * W_OBJ / (N * B))
+    g_o = net_o.query_bwd(Xs, ccs, bcs, d_df=d_df2.astype(np.float32))
+    assert np.abs(dfo_all[frames] - dfo).max() < 5e-6 * max(1.0, np.abs(dfo).max())
+    grad_close(dp_o[frames], g_o)
+    pf_obj = np.minimum(dfo_all[:, 1].astype(np.float64), 0.8).mean(-1) * occ_np
+    assert abs(t_o.cpu().numpy()[0] - pf_obj.mean()) < 1e-6 * abs(pf_obj.mean()) + 1e-9

@@ -101,8 +101,19 @@ def test_silhouette_setup_math():
     got = roi_align_masks(masks, boxes, 128)
     for i in range(5):
         assert torch.allclose(got[i], roi_align_mask(masks[i], boxes[i], 128), atol=1e-6), i
-    with pytest.raises(ValueError):
-        masks2bbox(torch.zeros(2, 8, 8))
+    # an empty object mask (fully occluded frame) must not abort the batch: the reference's mask2bbox returns its initial values
+    # (recon/opt_utils.py:148-153), the square box gets a negative side, ROIAlign takes no samples -> zero crops of both masks
+    from vistracker_amd.silhouette import EMPTY_BBOX, SilLossROI
+    mixed = torch.zeros(3, 64, 64); mixed[0, 10:30, 20:50] = 1; mixed[2, 5:9, 5:9] = 1
+    bb = masks2bbox(mixed)
+    assert bb[1].tolist() == list(EMPTY_BBOX) == mask2bbox(np.zeros((8, 8), np.uint8)).tolist() and bb[0].tolist() == [20, 10, 50, 30]
+    person = torch.zeros(3, 64, 64); person[:, 20:40, 20:40] = 1
+    verts = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0]], np.float32); faces = np.array([[0, 1, 2]], np.int32)
+    sil = SilLossROI(person, mixed, (verts, faces), torch.tensor([[1000.0, 800.0]] * 3), rend_size=32, device="cpu", net_input_size=64, crop_size=150)
+    assert sil.image_ref[1].abs().max() == 0 and (sil.keep_mask[1] == 1).all()          # no object, no person-only pixel in the (empty) crop
+    assert sil.image_ref[0].sum() > 0 and torch.isfinite(sil.K).all()
+    sq = make_bbox_square(np.array([[50000.0, 50000.0, -50100.0, -50100.0]]), 0.3)[0]
+    assert sq[2] < 0 and roi_align_mask(mixed[1], [sq[0], sq[1], sq[0] + sq[2], sq[1] + sq[3]], 32).abs().max() == 0
 
 
 def test_smplh_model_loader_without_chumpy(tmp_path, synth):

@@ -124,4 +124,11 @@ def dptr(t):
         raise VtError("libvistracker_hip ops need CUDA (HIP) tensors; there is no CPU fallback in the product path")
     if not t.is_contiguous():
         raise VtError("libvistracker_hip ops need contiguous tensors")
+    import torch
+    if t.device.index != torch.cuda.current_device():
+        # stream_ptr() is the current stream of the CURRENT device and HIP launches go to the current device: a tensor that lives
+        # elsewhere would be addressed from the wrong GPU.  Callers wrap multi-device use in ``torch.cuda.device(tensor.device)``
+        # (FitContext's entry points and the handle constructors do).
+        raise VtError(f"tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
+                      "wrap the call in `with torch.cuda.device(tensor.device):`")
     return t.data_ptr()

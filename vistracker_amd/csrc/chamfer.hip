@@ -7,8 +7,11 @@
 
 #define CH_CHUNK 1024
 
-template <bool XSIDE>
-__device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na, const float *__restrict__ bpts, int nb, float *sB,
+// Gradients are accumulated WITHOUT atomics so that the 'joint' phase is run-to-run reproducible: the near side's gradient ga[i] is owned
+// by the thread of point i; the far side's gb[j] collects the contributions of all points i whose nearest neighbour is j -- after each
+// block of 256 points the (nn index, gradient) records go through LDS and thread j adds the records that name j in record order (fixed
+// summation order, thread j is the only writer of gb[j]).  Costs one compare per (i, j) pair on top of the distance pass.
+__device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na, const float *__restrict__ bpts, int nb, float *sB, int *sNN, float *sG,
                                             float gs, float *ga, float *gb, double &acc)
 {
     // for every point of a: nearest point of b
@@ -28,12 +31,23 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
                 if (dd < best) { best = dd; bj = c0 + j; }
             }
         }
-        if (i < na && bj >= 0) {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        const bool live = i < na && bj >= 0;
+        if (live) {
             acc += (double)best / (double)na;
-            if (ga || gb) {
-                const float g0 = 2.f * (ax - bpts[3 * bj]) * gs / na, g1 = 2.f * (ay - bpts[3 * bj + 1]) * gs / na, g2 = 2.f * (az - bpts[3 * bj + 2]) * gs / na;
-                if (ga) { atomicAdd(ga + 3 * i, g0); atomicAdd(ga + 3 * i + 1, g1); atomicAdd(ga + 3 * i + 2, g2); }
-                if (gb) { atomicAdd(gb + 3 * bj, -g0); atomicAdd(gb + 3 * bj + 1, -g1); atomicAdd(gb + 3 * bj + 2, -g2); }
+            if (ga || gb) { g0 = 2.f * (ax - bpts[3 * bj]) * gs / na; g1 = 2.f * (ay - bpts[3 * bj + 1]) * gs / na; g2 = 2.f * (az - bpts[3 * bj + 2]) * gs / na; }
+            if (ga) { ga[3 * i] += g0; ga[3 * i + 1] += g1; ga[3 * i + 2] += g2; }
+        }
+        if (gb) {
+            __syncthreads();
+            sNN[threadIdx.x] = live ? bj : -1; sG[3 * threadIdx.x] = g0; sG[3 * threadIdx.x + 1] = g1; sG[3 * threadIdx.x + 2] = g2;
+            __syncthreads();
+            const int nrec = min(256, na - i0);
+            for (int j = threadIdx.x; j < nb; j += 256) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f; bool any = false;
+                for (int t = 0; t < nrec; t++)
+                    if (sNN[t] == j) { s0 += sG[3 * t]; s1 += sG[3 * t + 1]; s2 += sG[3 * t + 2]; any = true; }
+                if (any) { gb[3 * j] -= s0; gb[3 * j + 1] -= s1; gb[3 * j + 2] -= s2; }
             }
         }
     }
@@ -43,13 +57,17 @@ __global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ 
                                                       const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy)
 {
     __shared__ float sB[CH_CHUNK * 3];
+    __shared__ int sNN[256];
+    __shared__ float sG[256 * 3];
     __shared__ double red[4];
     const int p = blockIdx.x;
     const int ox = offx[p], nx = offx[p + 1] - ox, oy = offy[p], ny = offy[p + 1] - oy;
     double acc = 0;
     if (nx > 0 && ny > 0) {
-        chamfer_dir<true>(x + 3 * (size_t)ox, nx, y + 3 * (size_t)oy, ny, sB, gs, dx ? dx + 3 * (size_t)ox : nullptr, dy ? dy + 3 * (size_t)oy : nullptr, acc);
-        chamfer_dir<false>(y + 3 * (size_t)oy, ny, x + 3 * (size_t)ox, nx, sB, gs, dy ? dy + 3 * (size_t)oy : nullptr, dx ? dx + 3 * (size_t)ox : nullptr, acc);
+        float *gx = dx ? dx + 3 * (size_t)ox : nullptr, *gy = dy ? dy + 3 * (size_t)oy : nullptr;
+        chamfer_dir(x + 3 * (size_t)ox, nx, y + 3 * (size_t)oy, ny, sB, sNN, sG, gs, gx, gy, acc);
+        __syncthreads();        // the second direction adds to the same gradient rows from other threads
+        chamfer_dir(y + 3 * (size_t)oy, ny, x + 3 * (size_t)ox, nx, sB, sNN, sG, gs, gy, gx, acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     __syncthreads();

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <atomic>
 #include "../../include/vistracker.h"
 
 extern thread_local char vt_err_buf[512];
@@ -34,6 +35,27 @@ extern thread_local char vt_err_buf[512];
     } while (0)
 
 static inline hipStream_t vt_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Raise a kernel's dynamic-LDS limit once per (kernel, device).  The flag is a per-call-site bit mask indexed by the device ordinal:
+// thread-safe (bench.py drives two host threads), and a second GPU in the same process gets its own call (the attribute is per device).
+// Two threads racing on the same device both make the (idempotent) call; neither launches before its own call returned.
+struct vt_lds_once { std::atomic<unsigned long long> mask{0ull}; };
+static inline int vt_raise_lds_limit(vt_lds_once &once, const void *kernel, size_t bytes)
+{
+    int dev = 0;
+    VT_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.mask.load(std::memory_order_acquire) & bit) return VT_OK;
+    VT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    once.mask.fetch_or(bit, std::memory_order_release);
+    return VT_OK;
+}
+#define VT_LDS_LIMIT(kernel_, bytes_)                                                                          \
+    do {                                                                                                       \
+        static vt_lds_once once_;                                                                              \
+        const int rc_ = vt_raise_lds_limit(once_, reinterpret_cast<const void *>(kernel_), (bytes_));          \
+        if (rc_) return rc_;                                                                                   \
+    } while (0)
 
 template <typename T>
 static inline int vt_upload(T **dst, const T *host, size_t n, hipStream_t st)

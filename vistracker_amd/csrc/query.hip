@@ -1025,8 +1025,7 @@ extern "C" int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps
     VT_REQUIRE(h && maps && proj && B > 0 && maps->maps[0] && maps->res[0] >= 2, "vt_query_build_projection: bad argument");
     const long M = (long)B * maps->res[0] * maps->res[0];
     const size_t lds = sizeof(float) * 64 * PJ_AS;
-    static bool done = false;
-    if (!done) { VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(proj_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    VT_LDS_LIMIT(proj_gemm_kernel, lds);
     hipLaunchKernelGGL(proj_gemm_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, vt_stream(stream), maps->maps[0], h->projw, proj, M);
     VT_LAUNCH_CHECK();
     return VT_OK;
@@ -1042,8 +1041,7 @@ template <int G, int MODE, bool USEP>
 static int launch_(const QArgs &a, hipStream_t st)
 {
     const size_t lds = lds_bytes(G);
-    static bool done = false;
-    if (!done) { VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(query_kernel<G, MODE, USEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    VT_LDS_LIMIT((query_kernel<G, MODE, USEP>), lds);
     hipLaunchKernelGGL((query_kernel<G, MODE, USEP>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, a);
     VT_LAUNCH_CHECK();
     return VT_OK;

@@ -574,11 +574,7 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
     hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
     VT_LAUNCH_CHECK();
     const size_t lds_f = sizeof(float) * (FWD_FB * SAS + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3);
-    static bool attr_f = false;
-    if (!attr_f) {
-        VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_verts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-        attr_f = true;
-    }
+    VT_LDS_LIMIT(smplh_verts_kernel, lds_f);
     hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
                        verts, v_posed);
     VT_LAUNCH_CHECK();
@@ -594,11 +590,7 @@ extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const flo
     hipStream_t st = vt_stream(stream);
     const size_t lds = sizeof(float) * (256 * 13 + BWD_FB * 624);
     float *dvp_g = scratch + (size_t)NVT_ * B * PT_N, *part3 = dvp_g + (size_t)B * KTOT_;
-    static bool attr_done = false;
-    if (!attr_done) {
-        VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(smplh_bwd_tile_kernel<BWD_FB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    VT_LDS_LIMIT(smplh_bwd_tile_kernel<BWD_FB>, lds);
     hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->W_v64, ws, v_posed, dverts, B, scratch, dvp_g);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, 4, (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3);

@@ -105,6 +105,23 @@ def _check_finite(res, what):
         raise FloatingPointError(f"{what}: non-finite loss at Adam step {bad} (non-finite input or decoder activation out of range)")
 
 
+def _as_input(t, dev):
+    """constant input of a fit loop -> contiguous float32 tensor on ``dev`` (no copy when it already is one)"""
+    if t is None:
+        return None
+    return torch.as_tensor(t).to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _require_params(*ts):
+    """the optimised tensors are updated in place through raw pointers: they must already be contiguous float32 CUDA tensors"""
+    for t in ts:
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise L.VtError("fit loops update their parameters in place: pass contiguous float32 CUDA tensors "
+                            f"(got {type(t).__name__} {getattr(t, 'dtype', None)} on {getattr(t, 'device', None)})")
+        if t.device != ts[0].device:
+            raise L.VtError("fit loops: all parameters must live on the same device")
+
+
 @dataclass
 class FitResult:
     steps: int = 0
@@ -122,6 +139,21 @@ def morton_order(points) -> np.ndarray:
         x = (x | (x << 16)) & 0x030000FF; x = (x | (x << 8)) & 0x0300F00F; x = (x | (x << 4)) & 0x030C30C3
         return (x | (x << 2)) & 0x09249249
     return np.argsort(part(q[:, 0]) | (part(q[:, 1]) << 1) | (part(q[:, 2]) << 2), kind="stable")
+
+
+def morton_order_device(p: torch.Tensor) -> torch.Tensor:
+    """``morton_order`` for (N,2) or (N,3) points that live on the device: int32 indices, no host synchronisation"""
+    p = p.double()
+    lo = p.min(0).values; hi = p.max(0).values
+    q = ((p - lo) / (hi - lo + 1e-12) * 1023).long()
+
+    def part(x):
+        x = (x | (x << 16)) & 0x030000FF; x = (x | (x << 8)) & 0x0300F00F; x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+    key = part(q[:, 0]) | (part(q[:, 1]) << 1)
+    if p.shape[1] > 2:
+        key = key | (part(q[:, 2]) << 2)
+    return torch.argsort(key, stable=True).to(torch.int32)
 
 
 class FitContext:
@@ -180,13 +212,23 @@ class FitContext:
 
     # ---- SMPL-T pre-fit (fit_SMPLH_kpts.py:114-180) ------------------------------------------------------
     def fit_smplt(self, pose, betas, trans, kpts, max_iter=100, iter_for_global=8, temporal=True, pinit_w=900.0,
-                  lr_global=0.01, lr_all=0.001, it_range=None, check_every=1):
+                  lr_global=0.01, lr_all=0.001, it_range=None, check_every=1, weights=None, early_stop=True):
         """In-place Adam fit of pose (B,156), betas (B,10), trans (B,3) to 2D keypoints kpts (B,25,3).
-        ``it_range`` = (start, end) restricts the outer iterations (used by the trajectory parity tests)."""
+        ``it_range`` = (start, end) restricts the outer iterations (used by the trajectory parity tests).
+        ``weights``: the constants c of the fitter's ``get_loss_weights()`` table (w = c / (1 + decay)) for any of the terms
+        kpts / temp / ptemp / pose / pinit / hand; missing terms keep the 30fps defaults (``pinit_w`` for 'pinit')."""
+        with torch.cuda.device(pose.device):
+            return self._fit_smplt(pose, betas, trans, kpts, max_iter, iter_for_global, temporal, pinit_w, lr_global, lr_all, it_range, check_every, weights, early_stop)
+
+    def _fit_smplt(self, pose, betas, trans, kpts, max_iter, iter_for_global, temporal, pinit_w, lr_global, lr_all, it_range, check_every, weights, early_stop=True):
         dev = pose.device; B = pose.shape[0]
+        _require_params(pose, betas, trans)
+        kpts = _as_input(kpts, dev)
         names = ["kpts", "temp", "ptemp", "pose", "pinit", "hand"]
         terms = Terms(names, dev)
         table = dict(SMPLT_WEIGHTS); table["pinit"] = pinit_w
+        if weights is not None:
+            table.update({k: float(v) for k, v in weights.items() if k in table})
         verts = torch.empty(B, 6890, 3, device=dev); jtr = torch.empty(B, 52, 3, device=dev); vposed = torch.empty_like(verts)
         ws = torch.empty(_lib().vt_smplh_workspace_floats(B), device=dev); scratch = torch.empty(_lib().vt_smplh_bwd_scratch_floats(B), device=dev)
         dverts = torch.empty_like(verts); J = torch.empty(B, 25, 3, device=dev); dJ = torch.empty_like(J)
@@ -223,7 +265,7 @@ class FitContext:
                 _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 63, float(B * 63), float(w[4]),
                                            terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
                 adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(it > 0.3 * max_iter), state.data_ptr(),
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > 0.3 * max_iter), state.data_ptr(),
                                                     stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                 res.steps += 1
             res.outer_iters += 1
@@ -238,8 +280,19 @@ class FitContext:
 
     # ---- fit, SMPL stage (recon_fit_behave.py:393-513) ----------------------------------------------------
     def optimize_smpl(self, maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter=100, iter_for_betas=1,
-                      iter_for_pose=1, iter_for_kpts=1, it_range=None, net_size=512.0, check_every=1, prof=None):
+                      iter_for_pose=1, iter_for_kpts=1, it_range=None, net_size=512.0, check_every=1, prof=None, early_stop=True):
+        """pose (B,156), betas (B,10), trans (B,3): float32 CUDA tensors updated in place.  The constant inputs (crop_center, body_center,
+        body_kpts) are converted to contiguous float32 on the parameters' device if they are not already (a reference-style driver hands
+        over float64 from the dataloader's default collate)."""
+        with torch.cuda.device(pose.device):
+            return self._optimize_smpl(maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose,
+                                       iter_for_kpts, it_range, net_size, check_every, prof, early_stop)
+
+    def _optimize_smpl(self, maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose, iter_for_kpts,
+                       it_range, net_size, check_every, prof, early_stop=True):
         dev = pose.device; B = pose.shape[0]; V = 6890
+        _require_params(pose, betas, trans)
+        crop_center, body_center, body_kpts = _as_input(crop_center, dev), _as_input(body_center, dev), _as_input(body_kpts, dev)
         if self.use_projection:
             maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale
         names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
@@ -257,9 +310,10 @@ class FitContext:
             # processing order for this batch: Morton order of the IMAGE positions of the initial vertices of the middle frame (the body moves
             # little inside a batch and during the fit); a little better than the template's 3-D order because the perspective maps -- the
             # projection rows and tmpx, two thirds of the gathered bytes -- see exactly this neighbourhood structure.  Results do not depend on it.
+            # Computed on the device (bit interleave + one argsort of 6890 keys): no host round trip inside the batch.
             self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
-            v0 = verts[B // 2].cpu().numpy()
-            vert_order = torch.as_tensor(morton_order(np.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2], np.zeros(V)], 1)).astype(np.int32), device=dev)
+            v0 = verts[B // 2]
+            vert_order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
         self.hand_prior_value(pose, terms, "hand", vb)
         total = iter_for_betas + iter_for_kpts + iter_for_pose + max_iter
         start, end = it_range if it_range is not None else (0, total)
@@ -298,7 +352,7 @@ class FitContext:
                 _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
                                            terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
                 adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(it > arm_after), state.data_ptr(),
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(),
                                                     stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                 res.steps += 1
             res.outer_iters += 1
@@ -313,13 +367,25 @@ class FitContext:
 
     # ---- fit, object stage (recon_fit_trivis_full.py:283-377) ----------------------------------------------
     def optimize_smpl_object(self, maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil=None, noise=None,
-                             iter_for_obj=15, iter_for_sil=30, joint_iter=10, max_iter=100, it_range=None, seed=0, check_every=1, prof=None):
-        """obj_R (B,3,3), obj_t (B,3) are updated in place.  ``smpl_verts`` (B,6890,3): the frozen body (contacts).
-        ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``)."""
+                             iter_for_obj=15, iter_for_sil=30, joint_iter=10, max_iter=100, it_range=None, seed=0, check_every=1, prof=None, early_stop=True):
+        """obj_R (B,3,3), obj_t (B,3): float32 CUDA tensors updated in place.  ``smpl_verts`` (B,6890,3): the frozen body (contacts).
+        ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``).
+        Constant inputs are converted to contiguous float32 on the parameters' device if needed."""
+        with torch.cuda.device(obj_R.device):
+            return self._optimize_smpl_object(maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil,
+                                              joint_iter, max_iter, it_range, seed, check_every, prof, early_stop)
+
+    def _optimize_smpl_object(self, maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil,
+                              joint_iter, max_iter, it_range, seed, check_every, prof, early_stop=True):
         dev = obj_R.device; B = obj_R.shape[0]; N = self.obj_points.shape[0]; NV = self.obj_verts.shape[0]
+        _require_params(obj_R, obj_t)
+        smpl_verts, obj_s, crop_center, body_center, occ = (_as_input(x, dev) for x in (smpl_verts, obj_s, crop_center, body_center, occ))
+        obj_s = obj_s.reshape(-1)
+        if noise is not None:
+            noise = _as_input(noise, dev)
         if self.use_projection:
             maps.build_projection(self.net)
-        names = ["object", "otemp", "ovtemp", "mask", "trans", "contact"]
+        names = ["object", "otemp", "ovtemp", "mask", "trans", "contact", "scale"]
         terms = Terms(names, dev)
         total = joint_iter + iter_for_obj + max_iter + iter_for_sil
         start, end = it_range if it_range is not None else (0, total)
@@ -338,6 +404,10 @@ class FitContext:
             sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0], sil.size), device=dev)
             dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
         adam = None; res = FitResult(); contact = None; trans_init = None
+        # 'scale' = mean((obj_s - 1)^2) (recon_fit_trivis_full.py:161,227): obj_s is never optimised, so the term is a constant of the call
+        # -- zero for the obj_s == 1 that fit_recon passes -- but it is part of the summed loss the stop rule looks at
+        ones = torch.ones_like(obj_s)
+        _chk(_lib().vt_sqdiff_loss(obj_s.data_ptr(), 1, ones.data_ptr(), 1, B, 1, float(B), 0.0, terms.ptr("scale"), None, L.stream_ptr()))
         for it in range(start, end):
             if it < iter_for_obj:
                 phase = "object only"
@@ -358,7 +428,7 @@ class FitContext:
             for i in range(10):
                 k = (it - start) * 10 + i
                 nz = noise[k]
-                terms.zero()
+                terms.zero(0, 6)
                 _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
                 _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
                 acc = 0
@@ -397,7 +467,7 @@ class FitContext:
                 _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
                 _chk(_lib().vt_so3_project_backward(obj_R.data_ptr(), nz.data_ptr(), B, dR.data_ptr(), dM.data_ptr(), L.stream_ptr()))
                 adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(phase == "joint" and it > 0.25 * max_iter),
+                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(early_stop and phase == "joint" and it > 0.25 * max_iter),
                                                     state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
                 res.steps += 1
             res.outer_iters += 1

@@ -257,9 +257,12 @@ class ReconFitterTriVisFull(ReconFitterBase):
         q = data_dict["query_dict"]
         height_init = self.get_smpl_height(smpl).detach()
         with torch.no_grad():
-            pose = smpl.pose.data.contiguous().clone(); betas = smpl.betas.data.contiguous().clone(); trans = smpl.trans.data.contiguous().clone()
-            res = self.ctx.optimize_smpl(self._maps(model), pose, betas, trans, q["crop_center"].contiguous(), q["body_center"].contiguous(),
-                                         data_dict["body_kpts"].contiguous(), max_iter=max_iter, iter_for_betas=iter_for_betas,
+            # working copies in the form the fused loop updates in place (float32, contiguous, on the fit device); the constant inputs are
+            # normalised by FitContext (a reference-style dataloader collates crop_center / body_center as float64)
+            f32 = lambda t: t.data.to(device=self.device, dtype=torch.float32).contiguous().clone()
+            pose, betas, trans = f32(smpl.pose), f32(smpl.betas), f32(smpl.trans)
+            res = self.ctx.optimize_smpl(self._maps(model), pose, betas, trans, q["crop_center"], q["body_center"],
+                                         data_dict["body_kpts"], max_iter=max_iter, iter_for_betas=iter_for_betas,
                                          iter_for_pose=iter_for_pose, iter_for_kpts=iter_for_kpts)
             # copy_smpl_params semantics: pose, translation and the first two betas come back (recon_fit_base.py:808-816)
             smpl.pose.data.copy_(pose); smpl.trans.data.copy_(trans); smpl.betas.data[:, :2] = betas[:, :2]
@@ -280,10 +283,10 @@ class ReconFitterTriVisFull(ReconFitterBase):
         iters = self.get_opt_iters()
         with torch.no_grad():
             verts = smpl()[0].detach().contiguous()
-            obj_R = data_dict["obj_R"].data.contiguous(); obj_t = data_dict["obj_t"].data.contiguous(); obj_s = data_dict["obj_s"].data.view(-1).contiguous()
-            occ = data_dict["occ_ratios"].to(verts.device).float().contiguous()
-            res = self.ctx.optimize_smpl_object(self._maps(model), verts, obj_R, obj_t, obj_s, q["crop_center"].contiguous(), q["body_center"].contiguous(),
-                                                occ, sil=sil.setup(), iter_for_obj=iters["object"], iter_for_sil=iters["sil"], joint_iter=joint_iter)
+            f32 = lambda t: t.data.to(device=self.device, dtype=torch.float32).contiguous().clone()
+            obj_R, obj_t = f32(data_dict["obj_R"]), f32(data_dict["obj_t"])
+            res = self.ctx.optimize_smpl_object(self._maps(model), verts, obj_R, obj_t, data_dict["obj_s"].data, q["crop_center"], q["body_center"],
+                                                data_dict["occ_ratios"], sil=sil.setup(), iter_for_obj=iters["object"], iter_for_sil=iters["sil"], joint_iter=joint_iter)
             data_dict["obj_R"].data.copy_(obj_R); data_dict["obj_t"].data.copy_(obj_t)
         self.last["object"] = res
         return smpl, data_dict["obj_R"], data_dict["obj_t"]

@@ -44,6 +44,11 @@ def gather_params(local, num_frames: int, bs: int, start: int = 0, end: int | No
     mx = max(counts)
     pad = torch.zeros(mx, D, dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad)
-    return torch.cat([o[:c] for o, c in zip(outs, counts)], 0)
+    # RCCL ("nccl") gathers device tensors in place; gloo (CPU tests, single-GPU dry runs with several ranks) has no device all_gather:
+    # stage through the host there
+    via_host = pad.is_cuda and dist.get_backend() == "gloo"
+    send = pad.cpu() if via_host else pad
+    outs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(outs, send)
+    full = torch.cat([o[:c] for o, c in zip(outs, counts)], 0)
+    return full.to(local.device) if via_host else full

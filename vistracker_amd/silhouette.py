@@ -17,12 +17,19 @@ import torch.nn as nn
 from . import ops
 
 
+# An empty object mask (a fully occluded frame -- the tracker's core use case) has no contour: the reference's loop over contours never
+# runs and the initial values come back (recon/opt_utils.py:148-153).  The square box built from them has a NEGATIVE side, ROIAlign takes
+# zero samples per bin (ceil(negative / out) <= 0) and the crops of both masks are all zero; the frame's mask term is then only what
+# ``occ_ratios`` lets through (recon_fit_trivis_full.py:155-162).  Reproduced instead of raising: one such frame must not abort the batch.
+EMPTY_BBOX = (50000.0, 50000.0, -100.0, -100.0)
+
+
 def mask2bbox(mask: np.ndarray) -> np.ndarray:
     """xyxy bbox of ``mask > 127`` (uint8) as ``opt_utils.mask2bbox`` builds it from contour rectangles
     (recon/opt_utils.py:144-155): tight box with +1 on the max edge."""
     ys, xs = np.nonzero(mask > 127)
     if len(xs) == 0:
-        raise ValueError("empty object mask: the reference would produce an invalid bbox here")
+        return np.array(EMPTY_BBOX, dtype=np.float64)
     return np.array([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1], dtype=np.float64)
 
 
@@ -31,13 +38,15 @@ def masks2bbox(masks: torch.Tensor) -> np.ndarray:
     reference's loader, tight xyxy box with +1 on the max edge"""
     fg = (masks.float() * 255).to(torch.uint8) > 127
     cols, rows = fg.any(1), fg.any(2)                           # (B,W), (B,H)
-    if not bool(cols.any(1).all()):
-        raise ValueError("empty object mask: the reference would produce an invalid bbox here")
     W, H = cols.shape[1], rows.shape[1]
     ax = torch.arange(W, device=masks.device); ay = torch.arange(H, device=masks.device)
     x0 = torch.where(cols, ax, W).min(1)[0]; x1 = torch.where(cols, ax, -1).max(1)[0] + 1
     y0 = torch.where(rows, ay, H).min(1)[0]; y1 = torch.where(rows, ay, -1).max(1)[0] + 1
-    return torch.stack([x0, y0, x1, y1], 1).double().cpu().numpy()
+    boxes = torch.stack([x0, y0, x1, y1], 1).double()
+    empty = ~cols.any(1)
+    if bool(empty.any()):
+        boxes[empty] = torch.tensor(EMPTY_BBOX, dtype=torch.float64, device=boxes.device)
+    return boxes.cpu().numpy()
 
 
 def make_bbox_square(bbox_xywh: np.ndarray, expansion: float) -> np.ndarray:
@@ -54,6 +63,8 @@ def roi_align_mask(mask: torch.Tensor, box_xyxy, out: int) -> torch.Tensor:
     x1, y1, x2, y2 = [float(v) for v in box_xyxy]
     sw, sh = x1 - 0.5, y1 - 0.5
     rw, rh = x2 - x1, y2 - y1
+    if math.ceil(rw / out) <= 0 or math.ceil(rh / out) <= 0:      # degenerate box (EMPTY_BBOX): ROIAlign takes no samples, the crop is zero
+        return torch.zeros(out, out, device=mask.device)
     bw, bh = rw / out, rh / out
     gw, gh = max(int(math.ceil(rw / out)), 1), max(int(math.ceil(rh / out)), 1)
     dev = mask.device
@@ -85,9 +96,9 @@ def roi_align_masks(masks: torch.Tensor, boxes_xyxy, out: int) -> torch.Tensor:
     B, H, W = masks.shape
     boxes = np.asarray(boxes_xyxy, np.float64).reshape(B, 4)
     rw, rh = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
-    gw = np.maximum(np.ceil(rw / out).astype(np.int64), 1); gh = np.maximum(np.ceil(rh / out).astype(np.int64), 1)
+    gw = np.ceil(rw / out).astype(np.int64); gh = np.ceil(rh / out).astype(np.int64)
     dev = masks.device
-    res = torch.empty(B, out, out, device=dev)
+    res = torch.zeros(B, out, out, device=dev)      # frames with a degenerate box (EMPTY_BBOX: zero samples per bin) stay zero
     ar = torch.arange(out, device=dev, dtype=torch.float64)
 
     def prep(v, n):
@@ -101,6 +112,8 @@ def roi_align_masks(masks: torch.Tensor, boxes_xyxy, out: int) -> torch.Tensor:
         return lo, hi, v - lo.double(), dead
 
     for g_w, g_h in sorted(set(zip(gw.tolist(), gh.tolist()))):
+        if g_w <= 0 or g_h <= 0:
+            continue
         idx = np.flatnonzero((gw == g_w) & (gh == g_h)); n = len(idx)
         bx = torch.as_tensor(boxes[idx], device=dev)
         bw, bh = (bx[:, 2] - bx[:, 0]) / out, (bx[:, 3] - bx[:, 1]) / out

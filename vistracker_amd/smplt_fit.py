@@ -141,7 +141,7 @@ class BaseFitter:
         with torch.no_grad():
             pose = smpl.pose.data.contiguous().clone(); betas = smpl.betas.data.contiguous().clone(); trans = smpl.trans.data.contiguous().clone()
             res = self.ctx.fit_smplt(pose, betas, trans, kpts, max_iter=self.get_max_iters(), iter_for_global=self.get_globalopt_iters(),
-                                     temporal=self.temporal, pinit_w=w["pinit"], lr_global=self.lr_global, lr_all=self.lr_all)
+                                     temporal=self.temporal, pinit_w=w["pinit"], lr_global=self.lr_global, lr_all=self.lr_all, weights=w)
             smpl.pose.data.copy_(pose); smpl.trans.data.copy_(trans); smpl.betas.data[:, :2] = betas[:, :2]      # copy_smpl_params
         self.last = res
         self.save_results(smpl, seq_folder, kid, start, end, kpts[:, :, 2], image_files)
