@@ -1,0 +1,43 @@
+"""A/B of the two kernels behind vt_query_human_loss at the bench shape (B=96, SMPL vertices, 2-D Morton order, hoisted projection):
+time per launch and agreement of terms / coordinate gradients.  usage: qab.py [reps=20]"""
+import sys, ctypes as C; sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+import torch.nn.functional as F
+from vistracker_amd import ops, synthetic as syn, _lib as L
+from vistracker_amd.fitting import morton_order_device
+B, N = 96, 6890
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = "cuda"; g = torch.Generator(device=dev); g.manual_seed(0)
+maps = {}
+for name, c, res, _ in syn.MAP_SPECS:
+    lo = torch.randn(B, c, res // 8, res // 8, device=dev, generator=g)
+    maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+fm = ops.FeatureMaps(maps); net = ops.SifNetHandle(syn.sifnet_decoders(3)); fm.build_projection(net)
+model = syn.smplh_model(0); sp = syn.sequence_params(B, seed=7)
+t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+verts, _, _ = ops.smplh_forward(ops.SmplhHandle(model), t(sp["pose"]), t(sp["betas"]), t(sp["trans"]))
+pts = verts.detach().contiguous(); bc = t(sp["trans"]); cc = torch.tensor([[1018.952, 779.486]] * B, device=dev)
+labels = torch.as_tensor(syn.part_labels(model).astype(np.int32), device=dev)
+v0 = pts[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
+res = {}
+for thr in (256, 512):
+    L.check(L.lib().vt_query_set_human_kernel(thr))
+    dp = torch.full((B, N, 3), float("nan"), device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
+    def run():
+        L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, labels.data_ptr(), order.data_ptr(),
+                                            100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
+    run(); torch.cuda.synchronize(); first = (dp.clone(), terms.clone())
+    for _ in range(3): run()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    dp2 = torch.empty_like(dp); t2 = torch.zeros_like(terms)
+    dp.fill_(float("nan")); terms.zero_(); run(); torch.cuda.synchronize()
+    print(f"{thr}-thread kernel: {ms:.3f} ms/launch = {0.59265024 / ms * 1e3:.0f} TFLOP/s algorithmic = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; "
+          f"finite {bool(torch.isfinite(dp).all())}; rerun bit-identical {bool(torch.equal(dp, first[0]))} terms {bool(torch.equal(terms, first[1]))}")
+    res[thr] = (first[0].cpu().numpy(), first[1].cpu().numpy())
+a, b = res[256], res[512]
+err = np.abs(a[0] - b[0]).max(-1) / np.abs(a[0]).max()
+print("terms 256:", a[1], "512:", b[1], "rel diff", np.abs(a[1] - b[1]) / np.abs(a[1]))
+print("gradient: max |diff| / max |g| =", err.max(), " quantiles 50/99/99.9/99.99 %:", [float(np.quantile(err, q)) for q in (0.5, 0.99, 0.999, 0.9999)], " points > 1e-5:", int((err > 1e-5).sum()))

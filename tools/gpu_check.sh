@@ -9,6 +9,6 @@ tail -30 gpurun_out/${tag}_pytest.log
 ( time timeout 900 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 3000 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err
 d=$(mktemp -d /tmp/prof.XXXX)
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $d -o r -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 2 --warmup 1 --no-extras --no-cpu-baseline ) > gpurun_out/${tag}_prof.log 2>&1
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 2 --warmup 1 --no-extras --no-cpu-baseline ) > gpurun_out/${tag}_prof.log 2>&1
 f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_1stream.csv && head -12 $f
 tail -3 gpurun_out/${tag}_prof.log
