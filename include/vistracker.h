@@ -157,9 +157,10 @@ int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *p
                          const float *body_center, int B, int N, const float *occ, float w_obj,
                          float *dpts, double *terms, void *stream);
 
-/* Kernel selection for vt_query_human_loss when the maps carry the hoisted projection: 512 (default: one 512-thread workgroup per CU, thin
- * waves, three chunks of taps in flight) or 256 (the two-workgroups-per-CU kernel all other query entry points use).  Same arithmetic, results
- * agree to the round-off of the gradient's summation order; exists for A/B measurements and cross-check tests.  Process-wide. */
+/* Kernel selection for vt_query_human_loss when the maps carry the hoisted projection: 256 (default: the two-workgroups-per-CU kernel all
+ * query entry points use) or 512 (one 512-thread workgroup per CU, thin waves, three chunks of taps in flight -- measured slower, kept for A/B
+ * measurements and as an independent cross-check).  Same arithmetic, results agree to the round-off of the gradient's summation order.
+ * Process-wide. */
 int vt_query_set_human_kernel(int threads);
 
 /* One projection step of the SIF-Net surface-point generator, fused.  Replaces one iteration of

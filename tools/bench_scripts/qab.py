@@ -21,7 +21,7 @@ labels = torch.as_tensor(syn.part_labels(model).astype(np.int32), device=dev)
 v0 = pts[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
 res = {}
 for thr in (256, 512):
-    L.check(L.lib().vt_query_set_human_kernel(thr))
+    L.check(L.lib().vt_query_set_human_kernel(thr))   # 256 = default
     dp = torch.full((B, N, 3), float("nan"), device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
     def run():
         L.check(L.lib().vt_query_human_loss(net.h, C.byref(fm.c), pts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, N, labels.data_ptr(), order.data_ptr(),

@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
 
 // per-phase shader-clock breakdown (debug builds with -DPHASE_CLK only; tools/bench_scripts/qphase.py)
 #ifdef PHASE_CLK
-__device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_phase[16];
 #define PCLK(i_) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_phase[i_], t_ - tprev_); tprev_ = t_; } } while (0)
 #else
 #define PCLK(i_)
@@ -869,6 +869,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 // different summation order of the coordinate gradient.
 // =====================================================================================================================
 #define W8_PD 3
+#ifndef W8_ABL
+#define W8_ABL 0     /* timing experiments only (wrong results): 1 no MFMA in the L1 loops, 2 no tap loads, 4 no weight loads in the loops, 8 no blend/store, 16 no loop barriers */
+#endif
 struct Acc4 { f32x4 v[4]; };
 struct Taps1 { float4 t[4]; };
 
@@ -1034,6 +1037,9 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
         else { b = L / tiles; tile = L % tiles; }
     }
     const int n0 = tile * 64;
+#ifdef PHASE_CLK
+    unsigned long long tprev_ = clock64();
+#endif
 
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
     if (tid < 64) {
@@ -1057,6 +1063,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 #pragma unroll
     for (int pr = 0; pr < 4; pr++) { uv[pr][0] = sUV[(pr * 64 + gpt) * 2]; uv[pr][1] = sUV[(pr * 64 + gpt) * 2 + 1]; }
 
+    PCLK(0);
     // ================= layer 1, forward =================
     Taps1 tp[W8_PD];
 #pragma unroll
@@ -1109,14 +1116,15 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     }
     W8_STORE_FEAT(C0)
     tap1_issue(a, b, C0 + W8_PD, uv, sub, tp[0]);
+    PCLK(1);
 #pragma unroll
     for (int ci = C0; ci < NCHUNK; ci++) {
         const uint4 *buf = lds + (ci & 1) * 512;
-        __syncthreads();                                // chunk ci visible; the other slot's readers (MFMAs of chunk ci - 1) are done
-        k32_step8<G>(acc1, wf[(ci - C0) & 1], buf, buf + 256, 0, lane);
-        if (ci + 1 < NCHUNK) W8_STORE_FEAT(ci + 1)
-        if (ci + 2 <= NCHUNK) W8_LOAD_W1((ci - C0) & 1, ci + 2)     // steps C0 + 2 .. 19 (19 = the xyz step)
-        if (ci + 1 + W8_PD < NCHUNK) tap1_issue(a, b, ci + 1 + W8_PD, uv, sub, tp[(ci + 1 - C0) % W8_PD]);
+        if (!(W8_ABL & 16)) __syncthreads();            // chunk ci visible; the other slot's readers (MFMAs of chunk ci - 1) are done
+        if (!(W8_ABL & 1)) k32_step8<G>(acc1, wf[(ci - C0) & 1], buf, buf + 256, 0, lane);
+        if (!(W8_ABL & 8)) if (ci + 1 < NCHUNK) W8_STORE_FEAT(ci + 1)
+        if (!(W8_ABL & 4)) if (ci + 2 <= NCHUNK) W8_LOAD_W1((ci - C0) & 1, ci + 2)     // steps C0 + 2 .. 19 (19 = the xyz step)
+        if (!(W8_ABL & 2)) if (ci + 1 + W8_PD < NCHUNK) tap1_issue(a, b, ci + 1 + W8_PD, uv, sub, tp[(ci + 1 - C0) % W8_PD]);
     }
     {   // z_feat = (x, y, z - 2.2): internal channels 608..610 (K32 step 19, k = 8 q + t: only q == 0, t < 3 are non-zero)
         constexpr int sl = (NCHUNK - C0) & 1;           // slot that holds step 19
@@ -1138,6 +1146,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     }
 #undef W8_LOAD_W1
 #undef W8_STORE_FEAT
+    PCLK(2);
     WPre8 wp[G];
 #pragma unroll
     for (int g = 0; g < G; g++) wprefetch8(wp[g], a.hw[g].w2p, wave8, lane);
@@ -1150,6 +1159,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     }
     __syncthreads();
 
+    PCLK(3);
     // ================= layers 2, 3 (both heads per stage) =================
     Acc4 c[G];
     gemm128x<G>(c, Hp, wp, lane);
@@ -1167,6 +1177,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
     __syncthreads();
 
+    PCLK(4);
     // ================= layer 4 + objective, head-parallel: waves 0-3 head df, waves 4-7 head parts; wave (g4, w4) owns points 16 w4 .. +15 =================
     double loss_acc = 0.0;
     {
@@ -1231,6 +1242,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             gh[((j >> 3) * 64 + pt) * 8 + (j & 7)] = hi; gl[((j >> 3) * 64 + pt) * 8 + (j & 7)] = lo;
         }
     }
+    PCLK(5);
     // ================= backward through layers 4, 3, 2 (both heads per stage) =================
     WPre8 wq[G];
     uint4 w4t[G][2];
@@ -1269,6 +1281,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+    PCLK(6);
     {   // block-reduce the loss partials (waves 0-3 hold the df term, waves 4-7 the part term)
         double s = loss_acc;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -1299,6 +1312,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 #pragma unroll
     for (int t = 0; t < 2; t++) { const int pt = 16 * (2 * ph + t) + j; ptx[t] = sPt[pt * 3]; pty[t] = sPt[pt * 3 + 1]; piz[t] = 1.0f / sPt[pt * 3 + 2]; }
     __syncthreads();        // region 0 changes role again: activation planes -> tap-difference ring
+    PCLK(7);
 #pragma unroll
     for (int k = 0; k < W8_PD; k++) tap1_issue(a, b, C0 + k, uv, sub, tp[k]);
     uint4 wb[2][4][2];      // A fragments of W1 (chunk, s, hi|lo) for (ct, gb), two chunks
@@ -1366,14 +1380,15 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     }
     W8_STORE_GRAD(C0)
     tap1_issue(a, b, C0 + W8_PD, uv, sub, tp[0]);
+    PCLK(8);
 #pragma unroll
     for (int ci = C0; ci < NCHUNK; ci++) {
         const int sl = (ci - C0) & 1;
-        __syncthreads();                                // tap differences of chunk ci visible; the other slot's readers are done
+        if (!(W8_ABL & 16)) __syncthreads();            // tap differences of chunk ci visible; the other slot's readers are done
         f32x4 dd[2];
         dd[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dd[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < ((W8_ABL & 1) ? 0 : 4); s++) {
             const h8 wh = as_h8(wb[sl][s][0]), wl = as_h8(wb[sl][s][1]);
             dd[0] = MFMAH(wh, as_h8(dh[0][s][0]), dd[0]); dd[1] = MFMAH(wh, as_h8(dh[1][s][0]), dd[1]);
             dd[0] = MFMAH(wh, as_h8(dh[0][s][1]), dd[0]); dd[1] = MFMAH(wh, as_h8(dh[1][s][1]), dd[1]);
@@ -1386,9 +1401,9 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             u4[t] = *reinterpret_cast<const float4 *>(bu + (16 * (2 * ph + t) + j) * TS + 16 * ct + 4 * q);
             v4[t] = *reinterpret_cast<const float4 *>(bv + (16 * (2 * ph + t) + j) * TS + 16 * ct + 4 * q);
         }
-        if (ci + 1 < NCHUNK) W8_STORE_GRAD(ci + 1)
-        if (ci + 2 <= NCHUNK) W8_LOAD_WB(sl, ci + 2)    // chunk 19 = the xyz rows
-        if (ci + 1 + W8_PD < NCHUNK) tap1_issue(a, b, ci + 1 + W8_PD, uv, sub, tp[(ci + 1 - C0) % W8_PD]);
+        if (!(W8_ABL & 8)) if (ci + 1 < NCHUNK) W8_STORE_GRAD(ci + 1)
+        if (!(W8_ABL & 4)) if (ci + 2 <= NCHUNK) W8_LOAD_WB(sl, ci + 2)    // chunk 19 = the xyz rows
+        if (!(W8_ABL & 2)) if (ci + 1 + W8_PD < NCHUNK) tap1_issue(a, b, ci + 1 + W8_PD, uv, sub, tp[(ci + 1 - C0) % W8_PD]);
         // projection Jacobians of the chunk's map (compile-time after unrolling)
         const int pr = w8_proj(w8_map(ci));
 #pragma unroll
@@ -1408,6 +1423,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     }
 #undef W8_STORE_GRAD
 #undef W8_LOAD_WB
+    PCLK(9);
     if (ct == 0) {   // direct xyz features: rows 0..2 of channel tile 0 of "chunk" 19 (its fragments were the last W8_LOAD_WB)
         constexpr int sl = (NCHUNK - C0) & 1;
 #pragma unroll
@@ -1439,6 +1455,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             a.dpts[((size_t)b * a.N + (sIn[pt] >> 1)) * 3 + k] = s;
         }
     }
+    PCLK(10);
 }
 static size_t lds_bytes_human8() { return 16 * (2 * 2048 + 2 * 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + 2 * 64 + 4 * 64 * 3 + 64) + 8 * sizeof(double); }
 static int launch_human8(const QArgs &a, hipStream_t st)
@@ -1613,7 +1630,7 @@ __global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict_
 extern "C" int vt_phase_clk(unsigned long long *out, int reset)
 {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase));
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
     return 0;
 }
 #endif
@@ -1703,8 +1720,8 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
     return n == 2 ? launch<2, MODE_BWD>(a, vt_stream(stream)) : launch<1, MODE_BWD>(a, vt_stream(stream));
 }
 
-// which kernel serves vt_query_human_loss when the maps carry a projection: 512 (default) or 256 threads per workgroup
-static std::atomic<int> g_human_kernel_threads{[]() { const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); return (e && atoi(e) == 256) ? 256 : 512; }()};
+// which kernel serves vt_query_human_loss when the maps carry a projection: 256 (default, the faster one: DESIGN.md 4.1b) or 512 threads per workgroup
+static std::atomic<int> g_human_kernel_threads{[]() { const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); return (e && atoi(e) == 512) ? 512 : 256; }()};
 extern "C" int vt_query_set_human_kernel(int threads)
 {
     VT_REQUIRE(threads == 256 || threads == 512, "vt_query_set_human_kernel: threads must be 256 or 512");
@@ -1718,9 +1735,9 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(labels && dpts && terms, "vt_query_human_loss: null argument");
     a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
-    // with the hoisted projection: the 512-thread kernel (one workgroup per CU, deep tap prefetch) unless vt_query_set_human_kernel(256) /
-    // VT_QUERY_HUMAN_KERNEL=256 selected the 256-thread kernel (A/B measurements, cross-check tests)
-    const bool use8 = g_human_kernel_threads.load(std::memory_order_relaxed) != 256;
+    // vt_query_set_human_kernel(512) / VT_QUERY_HUMAN_KERNEL=512 select the 512-thread kernel (one workgroup per CU, deep tap prefetch): an
+    // experiment kept for A/B measurements and as an independent cross-check of the 256-thread kernel (measured slower)
+    const bool use8 = g_human_kernel_threads.load(std::memory_order_relaxed) == 512;
     const bool usep = a.proj != nullptr && a.pw == PROJ_COLS && (long)a.res[0] * a.res[0] * PROJ_COLS < (1L << 32);
     if (use8 && usep) return launch_human8(a, vt_stream(stream));
     return launch<2, MODE_HUMAN>(a, vt_stream(stream));
