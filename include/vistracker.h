@@ -157,6 +157,18 @@ int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *p
                          const float *body_center, int B, int N, const float *occ, float w_obj,
                          float *dpts, double *terms, void *stream);
 
+/* Arithmetic of the decoder GEMMs behind every vt_query_* call of a handle:
+ *   VT_PRECISION_SPLIT_F16 (default): 22-bit split-f16 operands on the f16 MFMA, fp32 accumulate (5.3x the f32-input MFMA rate; forward within
+ *       ~1e-6 of the fp32 reference); activations must satisfy |x| < 1023, beyond that the result is inf/NaN;
+ *   VT_PRECISION_FP32: exact fp32 products on the f32-input MFMA (the reference's nn.Conv1d arithmetic, model/chore.py:113-126), any magnitude,
+ *       ~1/5 of the speed; the hoisted projection of the maps is ignored.
+ * The fused fit loops of the host layer switch a handle to VT_PRECISION_FP32 and re-run the batch when the split route produced a non-finite
+ * loss.  Per handle, may be changed between calls. */
+#define VT_PRECISION_SPLIT_F16 0
+#define VT_PRECISION_FP32 1
+int vt_sifnet_set_precision(vt_sifnet *h, int mode);
+int vt_sifnet_get_precision(const vt_sifnet *h);
+
 /* Kernel selection for vt_query_human_loss when the maps carry the hoisted projection: 256 (default: the two-workgroups-per-CU kernel all
  * query entry points use) or 512 (one 512-thread workgroup per CU, thin waves, three chunks of taps in flight -- measured slower, kept for A/B
  * measurements and as an independent cross-check).  Same arithmetic, results agree to the round-off of the gradient's summation order.

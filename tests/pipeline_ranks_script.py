@@ -1,0 +1,32 @@
+"""TEST INFRASTRUCTURE (launched by tests/test_gpu_multirank.py under torch.distributed.run): the in-memory demo pipeline on a synthetic sequence with
+WORLD_SIZE ranks that all use cuda:0 (collectives through gloo on host copies); rank 0 writes the packed results to argv[1]."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from vistracker_amd import demo_inputs                     # noqa: E402
+from vistracker_amd.pipeline import PipelineConfig         # noqa: E402
+
+world = int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(0)
+if world > 1:
+    dist.init_process_group("gloo")
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+cfg = PipelineConfig(smplt_bs=40, neural_bs=32, fit_bs=48, smplt_max_iter=4, refit_max_iter=2)
+pipe, assets = demo_inputs.pipeline(cfg, n_obj_points=600)
+seq = demo_inputs.sequence(T, assets)
+out = pipe.run(seq)
+if not dist.is_initialized() or dist.get_rank() == 0:
+    rc, st, nn_ = out["recon"], out["smplt_smoothed_fit"], out["neural"]
+    np.savez(sys.argv[1], poses=rc["poses"], betas=rc["betas"], trans=rc["trans"], obj_angles=rc["obj_angles"], obj_trans=rc["obj_trans"],
+             smplt_poses=st["poses"], smplt_trans=st["trans"], neural_pca=np.asarray(nn_["neural_pca"]), neural_vis=np.asarray(nn_["neural_visibility"]),
+             fit_steps=np.asarray(pipe.log["fit_steps"]), smplt_steps=np.asarray(pipe.log["smplt_steps"]))
+    print("PIPELINE_OK", world, pipe.log["fit_steps"])
+if dist.is_initialized():
+    dist.destroy_process_group()

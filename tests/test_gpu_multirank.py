@@ -26,3 +26,26 @@ def test_bench_two_ranks_on_one_gpu():
     # both ranks' batches are counted: 2 x 96 frames / the slower rank's time
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 96) < 1e-6 * 192
     assert line["config"]["adam_steps_smpl_stage"] >= 280 and line["roofline"]["launches"] >= 280
+
+
+def test_pipeline_two_ranks_equal_one_rank(tmp_path):
+    """The demo pipeline sharded over two ranks (batch-aligned shards, one all-gather per barrier) returns what the single-rank run returns:
+    frames shard by whole batches, every batch's random stream is keyed by its first frame, and no step depends on the rank.  The SMPL-T stages
+    must agree bit for bit; the joint-fit rows are compared bit for bit as well (deterministic kernels: fixed-order reductions, fp64 atomics)."""
+    import numpy as np
+    script = os.path.join(ROOT, "tests", "pipeline_ranks_script.py")
+    outs = []
+    for n, port in ((1, 29551), (2, 29552)):
+        f = tmp_path / f"r{n}.npz"
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               script, str(f), "150"]
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+        assert out.returncode == 0 and "PIPELINE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        outs.append(dict(np.load(f)))
+    a, b = outs
+    assert np.array_equal(a["smplt_steps"], b["smplt_steps"]) and np.array_equal(a["fit_steps"], b["fit_steps"])
+    for k in ("smplt_poses", "smplt_trans", "neural_pca", "neural_vis"):
+        assert np.array_equal(a[k], b[k]), k
+    worst = {k: float(np.abs(a[k] - b[k]).max()) for k in ("poses", "betas", "trans", "obj_angles", "obj_trans")}
+    assert all(v == 0.0 for v in worst.values()), worst

@@ -133,3 +133,64 @@ def test_smplh_model_loader_without_chumpy(tmp_path, synth):
     pickle.dump({"x": sp_.CompletedProcess([], 0)}, open(tmp_path / "evil.pkl", "wb"))
     with pytest.raises(pickle.UnpicklingError):
         load_smplh_model(str(tmp_path / "evil.pkl"))
+
+
+def test_generator_round_logic_on_cpu():
+    """The batched rounds of Generator.gen_pc_batch (compaction of the kept points, per-frame fill positions, resampling around kept points,
+    restart of frames without kept points; recon/gen/generator.py:149-257) with a stub in place of the projection kernel: the collected points of
+    every frame are exactly the kept points of rounds 1, 2, ... in sample order, cut to the common count."""
+    import torch
+    from vistracker_amd.generator import GeneratorTriplaneVis
+
+    class Stub(GeneratorTriplaneVis):
+        def __init__(self):
+            self.sparse_thres, self.filter_val, self.threshold = 0.05, 0.03, 1.0
+            self.device = torch.device("cpu"); self.seed = 3
+            self.rng = torch.Generator(device="cpu"); self.rng.manual_seed(3)
+            self.kept = None; self.rounds = 0; self.inputs = []
+
+        def approx_surface(self, model, samples, num_steps, query_input, df_type):
+            # "surface" = the samples themselves; df small for a pseudo-random 30 % of them (frame 2: none in round 0 -> restart from the grid)
+            B, S = samples.shape[:2]
+            h = torch.sin(samples.sum(-1) * 37.0 + self.rounds)
+            near = h > 0.4
+            if self.rounds == 0:
+                near[2] = False
+            df = torch.where(near, torch.tensor(0.01), torch.tensor(0.5))
+            preds = (torch.stack([df, df], 1), samples.transpose(1, 2).repeat(1, 3, 1).reshape(B, 3, 3, S), torch.randn(B, 14, S, generator=self.rng),
+                     samples.transpose(1, 2).contiguous(), torch.full((B, 1, S), 0.25))
+            mask = near & (samples[:, :, 2] > 1.0)
+            if self.rounds > 0:
+                for i in range(B):
+                    self.kept[i].append(samples[i, mask[i]].clone())
+            else:
+                self.kept = [[] for _ in range(B)]
+            self.inputs.append((samples.clone(), mask.clone()))
+            self.rounds += 1
+            return samples.clone(), preds
+
+    gen = Stub()
+    B = 4
+    bc = torch.tensor([[0.0, 0.0, 2.2]] * B)
+    init = gen.get_grid_samples(3000, B, bc)
+    out = gen.gen_pc_batch(None, "object", init, 9000, {"crop_center": torch.zeros(B, 2), "body_center": bc, "path": ["x"] * B}, num_steps=1)
+    n = out["points"].shape[1]
+    assert n >= 9000 and out["parts"].shape == (B, n) and out["pca_axis"].shape == (B, 3, 3) and out["centers"].shape == (B, 6) and out["visibility"].shape == (B, 1)
+    for i in range(B):
+        ref = torch.cat(gen.kept[i], 0)
+        assert ref.shape[0] >= n and torch.equal(out["points"][i], ref[:n])
+        # centers = mean of the per-point predictions (= the points themselves in the stub); NaN placeholder for the human centre in front
+        assert torch.allclose(out["centers"][i, 3:], ref[:n].mean(0), atol=1e-5) and torch.isnan(out["centers"][i, :3]).all()
+    assert torch.allclose(out["visibility"], torch.full((B, 1), 0.25))
+    # round 1 inputs: frames with kept points were resampled around them (threshold / 3 perturbation), frame 2 restarted from the grid (0.5)
+    s0, m0 = gen.inputs[0]; s1, _ = gen.inputs[1]
+    assert s1.shape == (B, 20000, 3)
+    d = torch.cdist(s1[0, :500], s0[0, m0[0]]).min(1).values
+    assert d.median() < 0.25                                   # near a kept sample
+    spread = (s1[2] - bc[2]).std(0)
+    assert (spread > 0.5).all()                                # frame 2: grid box + 0.5 m noise
+    # same seed -> same result; the per-batch key of the pipeline restarts the stream
+    g2 = Stub(); out2 = g2.gen_pc_batch(None, "object", g2.get_grid_samples(3000, B, bc), 9000, {"crop_center": torch.zeros(B, 2), "body_center": bc}, num_steps=1)
+    assert torch.equal(out2["points"], out["points"])
+    g2.reseed(96); a = torch.rand(3, generator=g2.rng); g2.reseed(96); b = torch.rand(3, generator=g2.rng); g2.reseed(192); c = torch.rand(3, generator=g2.rng)
+    assert torch.equal(a, b) and not torch.equal(a, c)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "vt_query_human_loss": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, fp, cf, cf, fp, fp, vp]),
     "vt_query_object_loss": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, cf, fp, fp, vp]),
     "vt_query_set_human_kernel": (ci, [ci]),
+    "vt_sifnet_set_precision": (ci, [vp, ci]),
+    "vt_sifnet_get_precision": (ci, [vp]),
     "vt_groupnorm_nhwc": (ci, [fp, fp, fp, ci, ci, ci, ci, cf, ci, fp, fp, vp]),
     "vt_upsample2x_bicubic_add": (ci, [fp, fp, ci, ci, ci, ci, fp, vp]),
     "vt_triplane_render": (ci, [fp, fp, ci, ci, fp, ci, ci, fp, fp, fp, vp]),

@@ -27,6 +27,7 @@
 //   * fused objective variants (human: clamp(df_h)-mean + part cross-entropy; object: visibility weighted clamp(df_o))
 //     produce the loss terms and the weighted coordinate gradient in the same launch.
 #include "common.h"
+#include "query_f32.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -65,6 +66,8 @@ struct vt_sifnet {
     HeadW head[5];
     float cam[5];
     float *projw;           // [256 im_feat channels][PROJ_COLS] fp32: ACT_SCALE s_W1 W1[u][c] of the heads df | parts (vt_query_build_projection)
+    f32q::Net *f32;         // the same decoders packed for the strict-fp32 kernels (query_f32.hip)
+    std::atomic<int> precision;     // VT_PRECISION_SPLIT_F16 (default) | VT_PRECISION_FP32: which kernels serve the vt_query_* calls of this handle
 };
 
 struct QArgs {
@@ -1575,10 +1578,21 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
     VT_HIP(hipStreamSynchronize(st));
     delete[] host; delete[] projw_host;
     for (int i = 0; i < 5; i++) h->cam[i] = cam[i];
+    h->f32 = nullptr; h->precision.store(VT_PRECISION_SPLIT_F16);
+    { const int rc = f32q::create(&h->f32, w, bvec, cam, stream); if (rc) return rc; }
     *out = h;
     return VT_OK;
 }
-extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; (void)hipFree(h->blob); (void)hipFree(h->projw); delete h; }
+extern "C" void vt_sifnet_destroy(vt_sifnet *h) { if (!h) return; (void)hipFree(h->blob); (void)hipFree(h->projw); f32q::destroy(h->f32); delete h; }
+
+extern "C" int vt_sifnet_set_precision(vt_sifnet *h, int mode)
+{
+    VT_REQUIRE(h && (mode == VT_PRECISION_SPLIT_F16 || mode == VT_PRECISION_FP32), "vt_sifnet_set_precision: bad handle or mode");
+    h->precision.store(mode, std::memory_order_relaxed);
+    return VT_OK;
+}
+extern "C" int vt_sifnet_get_precision(const vt_sifnet *h) { return h ? h->precision.load(std::memory_order_relaxed) : VT_ERR_ARG; }
+#define VT_IS_F32(h_) ((h_) && (h_)->precision.load(std::memory_order_relaxed) == VT_PRECISION_FP32)
 
 // ---- hoisted projection: P[m][n] = sum_c im_feat[m][c] Wp[c][n], m over all texels of the batch, c < 256, n < PROJ_COLS; fp32 MFMA
 // (16x16x4), one workgroup per 64 texels: the A tile (64 x 256) sits in LDS, wave w owns columns 64 w .. +63 (4 x 4 tiles) and streams
@@ -1690,6 +1704,7 @@ static int fill_common(QArgs &a, const vt_sifnet *h, const vt_maps *maps, const 
 extern "C" int vt_query_forward(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                 int B, int N, float *df, float *pca, float *parts, float *centers, float *vis, void *stream)
 {
+    if (VT_IS_F32(h)) return f32q::forward(h->f32, maps, pts, crop_center, body_center, B, N, df, pca, parts, centers, vis, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     float *outs[5] = {df, pca, parts, centers, vis};
     int ids[5], n = 0;
@@ -1708,6 +1723,7 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
                                  int B, int N, const float *d_df, const float *d_pca, const float *d_parts, const float *d_centers,
                                  const float *d_vis, float *dpts, void *stream)
 {
+    if (VT_IS_F32(h)) return f32q::backward(h->f32, maps, pts, crop_center, body_center, B, N, d_df, d_pca, d_parts, d_centers, d_vis, dpts, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(dpts, "vt_query_backward: dpts is null");
     const float *gs[5] = {d_df, d_pca, d_parts, d_centers, d_vis};
@@ -1732,6 +1748,7 @@ extern "C" int vt_query_set_human_kernel(int threads)
 extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                    int B, int N, const int *labels, const int *order, float w_dfh, float w_part, float *dpts, double *terms, void *stream)
 {
+    if (VT_IS_F32(h)) return f32q::human_loss(h->f32, maps, pts, crop_center, body_center, B, N, labels, order, w_dfh, w_part, dpts, terms, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(labels && dpts && terms, "vt_query_human_loss: null argument");
     a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
@@ -1746,6 +1763,7 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
 extern "C" int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                      int B, int N, int df_idx, float threshold, float *pts_out, float *df_target, void *stream)
 {
+    if (VT_IS_F32(h)) return f32q::project_step(h->f32, maps, pts, crop_center, body_center, B, N, df_idx, threshold, pts_out, df_target, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(pts_out && (df_idx == 0 || df_idx == 1), "vt_query_project_step: pts_out is null or df_idx not in {0 (human), 1 (object)}");
     a.hw[0] = h->head[0]; a.df_idx = df_idx; a.w0 = threshold; a.pts_out = pts_out; a.dft_out = df_target;
@@ -1755,6 +1773,7 @@ extern "C" int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, co
 extern "C" int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                     int B, int N, const float *occ, float w_obj, float *dpts, double *terms, void *stream)
 {
+    if (VT_IS_F32(h)) return f32q::object_loss(h->f32, maps, pts, crop_center, body_center, B, N, occ, w_obj, dpts, terms, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(occ && dpts && terms, "vt_query_object_loss: null argument");
     a.hw[0] = h->head[0]; a.occ = occ; a.w0 = w_obj; a.dpts = dpts; a.terms = terms;

@@ -188,6 +188,27 @@ class FitContext:
         self.jw66 = t(JOINT_WEIGHTS_66)
 
     # ---- shared pieces ----------------------------------------------------------------------------------
+    fp32_fallbacks = 0      # how many fits of this context had to be repeated on the strict-fp32 kernels
+
+    def _with_fp32_fallback(self, params, run):
+        """Run a fit; if the split-f16 decoders produced a non-finite loss (an activation beyond the range of the split operands, |x| >= 1023:
+        DESIGN.md 4.1 -- possible with a real checkpoint, the reference's fp32 Conv1d has no such limit) restore the parameters, switch the
+        network handle to the strict-fp32 kernels (query_f32.hip) and run the fit again.  The handle stays on fp32 afterwards (the same network
+        will overflow again); a loss that is non-finite on the fp32 route too (NaN inputs) still raises."""
+        if self.net is None or self.net.precision == "fp32":
+            return run()
+        saved = [p.clone() for p in params]
+        try:
+            return run()
+        except FloatingPointError as e:
+            import warnings
+            warnings.warn(f"{e}; repeating the fit on the strict-fp32 decoder kernels (5x slower)", RuntimeWarning)
+            for p, s0 in zip(params, saved):
+                p.copy_(s0)
+            self.net.set_precision("fp32")
+            self.fp32_fallbacks += 1
+            return run()
+
     def smpl_forward(self, pose, betas, trans, verts, jtr, vposed, ws):
         _chk(_lib().vt_smplh_forward(self.smpl.h, pose.data_ptr(), betas.data_ptr(), trans.data_ptr(), pose.shape[0], verts.data_ptr(),
                                      jtr.data_ptr(), vposed.data_ptr(), ws.data_ptr(), L.stream_ptr()))
@@ -285,15 +306,16 @@ class FitContext:
         body_kpts) are converted to contiguous float32 on the parameters' device if they are not already (a reference-style driver hands
         over float64 from the dataloader's default collate)."""
         with torch.cuda.device(pose.device):
-            return self._optimize_smpl(maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose,
-                                       iter_for_kpts, it_range, net_size, check_every, prof, early_stop)
+            return self._with_fp32_fallback((pose, betas, trans), lambda: self._optimize_smpl(
+                maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose, iter_for_kpts, it_range, net_size,
+                check_every, prof, early_stop))
 
     def _optimize_smpl(self, maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose, iter_for_kpts,
                        it_range, net_size, check_every, prof, early_stop=True):
         dev = pose.device; B = pose.shape[0]; V = 6890
         _require_params(pose, betas, trans)
         crop_center, body_center, body_kpts = _as_input(crop_center, dev), _as_input(body_center, dev), _as_input(body_kpts, dev)
-        if self.use_projection:
+        if self.use_projection and self.net.precision != "fp32":
             maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale
         names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
         vert_order = self.vert_order
@@ -372,8 +394,9 @@ class FitContext:
         ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``).
         Constant inputs are converted to contiguous float32 on the parameters' device if needed."""
         with torch.cuda.device(obj_R.device):
-            return self._optimize_smpl_object(maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil,
-                                              joint_iter, max_iter, it_range, seed, check_every, prof, early_stop)
+            return self._with_fp32_fallback((obj_R, obj_t), lambda: self._optimize_smpl_object(
+                maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil, joint_iter, max_iter, it_range,
+                seed, check_every, prof, early_stop))
 
     def _optimize_smpl_object(self, maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil,
                               joint_iter, max_iter, it_range, seed, check_every, prof, early_stop=True):
@@ -383,7 +406,7 @@ class FitContext:
         obj_s = obj_s.reshape(-1)
         if noise is not None:
             noise = _as_input(noise, dev)
-        if self.use_projection:
+        if self.use_projection and self.net.precision != "fp32":
             maps.build_projection(self.net)
         names = ["object", "otemp", "ovtemp", "mask", "trans", "contact", "scale"]
         terms = Terms(names, dev)

@@ -29,6 +29,7 @@ class Generator:
         self.sparse_thres, self.filter_val, self.threshold = sparse_thres, filter_val, threshold
         self.sample_num = 100000
         self.model, self.device = model, torch.device(device)
+        self.seed = seed
         self.rng = torch.Generator(device=self.device); self.rng.manual_seed(seed)
         self.pmin, self.pmax = np.array([-3.0, -0.9, 0.2]), np.array([3.0, 1.80, 4.0])
         self.init_others(**kwargs)
@@ -78,13 +79,10 @@ class Generator:
     def get_out_names(self):
         return ["points", "pca_axis", "parts", "centers"]
 
-    def parse_preds(self, batch_size, counts, mask, out_dict, out_names, preds, samples_surface):
-        """collect the near-surface points and their predictions per example (generator.py:118-127); stays on the device"""
-        for i in range(batch_size):
-            out_dict["points"][i].append(samples_surface[i, mask[i]].detach())
-            for name, pred in zip(out_names[1:], preds[1:]):
-                out_dict[name][i].append(pred[i, ..., mask[i]].detach())
-            counts.append(int(mask[i].sum().item()))
+    def reseed(self, key: int):
+        """restart the random stream from (seed, key): the pipeline keys every batch by its first frame, so a batch draws the same samples no matter
+        which rank processes it or what ran before (an N-rank run reproduces the 1-rank run)"""
+        self.rng.manual_seed((int(self.seed) * 1000003 + int(key)) % (2 ** 63 - 1))
 
     def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=True, filter_images=True):
         if filter_images:
@@ -94,41 +92,70 @@ class Generator:
         return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute) for t in ("human", "object")}
 
     def gen_pc_batch(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter=100, mute=True):
-        """iterate: project -> keep points with target < filter_val and z > 1 -> resample 20 000 around the kept points
-        (generator.py:149-212)"""
+        """iterate: project -> keep points with target < filter_val and z > 1 -> resample 20 000 around the kept points (generator.py:149-212).
+
+        The whole batch advances with device-wide tensor ops -- no per-frame Python loop, ONE host synchronisation per round (the loop condition
+        ``min over frames of the number of kept points``):
+          * kept points are compacted with a stable argsort of the mask (kept indices first, in sample order) and appended to per-frame buffers at
+            each frame's fill position (one scatter per output; entries past the capacity go to a trash row -- the reference cuts every frame
+            to the common ``samples_count`` anyway, and samples_count < num_points + 20 000 = the capacity);
+          * resampling draws ``k = floor(U * count_i)`` per new sample, looks the k-th kept index up in the compacted order and adds the Gaussian
+            perturbation; frames with fewer than two kept points restart from the initial grid (0.5 m perturbation) exactly like the reference.
+        Same distributions as the reference's ``torch.randint`` / ``torch.randn`` per frame, one seeded device stream."""
         query_input = self.prep_query_input(batch)
         df_idx = 0 if df_type == "human" else 1
-        batch_size = samples_init.shape[0]
+        dev = self.device
+        B, S0 = samples_init.shape[:2]
         out_names = self.get_out_names()
-        out_dict = {n: [[] for _ in range(batch_size)] for n in out_names}
         sample_num = 20000
+        cap = num_points + max(sample_num, S0)
+        samples_init = samples_init.to(dev)
+        buf = {"points": torch.zeros(B, cap + 1, 3, device=dev)}
+        fill = torch.zeros(B, dtype=torch.long, device=dev)
         it, samples_count = 0, 0
-        samples = samples_init.clone().to(self.device)
+        samples = samples_init.clone()
         while samples_count < num_points:
             samples_surface, preds = self.approx_surface(model, samples, num_steps, query_input, df_type=df_type)
+            S = samples.shape[1]
             df_target = torch.clamp(preds[0][:, df_idx, :], max=self.threshold)
             mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0)
+            cnt = mask.sum(1)                                                  # (B,) kept points per frame
+            order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)  # kept sample indices first, in sample order
+            ar = torch.arange(S, device=dev)[None]
             if it > 0:
-                counts = []
-                self.parse_preds(batch_size, counts, mask, out_dict, out_names, preds, samples_surface)
-                samples_count += int(np.min(counts))
+                dest = fill[:, None] + ar
+                valid = (ar < cnt[:, None]) & (dest < cap)
+                dest = torch.where(valid, dest, torch.full_like(dest, cap))    # everything else lands in the trash row
+                buf["points"].scatter_(1, dest[..., None].expand(B, S, 3), samples_surface.gather(1, order[..., None].expand(B, S, 3)))
+                for name, pred in zip(out_names[1:], preds[1:]):
+                    pr = pred.reshape(B, -1, S).transpose(1, 2)                # (B, S, C)
+                    Cc = pr.shape[2]
+                    if name not in buf:
+                        buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
+                    buf[name].scatter_(1, dest[..., None].expand(B, S, Cc), pr.gather(1, order[..., None].expand(B, S, Cc)))
+                fill = torch.minimum(fill + cnt, torch.full_like(fill, cap))
+                samples_count += int(cnt.min().item())                          # the one host sync of the round
                 if not mute:
                     print(f"{samples_count} points")
-            new = []
-            for i in range(batch_size):
-                s_i = samples[i, mask[i], :]
-                if s_i.shape[0] > 1:
-                    idx = torch.randint(s_i.shape[0], (sample_num,), device=self.device, generator=self.rng)
-                    s_i = s_i[idx] + (self.threshold / 3) * torch.randn(sample_num, 3, device=self.device, generator=self.rng)
-                else:
-                    idx = torch.randint(samples_init.shape[1], (sample_num,), device=self.device, generator=self.rng)
-                    s_i = samples_init[i, idx].to(self.device) + 0.5 * torch.randn(sample_num, 3, device=self.device, generator=self.rng)
-                new.append(s_i.unsqueeze(0))
-            samples = torch.cat(new, 0).detach()
+            # samples of the next round
+            u = torch.rand(B, sample_num, device=dev, generator=self.rng)
+            pert = torch.randn(B, sample_num, 3, device=dev, generator=self.rng)
+            k = torch.minimum((u * cnt[:, None]).long(), (cnt[:, None] - 1).clamp(min=0))
+            near = samples.gather(1, order.gather(1, k)[..., None].expand(B, sample_num, 3)) + (self.threshold / 3) * pert
+            k0 = (u * S0).long().clamp(max=S0 - 1)
+            restart = samples_init.gather(1, k0[..., None].expand(B, sample_num, 3)) + 0.5 * pert
+            samples = torch.where((cnt > 1)[:, None, None], near, restart).detach()
             it += 1
             if it == max_iter:
                 raise RuntimeError(f"point generation for df {df_type} failed after {max_iter} iterations for files: {batch.get('path')}")
-        return self.compose_outdict(batch_size, out_dict, out_names, samples_count, obj_mask=False, query_input=query_input)
+        # hand the buffers over in the reference's per-frame list layout (views, no copies) and let compose_outdict reduce them
+        out_dict = {"points": [[buf["points"][i, :cap]] for i in range(B)]}
+        for name in out_names[1:]:
+            t = buf[name][:, :cap].transpose(1, 2)                             # (B, C, cap)
+            if name == "pca_axis":
+                t = t.reshape(B, 3, 3, cap)
+            out_dict[name] = [[t[i]] for i in range(B)]
+        return self.compose_outdict(B, out_dict, out_names, samples_count, obj_mask=False, query_input=query_input)
 
     def compose_outdict(self, batch_size, out_dict, out_names, samples_count, obj_mask=False, query_input=None):
         """points (B,N,3), parts (B,N) argmax, pca_axis (B,3,3) mean, centers (B,3) mean (generator.py:217-257)"""

@@ -194,6 +194,18 @@ class SifNetHandle:
             L.check(L.lib().vt_sifnet_create(C.byref(h), wp, bp, cam.ctypes.data, L.stream_ptr()))
         self.h = h; self.cam = cam
 
+    PRECISIONS = {"split-f16": 0, "fp32": 1}
+
+    def set_precision(self, mode: str):
+        """'split-f16' (default: 22-bit split operands on the f16 MFMA) or 'fp32' (exact fp32 products on the f32-input MFMA, any activation
+        magnitude, ~1/5 of the speed) for every query call through this handle (vt_sifnet_set_precision)"""
+        L.check(L.lib().vt_sifnet_set_precision(self.h, self.PRECISIONS[mode]))
+        return self
+
+    @property
+    def precision(self) -> str:
+        return {v: k for k, v in self.PRECISIONS.items()}[L.lib().vt_sifnet_get_precision(self.h)]
+
     def __del__(self):
         try:
             if getattr(self, "h", None):

@@ -147,6 +147,7 @@ class SequencePipeline:
         big = {k: torch.empty(T, r, r, c, device=self.device) for k, r, c in MAPSPEC} if resident else None
         for s, e in self._shard(T, cfg.neural_bs):
             batch = {k: v[s:e] for k, v in data.items()}
+            self.generator.reseed(s)            # random stream keyed by the batch's first frame: the same samples on any rank
             bm = None
             if resident:
                 self.net.filter(batch["images"], out={k: t[s:e] for k, t in big.items()})
@@ -170,6 +171,7 @@ class SequencePipeline:
         rows = []
         for s, e in self._shard(T, cfg.fit_bs):
             smpl = SMPLHGenerator.get_smplh(poses[s:e], betas[s:e], trans[s:e], gender, self.device, model_root=self.model_dict)
+            self.generator.reseed(s)
             bm = ops.FeatureMaps({k: t[s:e] for k, t in big.items()}) if resident else None
             pcg = None
             if cfg.reuse_neural:
