@@ -3,6 +3,12 @@ WORLD_SIZE ranks that all use cuda:0 (collectives through gloo on host copies); 
 import os
 import sys
 
+# Library kernels must be CHOSEN the same way in every process: MIOpen's default find mode times candidate convolution algorithms and keeps the
+# fastest, so two processes may run different algorithms (last-bit differences in the feature maps, which the generator's discrete keep/resample
+# decisions amplify into different point clouds).  FAST = heuristic choice, no timing.  rocBLAS: no atomics-based split-K.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+os.environ.setdefault("ROCBLAS_DEFAULT_ATOMICS_MODE", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -15,6 +21,7 @@ from vistracker_amd.pipeline import PipelineConfig         # noqa: E402
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
 torch.cuda.set_device(0)
+torch.backends.cudnn.benchmark = False          # MIOpen: no timing-driven algorithm choice
 if world > 1:
     dist.init_process_group("gloo")
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 150
@@ -25,7 +32,7 @@ out = pipe.run(seq)
 if not dist.is_initialized() or dist.get_rank() == 0:
     rc, st, nn_ = out["recon"], out["smplt_smoothed_fit"], out["neural"]
     np.savez(sys.argv[1], poses=rc["poses"], betas=rc["betas"], trans=rc["trans"], obj_angles=rc["obj_angles"], obj_trans=rc["obj_trans"],
-             smplt_poses=st["poses"], smplt_trans=st["trans"], neural_pca=np.asarray(nn_["neural_pca"]), neural_vis=np.asarray(nn_["neural_visibility"]),
+             smplt_poses=st["poses"], smplt_trans=st["trans"], smplt1_poses=out["smplt"]["poses"], smplt1_trans=out["smplt"]["trans"], neural_pca=np.asarray(nn_["neural_pca"]), neural_vis=np.asarray(nn_["neural_visibility"]),
              fit_steps=np.asarray(pipe.log["fit_steps"]), smplt_steps=np.asarray(pipe.log["smplt_steps"]))
     print("PIPELINE_OK", world, pipe.log["fit_steps"])
 if dist.is_initialized():

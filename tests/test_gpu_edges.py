@@ -210,3 +210,38 @@ def test_empty_object_mask_in_a_batch(synth):
     res = c["ctx"].optimize_smpl_object(c["maps"], cu(c["sverts"]), R, t, torch.ones(B, device="cuda"), cu(c["cc"]), cu(c["bc"]), cu(c["occ"]), sil=sil.setup(),
                                         noise=cu(c["noise"]), iter_for_obj=1, iter_for_sil=1, it_range=(0, 3))
     assert res.steps == 30 and np.isfinite(res.losses).all() and torch.isfinite(R).all() and torch.isfinite(t).all()
+
+
+def test_activation_range_fallback_to_fp32(synth):
+    """Adversarial magnitudes (features x 100, decoder weights x 10): hidden activations leave the range of the split-f16 operands (|x| >= 1023), the
+    split route yields a non-finite loss -- the fit restores its parameters, switches the handle to the strict-fp32 kernels and returns the fp32
+    result (the reference's Conv1d decoders have no such limit, model/chore.py:113-126)."""
+    from oracle import oracle as O
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext
+    from conftest import golden
+    g = golden("smplfit")
+    dec = syn.sifnet_decoders(3, gain=10.0)
+    mp = {k: (100.0 * v).astype(np.float32) for k, v in syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])).items()}
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], dec, synth["labels"], np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32), np.zeros((8, 3), np.float32))
+    maps = ops.FeatureMaps.from_nchw(mp)
+    pts = cu(g["trans"])[:, None, :] + torch.randn(4, 70, 3, device="cuda") * 0.2
+    df = ops.sifnet_query(ctx.net, maps, pts, cu(g["crop_center"]), cu(g["body_center"]), head_mask=1)[0]
+    assert not torch.isfinite(df).all()                                  # the split route overflows on this network ...
+    ctx.net.set_precision("fp32")
+    df32 = ops.sifnet_query(ctx.net, maps, pts, cu(g["crop_center"]), cu(g["body_center"]), head_mask=1)[0]
+    df_o = O.SifNet(dec, mp).query(pts.cpu().numpy(), g["crop_center"], g["body_center"], head_mask=1)[0]
+    assert torch.isfinite(df32).all() and np.abs(df32.cpu().numpy() - df_o).max() < 2e-5 * np.abs(df_o).max()      # ... the fp32 route does not
+    ctx.net.set_precision("split-f16")
+    pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+    with pytest.warns(RuntimeWarning, match="strict-fp32"):
+        res = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
+    assert ctx.fp32_fallbacks == 1 and ctx.net.precision == "fp32" and res.steps == 10 and np.isfinite(res.losses).all()
+    assert torch.isfinite(pose).all() and not torch.equal(trans, cu(g["trans"]))
+    m = O.SmplModel(synth["model"]); b25 = O.Landmarks(synth["regs"]["body25"])
+    total, _, _, _, _ = O.smplfit_loss_and_grad(m, b25, synth["priors"], O.SifNet(dec, mp), synth["labels"], g["pose"], g["betas"], g["trans"], crop_center=g["crop_center"],
+                                                body_center=g["body_center"], body_kpts=g["body_kpts"], pose_init=g["pose"][:, 3:72].copy(), phase="global", decay=1)
+    assert abs(res.losses[0] - total) < 1e-4 * abs(total), (res.losses[0], total)
+    # a second fit on the same context goes straight to fp32: no warning, no repeat
+    res2 = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
+    assert ctx.fp32_fallbacks == 1 and np.isfinite(res2.losses).all()

@@ -39,13 +39,17 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
         f = tmp_path / f"r{n}.npz"
         env = dict(os.environ, MASTER_ADDR="127.0.0.1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               script, str(f), "150"]
+               script, str(f), "100"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
         assert out.returncode == 0 and "PIPELINE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
         outs.append(dict(np.load(f)))
     a, b = outs
-    assert np.array_equal(a["smplt_steps"], b["smplt_steps"]) and np.array_equal(a["fit_steps"], b["fit_steps"])
-    for k in ("smplt_poses", "smplt_trans", "neural_pca", "neural_vis"):
-        assert np.array_equal(a[k], b[k]), k
+    # the step logs are per rank: rank 0 of the 2-rank run holds the first half of the batches of every stage
+    n1 = len(b["smplt_steps"]) // 2; m1 = len(a["smplt_steps"]) // 2
+    assert np.array_equal(a["smplt_steps"][:n1], b["smplt_steps"][:n1]) and np.array_equal(a["smplt_steps"][m1:m1 + n1], b["smplt_steps"][n1:])
+    assert np.array_equal(a["fit_steps"][:len(b["fit_steps"])], b["fit_steps"])
+    diffs = {k: float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max()) for k in a if k not in ("fit_steps", "smplt_steps")}
+    for k in ("smplt1_poses", "smplt1_trans", "smplt_poses", "smplt_trans", "neural_pca", "neural_vis"):
+        assert np.array_equal(a[k], b[k]), (k, diffs[k], int((a[k] != b[k]).sum()), a[k].size)
     worst = {k: float(np.abs(a[k] - b[k]).max()) for k in ("poses", "betas", "trans", "obj_angles", "obj_trans")}
     assert all(v == 0.0 for v in worst.values()), worst

@@ -101,18 +101,24 @@ __device__ __forceinline__ void chunk_info(int i, int &mi, int &co) { const int2
 __device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
 // x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32.  Two elements cost 4 VALU instructions: one packed
 // RTN conversion, two mixed-precision FMAs (v_fma_mix_f32: -hi * 1 + x, reading hi straight from its packed half), one packed conversion.
-__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo)
+// `rmax` tracks max |x| of everything this thread ever splits (one v_max3_f32 per pair): a value beyond the fp16 range would become inf in
+// `hi`, NaN a product later -- and a ReLU (fmaxf(NaN, 0) = 0) would turn that into a FINITE wrong result.  The kernels publish rmax > SPLIT_MAX
+// to the workgroup and poison their outputs with NaN, so the failure is loud (and the host layer falls back to the strict-fp32 kernels).
+#define SPLIT_MAX 65504.0f
+#define OVF_PUBLISH() do { if (rmax > SPLIT_MAX) *sOvf = 1; } while (0)       /* always ahead of the barrier that precedes the readers of *sOvf */
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &lo, float &rmax)
 {
     float r0, r1;
+    rmax = fmaxf(fmaxf(rmax, fabsf(x0)), fabsf(x1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
-__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo, float &rmax)
 {
-    split2(x0, x1, hi.x, lo.x);
-    split2(x2, x3, hi.y, lo.y);
+    split2(x0, x1, hi.x, lo.x, rmax);
+    split2(x2, x3, hi.y, lo.y, rmax);
 }
 
 // Bilinear sampling, split in two so that nothing is recomputed per chunk:
@@ -172,7 +178,7 @@ __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co
 }
 #define TAPSUM_(c_, w_) __builtin_fmaf(se.c_, (w_)[3], __builtin_fmaf(sw.c_, (w_)[2], __builtin_fmaf(ne.c_, (w_)[1], nw.c_ * (w_)[0])))
 // blend the taps to (scaled) features, split, and store into the K-block-major chunk planes [4 kb][64 pt][8 halves] (forward) ...
-__device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> &g, uint2 *hi8, uint2 *lo8, int tid)
+__device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> &g, uint2 *hi8, uint2 *lo8, int tid, float &rmax)
 {
     const int sub = tid & 7, pp = tid >> 3;
 #pragma unroll
@@ -180,7 +186,7 @@ __device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> 
         const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
         const float *w = g.c[0][pass];
         uint2 hi, lo;
-        split4(TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w), hi, lo);
+        split4(TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w), hi, lo, rmax);
         const int idx = (((sub >> 1) * 64 + pp + 32 * pass) << 1) + (sub & 1);
         hi8[idx] = hi; lo8[idx] = lo;
     }
@@ -295,7 +301,7 @@ __device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
             }
 }
 // D fragments (already in operand units) -> split planes [16 kb][64 pt][8 halves] (8-B units)
-__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, int wave, int lane)
+__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, int wave, int lane, float &rmax)
 {
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
@@ -303,7 +309,7 @@ __device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *l
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             uint2 hi, lo;
-            split4(c.v[nt][p][0], c.v[nt][p][1], c.v[nt][p][2], c.v[nt][p][3], hi, lo);
+            split4(c.v[nt][p][0], c.v[nt][p][1], c.v[nt][p][2], c.v[nt][p][3], hi, lo, rmax);
             const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
             hi8[idx] = hi; lo8[idx] = lo;
         }
@@ -350,6 +356,8 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     float *sDf = sInv + G * 64;             // [64] clamped distance of the point (MODE_PROJECT)
     int *sIn = reinterpret_cast<int *>(sDf + 64);   // [64]
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
+    int *sOvf = reinterpret_cast<int *>(sRed + 8);           // [1] some split operand of this workgroup left the fp16 range
+    float rmax = 0.f;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     // XCD-aware block -> (frame, tile) map: the dispatcher places workgroup L on XCD L % 8 (speed only, never correctness), so
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #endif
 
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
+    if (tid == 0) *sOvf = 0;
     if (tid < 64) {
         const int n = min(n0 + tid, a.N - 1);
         const int pn = a.order ? a.order[n] : n;        // a locality-preserving order (FitContext: Morton order of the template) keeps the gathers of a tile in few texels
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     LOAD_W1(C0)
     // software pipeline: the features of chunk ci+1 are blended / split / stored (VALU + LDS stores) in the same barrier interval
     // as the MFMAs of chunk ci, so the two interleave; the taps of chunk ci+2 are requested as soon as the tap registers are free
-    taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512), reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512 + 256), tid);
+    taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512), reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512 + 256), tid, rmax);
     { int mi, co; chunk_info(C0 + 1, mi, co); if (co == 0) taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
     for (int ci = C0; ci < NCHUNK; ci++) {
         uint4 *buf = lds + (ci & 1) * 512, *nbuf = lds + ((ci + 1) & 1) * 512;      // {hi [4 kb][64], lo [4 kb][64]}
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
         // vmcnt retires loads IN ORDER: the weight fragments of the next chunk are requested BEFORE the taps of chunk ci+2, so that
         // waiting for them (top of the next iteration) does not also wait for the far slower gather
-        if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid);
+        if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid, rmax);
         LOAD_W1(ci + 1)
         if (ci + 2 < NCHUNK) {
             int mi, co; chunk_info(ci + 2, mi, co);
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
             if (q == 0) {
                 const float *pp = sPt + (16 * p + j) * 3;
-                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo);
+                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo, rmax);
             }
             xh[p] = make_uint4(hi.x, hi.y, 0u, 0u); xl[p] = make_uint4(lo.x, lo.y, 0u, 0u);
         }
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #pragma unroll
     for (int g = 0; g < G; g++) {
         m1s[g] = bias_relu(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave, lane);
-        store_planes(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane);
+        store_planes(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane, rmax); OVF_PUBLISH();
     }
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
@@ -509,12 +518,12 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         wprefetch(wp, hw.w3p, wave, lane);
         const unsigned m2 = bias_relu(c, hw.b2, hw.cf[1], wave, lane);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
         __syncthreads();
         gemm128(c, Hhi, Hlo, wp, lane);
         const unsigned m3 = bias_relu(c, hw.b3, hw.cf[2], wave, lane);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
         __syncthreads();
         // layer 4 (points as rows): wave w owns the 16 points of tile w, columns = up to 16 outputs (zero padded)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -533,6 +542,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             const bool inimg = (sIn[pt] & 1) != 0;
             const int pn = sIn[pt] >> 1;
             float val = o4[r] * hw.cf[3] + bias4;
+            if (*sOvf) val = __builtin_nanf("");        // an operand left the split range: no silent finite garbage
             go[r] = 0.f;
             if (MODE == MODE_FWD) {
                 if (hw.id == 0 && !inimg) val = OUT_DIST;                       // df[~in_img] = 5.0 (chore_triplane.py:156-159)
@@ -628,18 +638,18 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                 }
         }
         scale_mask(c, hw.cb[3], m3);
-        store_planes(c, Hhi8, Hlo8, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g2 = W3^T . g3
         wprefetch(wq, hw.w2tp, wave, lane);
         scale_mask(c, hw.cb[2], m2);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane);
+        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g1 = W2^T . g2
         scale_mask(c, hw.cb[1], m1);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane);   // the planes now hold d loss' / d (pre-activation 1) of this head
+        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();   // the planes now hold d loss' / d (pre-activation 1) of this head
         __syncthreads();
     }
 
@@ -657,6 +667,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             double s = sRed[tid * 4] + sRed[tid * 4 + 1] + sRed[tid * 4 + 2] + sRed[tid * 4 + 3];
             if (MODE == MODE_HUMAN) s = tid == 0 ? s / ((double)a.B * a.N) : s / (double)a.B;
             else s = s / ((double)a.B * a.N);
+            if (*sOvf) s = (double)__builtin_nanf("");
             if (MODE == MODE_HUMAN || tid == 0) atomicAdd(a.terms + tid, s);
         }
     }
@@ -833,6 +844,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // reduce the channel partials over the 4 lane groups q that share a point
     gx += __shfl_xor(gx, 16, 64); gy += __shfl_xor(gy, 16, 64); gz += __shfl_xor(gz, 16, 64);
     gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+    if (*sOvf) gx = gy = gz = __builtin_nanf("");
     if (q == 0) {
         const int n = n0 + mypt;
         if (n < a.N) {
@@ -979,13 +991,13 @@ __device__ __forceinline__ void scale_mask8(Acc4 &c, float sc, unsigned m)
         }
 }
 // thin-wave D fragments -> split planes [16 kb][64 pt][8 halves]: hidden unit 16 wave8 + 4 q + r -> kb = 2 wave8 + (q >> 1), half (q & 1)
-__device__ __forceinline__ void store_planes8(const Acc4 &c, uint2 *hi8, uint2 *lo8, int wave8, int lane)
+__device__ __forceinline__ void store_planes8(const Acc4 &c, uint2 *hi8, uint2 *lo8, int wave8, int lane, float &rmax)
 {
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         uint2 hi, lo;
-        split4(c.v[p][0], c.v[p][1], c.v[p][2], c.v[p][3], hi, lo);
+        split4(c.v[p][0], c.v[p][1], c.v[p][2], c.v[p][3], hi, lo, rmax);
         const int idx = (((2 * wave8 + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
         hi8[idx] = hi; lo8[idx] = lo;
     }
@@ -1030,6 +1042,8 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     float *sPart = sInv + G * 64;                       // [4][64][3] gradient partials of the four (channel tile, head) waves of a point half
     int *sIn = reinterpret_cast<int *>(sPart + 4 * 64 * 3);  // [64]
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
+    int *sOvf = reinterpret_cast<int *>(sRed + 8);           // [1]
+    float rmax = 0.f;
 
     const int tid = threadIdx.x, wave8 = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int sub = tid & 7, gpt = tid >> 3;            // gather role: 16-byte piece `sub` of the taps of point gpt
@@ -1045,6 +1059,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 #endif
 
     // ---- per-point projections (camera.py:52-90, chore_triplane.py:207-251)
+    if (tid == 0) *sOvf = 0;
     if (tid < 64) {
         const int n = min(n0 + tid, a.N - 1);
         const int pn = a.order ? a.order[n] : n;
@@ -1112,7 +1127,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
         tap1_geom<1, false, true>(a.res[mi_], w8_chan(mi_), uv[w8_proj(mi_)][0], uv[w8_proj(mi_)][1], sub, o_, c_);  \
         const Taps1 &r = tp[((ci_) - C0) % W8_PD];                                                                   \
         uint2 hi_, lo_;                                                                                              \
-        split4(TAP1SUM_(x, c_[0]), TAP1SUM_(y, c_[0]), TAP1SUM_(z, c_[0]), TAP1SUM_(w, c_[0]), hi_, lo_);            \
+        split4(TAP1SUM_(x, c_[0]), TAP1SUM_(y, c_[0]), TAP1SUM_(z, c_[0]), TAP1SUM_(w, c_[0]), hi_, lo_, rmax);            \
         uint2 *hi8_ = reinterpret_cast<uint2 *>(lds + ((ci_) & 1) * 512), *lo8_ = reinterpret_cast<uint2 *>(lds + ((ci_) & 1) * 512 + 256); \
         const int idx_ = (((sub >> 1) * 64 + gpt) << 1) + (sub & 1);                                                 \
         hi8_[idx_] = hi_; lo8_[idx_] = lo_;                                                                          \
@@ -1136,7 +1151,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
             if (q == 0) {
                 const float *pp = sPt + (16 * p + j) * 3;
-                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo);
+                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo, rmax);
             }
             const h8 xh = as_h8(make_uint4(hi.x, hi.y, 0u, 0u)), xl = as_h8(make_uint4(lo.x, lo.y, 0u, 0u));
 #pragma unroll
@@ -1158,7 +1173,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 #pragma unroll
     for (int g = 0; g < G; g++) {
         m1[g] = bias_relu8(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave8, lane);
-        store_planes8(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+        store_planes8(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     }
     __syncthreads();
 
@@ -1170,14 +1185,14 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     for (int g = 0; g < G; g++) { wprefetch8(wp[g], a.hw[g].w3p, wave8, lane); m2[g] = bias_relu8(c[g], a.hw[g].b2, a.hw[g].cf[1], wave8, lane); }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     __syncthreads();
     gemm128x<G>(c, Hp, wp, lane);
 #pragma unroll
     for (int g = 0; g < G; g++) m3[g] = bias_relu8(c[g], a.hw[g].b3, a.hw[g].cf[2], wave8, lane);
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     __syncthreads();
 
     PCLK(4);
@@ -1202,7 +1217,8 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             const bool valid = n < a.N, live = j < hw.kout;
             const bool inimg = (sIn[pt] & 1) != 0;
             const int pn = sIn[pt] >> 1;
-            const float val = o4[r] * hw.cf[3] + bias4;
+            float val = o4[r] * hw.cf[3] + bias4;
+            if (*sOvf) val = __builtin_nanf("");
             go[r] = 0.f;
             if (g4 == 0) {
                 // df_h = clamp(df[:,0], max=.1).mean()  (recon_fit_base.py:640-647); df[~in_img] = 5 (chore_triplane.py:156-159)
@@ -1268,7 +1284,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             c[g].v[p] = MFMAH(as_h8(w4t[g][1]), xh, c[g].v[p]);
         }
         scale_mask8(c[g], a.hw[g].cb[3], m3[g]);
-        store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+        store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     }
     __syncthreads();
     gemm128x<G>(c, Hp, wq, lane);                       // g2 = W3^T . g3
@@ -1276,14 +1292,14 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     for (int g = 0; g < G; g++) { wprefetch8(wq[g], a.hw[g].w2tp, wave8, lane); scale_mask8(c[g], a.hw[g].cb[2], m2[g]); }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     __syncthreads();
     gemm128x<G>(c, Hp, wq, lane);                       // g1 = W2^T . g2
 #pragma unroll
     for (int g = 0; g < G; g++) scale_mask8(c[g], a.hw[g].cb[1], m1[g]);
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane);
+    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
     PCLK(6);
     {   // block-reduce the loss partials (waves 0-3 hold the df term, waves 4-7 the part term)
         double s = loss_acc;
@@ -1294,6 +1310,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     if (tid < 2) {
         double s = sRed[tid * 4] + sRed[tid * 4 + 1] + sRed[tid * 4 + 2] + sRed[tid * 4 + 3];
         s = tid == 0 ? s / ((double)a.B * a.N) : s / (double)a.B;
+        if (*sOvf) s = (double)__builtin_nanf("");
         atomicAdd(a.terms + tid, s);
     }
 
@@ -1454,13 +1471,14 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     if (tid < 64 * 3) {
         const int pt = tid / 3, k = tid - 3 * pt, n = n0 + pt;
         if (n < a.N) {
-            const float s = ((sPart[(0 * 64 + pt) * 3 + k] + sPart[(1 * 64 + pt) * 3 + k]) + sPart[(2 * 64 + pt) * 3 + k]) + sPart[(3 * 64 + pt) * 3 + k];
+            float s = ((sPart[(0 * 64 + pt) * 3 + k] + sPart[(1 * 64 + pt) * 3 + k]) + sPart[(2 * 64 + pt) * 3 + k]) + sPart[(3 * 64 + pt) * 3 + k];
+            if (*sOvf) s = __builtin_nanf("");
             a.dpts[((size_t)b * a.N + (sIn[pt] >> 1)) * 3 + k] = s;
         }
     }
     PCLK(10);
 }
-static size_t lds_bytes_human8() { return 16 * (2 * 2048 + 2 * 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + 2 * 64 + 4 * 64 * 3 + 64) + 8 * sizeof(double); }
+static size_t lds_bytes_human8() { return 16 * (2 * 2048 + 2 * 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + 2 * 64 + 4 * 64 * 3 + 64) + 8 * sizeof(double) + 8; }
 static int launch_human8(const QArgs &a, hipStream_t st)
 {
     const size_t lds = lds_bytes_human8();
@@ -1668,7 +1686,7 @@ extern "C" int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps
 static size_t lds_bytes(int G)
 {
     const size_t r0 = (size_t)G * 2048 > (size_t)1152 + G * 1024 ? (size_t)G * 2048 : (size_t)1152 + G * 1024;
-    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64 + 64) + 8 * sizeof(double);
+    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64 + 64) + 8 * sizeof(double) + 8;
 }
 
 template <int G, int MODE, bool USEP>

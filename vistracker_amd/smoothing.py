@@ -72,9 +72,14 @@ def slide_window_to_sequence(slide_window, window_step, window_size):
     L = (B - 1) * window_step + window_size
     acc = torch.zeros(L, D, device=slide_window.device, dtype=torch.float32)
     cnt = torch.zeros(L, 1, device=slide_window.device, dtype=torch.float32)
-    idx = (torch.arange(B, device=slide_window.device) * window_step).unsqueeze(1) + torch.arange(T, device=slide_window.device).unsqueeze(0)
-    acc.index_add_(0, idx.reshape(-1), slide_window.reshape(-1, D).float())
-    cnt.index_add_(0, idx.reshape(-1), torch.ones(B * T, 1, device=slide_window.device))
+    sw = slide_window.float()
+    # one strided add per position inside the clip: position t of clip b lands on frame b * step + t, so for a fixed t the targets are distinct
+    # -- a fixed summation order (index_add_ accumulates with atomics: last bits differ from run to run, and everything downstream of the
+    # smoothed poses -- renders, encoder, the generator's keep/resample decisions -- amplifies that)
+    span = (B - 1) * window_step + 1
+    for t in range(T):
+        acc[t:t + span:window_step] += sw[:, t]
+        cnt[t:t + span:window_step] += 1.0
     return acc / cnt
 
 
