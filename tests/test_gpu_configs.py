@@ -1,0 +1,79 @@
+"""GPU (-m gpu): BASELINE.json configs[3] and configs[4] exercised AT THEIR WORKLOAD SIZE (bench.py reports their timings as the
+``sifnet_inference`` / ``demo_pipeline`` legs of the bench line):
+  * configs[3]  SIF-Net (tri-vis-l2) inference, batch 16: the four HGFilter encoders on 512 x 512 crops (pinned to the reference module run on
+    CPU at 512 x 512: tools/gen_golden_encoder512.py -> tests/golden/encoder512.npz), one 5-head query of 50 000 samples per frame and the
+    10-step surface projection of the generator;
+  * configs[4]  the demo.sh chain (steps 1-6) with the REFERENCE schedules and batch sizes (SMPL-T bs 512 / 100+30 outer iterations, neural bs 64,
+    joint fit bs 96 with 3000 object points) on a sequence of several joint-fit batches incl. a ragged tail."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_sifnet_inference_at_config3_size(synth):
+    from vistracker_amd import demo_inputs, ops
+    from vistracker_amd.generator import GeneratorTriplaneVis
+    B, N = 16, 50000
+    g = golden("encoder512")
+    S, st = int(g["size"]), int(g["stride"])
+    rng = np.random.default_rng(int(g["seed"]))
+    img0 = rng.uniform(0, 1, (1, 8, S, S)).astype(np.float32); img0[:, 3:] = (img0[:, 3:] > 0.5)      # the generating script's input
+    gen_t = torch.Generator(device="cuda"); gen_t.manual_seed(1)
+    images = torch.rand(B, 8, S, S, device="cuda", generator=gen_t); images[:, 3:] = (images[:, 3:] > 0.5).float()
+    images[0] = torch.as_tensor(img0[0], device="cuda")
+    net = demo_inputs.sifnet(synth["decoders"])
+    net.filter(images)
+    for name, t, c, r in zip(ops.MAP_ORDER, net.maps.t, ops.MAP_CHANNELS, (128, 256, 256, 256, 256, 128, 128, 128)):
+        assert tuple(t.shape) == (B, r, r, c) and bool(torch.isfinite(t).all()), name
+        ref = g[name][0].transpose(1, 2, 0)                                # (h/8, w/8, C) slice of the reference's NCHW output of frame 0
+        got = t[0, ::st, ::st].cpu().numpy()
+        e = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        assert e < 2e-4, (name, e)                                         # fp32 convolutions, MIOpen vs CPU summation order (same bar as the 64 x 64 test)
+    # a batch of 16 is encoded in one 16-frame chunk: frame 0 alone gives the same maps
+    net1 = demo_inputs.sifnet(synth["decoders"]); net1.filter(images[:1])
+    assert all(torch.allclose(a[0], b[0], atol=1e-5, rtol=1e-5) for a, b in zip(net.maps.t, net1.maps.t))
+    # one 5-head query of 50 000 grid samples per frame
+    bc = torch.tensor([[0.0, 0.0, 2.2]] * B, device="cuda"); cc = torch.tensor([[1018.952, 779.486]] * B, device="cuda")
+    gen = GeneratorTriplaneVis(net, "x", seed=1)
+    pts = gen.get_grid_samples(N, B, bc)
+    net.query(pts, crop_center=cc, body_center=bc)
+    df, pca, parts, centers, vis = net.get_preds()
+    assert df.shape == (B, 2, N) and pca.shape == (B, 3, 3, N) and parts.shape == (B, 14, N) and centers.shape == (B, 3, N) and vis.shape == (B, 1, N)
+    assert all(bool(torch.isfinite(x).all()) for x in (df, pca, parts, centers, vis)) and bool(((vis > 0) & (vis < 1)).all())
+    px = 979.7844 * pts[..., 0] / pts[..., 2] + 1018.952 - cc[:, :1]
+    out_img = (px.abs() > 600.5)                                           # clearly outside the 1200-px crop
+    assert bool((df[:, 0][out_img] == 5.0).all()) and int(out_img.sum()) > 0
+    # per-point results do not depend on what else is in the launch: a 3000-point slice queried alone
+    net.query(pts[:, 1000:4000].contiguous(), crop_center=cc, body_center=bc)
+    df_s = net.get_preds()[0]
+    assert torch.equal(df_s, df[:, :, 1000:4000])
+    # the generator's 10-step surface projection at this size moves the samples towards the predicted surface
+    q = {"crop_center": cc, "body_center": bc}
+    surf, preds = gen.approx_surface(net, pts, 10, q, "object")
+    assert surf.shape == pts.shape and bool(torch.isfinite(surf).all())
+    before = torch.clamp(df[:, 1], max=gen.threshold).mean().item(); after = torch.clamp(preds[0][:, 1], max=gen.threshold).mean().item()
+    assert after < before, (before, after)
+
+
+def test_demo_pipeline_reference_schedules(synth):
+    """scripts/demo.sh steps 1-6 with the reference's batch sizes and schedules on 200 frames = joint-fit batches of 96 + 96 + 8 frames."""
+    from vistracker_amd import demo_inputs
+    from vistracker_amd.pipeline import PipelineConfig
+    T = 200
+    pipe, assets = demo_inputs.pipeline(PipelineConfig(), n_obj_points=3000, assets=synth)
+    seq = demo_inputs.sequence(T, assets)
+    out = pipe.run(seq)
+    rc = out["recon"]
+    assert rc["poses"].shape == (T, 156) and rc["obj_angles"].shape == (T, 3, 3) and all(np.isfinite(rc[k]).all() for k in ("poses", "betas", "trans", "obj_angles", "obj_trans"))
+    R = np.asarray(rc["obj_angles"]); assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+    steps = pipe.log["fit_steps"]
+    assert len(steps) == 3                                                  # 96 + 96 + 8 frames
+    # reference stop rules: armed after it > 27 (SMPL stage: >= 280 steps) and in phase 'joint' from it >= 45 (object stage: >= 450 steps)
+    assert all(280 <= a <= 1030 and 450 <= b <= 1550 for a, b in steps), steps
+    assert len(pipe.log["smplt_steps"]) == 2 and pipe.log["smplt_steps"][0] > 300          # one 200-frame batch per SMPL-T stage: 100 / 30 outer iterations allowed
+    sec = pipe.log["seconds"]
+    print("stage seconds:", {k: round(v, 2) for k, v in sec.items()}, steps)
