@@ -194,3 +194,27 @@ def test_generator_round_logic_on_cpu():
     assert torch.equal(out2["points"], out["points"])
     g2.reseed(96); a = torch.rand(3, generator=g2.rng); g2.reseed(96); b = torch.rand(3, generator=g2.rng); g2.reseed(192); c = torch.rand(3, generator=g2.rng)
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_sequence_io_helpers(tmp_path):
+    """path / crop helpers of the sequence-folder IO (data/base_data.py:139-233, behave DataPaths): no GPU"""
+    from vistracker_amd import sequence_io as S
+    f = "/data/behave/Date03_Sub03_chairwood/t0021.000/k1.color.jpg"
+    assert S.kinect_id(f) == 1 and S.seq_and_frame(f) == ("Date03_Sub03_chairwood", "t0021.000")
+    m1 = np.zeros((100, 200), np.uint8); m1[10:20, 30:40] = 255
+    m2 = np.zeros((100, 200), np.uint8); m2[50:70, 100:150] = 200
+    bmin, bmax = S.masks2bbox([m1, m2])
+    assert bmin.tolist() == [30, 10] and bmax.tolist() == [150, 70]
+    assert S.masks2bbox([np.zeros((4, 4), np.uint8)])[1].tolist() == [-100.0, -100.0]
+    img = np.arange(100 * 200, dtype=np.float32).reshape(100, 200)
+    c = S.crop(img, np.array([10, 5]), 40)                       # hangs over the top-left corner: zero padded
+    assert c.shape == (40, 40) and c[0, 0] == 0 and c[15, 10] == img[0, 0] and c[39, 39] == img[24, 29]
+    c3 = S.crop(np.ones((100, 200, 3), np.uint8), np.array([195, 95]), 40)
+    assert c3.shape == (40, 40, 3) and c3[0, 0, 0] == 1 and c3[39, 39, 0] == 0
+    r = S.resize_bilinear(np.full((1200, 1200), 7.0, np.float32), 512)
+    assert r.shape == (512, 512) and np.allclose(r, 7.0)
+    ramp = np.tile(np.arange(8, dtype=np.float32), (8, 1))
+    assert np.allclose(S.resize_bilinear(ramp, 4)[0], [0.5, 2.5, 4.5, 6.5])      # half-pixel centres, no anti-aliasing (cv2.INTER_LINEAR)
+    for i in range(3):
+        os.makedirs(tmp_path / "seq" / f"t000{i}.000")
+    assert [os.path.basename(x) for x in S.frame_folders(str(tmp_path / "seq"))] == ["t0000.000", "t0001.000", "t0002.000"]
