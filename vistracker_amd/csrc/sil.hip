@@ -57,6 +57,7 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
 
 // workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
 // x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2) fp64 (order-insensitive atomics)
+#define SIL_FIX 17179869184.0      /* 2^34: fixed-point unit of the backward accumulators */
 struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; };
 static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
 {
@@ -279,8 +280,11 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const float g = wave_sum(acc[k][c]);
-            // fp64 accumulation: the per-vertex sum over its faces no longer depends (to fp32 precision) on the order the waves arrive
-            if (lane == 0 && g != 0.f) atomicAdd(gproj + ((size_t)b * NV + vi[k]) * 2 + c, (double)g);
+            // FIXED-POINT accumulation (2^-34 units in a 64-bit integer, |sum| < 5e8): integer addition is associative, so the per-vertex sum over
+            // its faces is bit-identical whatever order the waves arrive in.  (fp64 atomics left a ~2^-29 chance per value that two runs round to
+            // different floats -- enough, over 300 'sil' steps, to make one run in ten drift from another through Adam's amplification.)
+            if (lane == 0 && g != 0.f)
+                atomicAdd(reinterpret_cast<unsigned long long *>(gproj) + ((size_t)b * NV + vi[k]) * 2 + c, (unsigned long long)__double2ll_rn((double)g * SIL_FIX));
         }
 }
 
@@ -290,7 +294,8 @@ __global__ void sil_unproject_kernel(const float *__restrict__ verts, const floa
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= NV) return;
     const float *v = verts + ((size_t)b * NV + i) * 3, *k = K + 9 * b;
-    const float z = v[2] + 1e-9f, gu = (float)gproj[((size_t)b * NV + i) * 2], gv = (float)gproj[((size_t)b * NV + i) * 2 + 1];
+    const long long *gq = reinterpret_cast<const long long *>(gproj);
+    const float z = v[2] + 1e-9f, gu = (float)((double)gq[((size_t)b * NV + i) * 2] * (1.0 / SIL_FIX)), gv = (float)((double)gq[((size_t)b * NV + i) * 2 + 1] * (1.0 / SIL_FIX));
     const float gx_ = 2.f * gu * k[0] - 2.f * gv * k[3], gy_ = 2.f * gu * k[1] - 2.f * gv * k[4];
     float *o = dverts + ((size_t)b * NV + i) * 3;
     o[0] = gx_ / z; o[1] = gy_ / z; o[2] = -(gx_ * v[0] + gy_ * v[1]) / (z * z);

@@ -202,7 +202,7 @@ class ReconFolderSource:
         dev = self.fitter.device
         kp = self.load_kpts([p.replace(".color.jpg", ".color.json") for p in data["path"]]).to(dev)
         f = lambda k: torch.as_tensor(data[k]).to(dev)
-        return self.fitter.scale_body_kpts(kp, f("resize_scale"), f("crop_scale"), f("old_crop_center")).float()
+        return self.fitter.scale_body_kpts(kp, f("resize_scale"), f("crop_scale"), f("old_crop_center")).float().cpu().numpy()
 
     # -- outputs (recon_fit_base.py:260-313, 830-844; opt_utils.py:126-141)
     def get_output_paths(self, image_paths):
