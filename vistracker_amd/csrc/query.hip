@@ -333,6 +333,18 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
 }
 
+// Compile-time interleave of the MFMAs of one chunk with the independent VALU work of the next (blend / split of the taps): left to itself
+// hipcc issues the 24 G MFMAs of a K32 step back to back (the wave then waits 16 cycles per MFMA with empty VALU slots) and the ~100 VALU
+// instructions of the blend afterwards (with an idle matrix pipe).  MEASURED: no effect (2.033 vs 2.039 ms per launch of the SMPL-stage kernel; the
+// ISA does interleave 1 MFMA : 2 VALU) -- the second workgroup's wave on the SIMD already fills those slots.  Off by default, -DQ_SGB=1 to repeat.
+#ifndef Q_SGB
+#define Q_SGB 0
+#endif
+#if Q_SGB
+#define SCHED_MFMA_VALU(n_, v_) _Pragma("unroll") for (int i_ = 0; i_ < (n_); i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (v_), 0); }
+#else
+#define SCHED_MFMA_VALU(n_, v_)
+#endif
 // per-phase shader-clock breakdown (debug builds with -DPHASE_CLK only; tools/bench_scripts/qphase.py)
 #ifdef PHASE_CLK
 __device__ unsigned long long g_phase[16];
@@ -460,6 +472,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         // vmcnt retires loads IN ORDER: the weight fragments of the next chunk are requested BEFORE the taps of chunk ci+2, so that
         // waiting for them (top of the next iteration) does not also wait for the far slower gather
         if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid, rmax);
+        SCHED_MFMA_VALU(24 * G, 2)
         LOAD_W1(ci + 1)
         if (ci + 2 < NCHUNK) {
             int mi, co; chunk_info(ci + 2, mi, co);
@@ -777,6 +790,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wl[g][0], xh[g], dd[g][0]); dd[g][1] = MFMAH(wl[g][1], xh[g], dd[g][1]); }
         }
         taps_store_grad(tp, tgb, bu, bv, tid);
+        SCHED_MFMA_VALU(24 * G, 2)
         __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
         // read this point's tap differences FIRST, then start the DMA of the next slab: hipcc orders an LDS read after an LDS-DMA
         // with a full vmcnt(0) wait (they may alias), which put the whole DMA latency in front of the epilogue
