@@ -227,6 +227,20 @@ int vt_sqdiff_loss(const float *a, int a_stride, const float *b, int b_stride, i
                    float gscale, double *term, float *da, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Human / object interpenetration ("collide", weight 3^2 / (1 + decay) in phase 'joint').  Replaces RegistrationBase.smpl_obj_collision /
+ * compute_collision_loss (recon/recon_fit_base.py:97-100,736-765; recon_fit_trivis_full.py:260-264): mesh_intersection's BVH(max_collisions=8)
+ * + DistanceFieldPenetrationLoss(sigma=0.5, point2plane=False) -- un-vendored, PARITY UNPINNED, restated from Tzionas et al. 2016.
+ * smpl_verts (B,NVs,3), smpl_faces (NFs,3) int32, obj_verts (B,NVo,3) = the TRANSFORMED template, obj_faces (NFo,3) int32, all device.
+ * *term += mean over frames of the penetration of the human-object triangle pairs (first max_collisions colliding SMPL faces per object face);
+ * d_obj_t (B,3) += gscale * d value / d(object translation)  (the parameter phase 'joint' optimises; NULL to skip);
+ * pairs_per_frame (B) int32 device, optional.  workspace: vt_collision_workspace_bytes(B, NFs) bytes, 8-byte aligned.
+ * ------------------------------------------------------------------------------------------------- */
+long vt_collision_workspace_bytes(int B, int n_smpl_faces);
+int vt_collision_loss(const float *smpl_verts, int n_smpl_verts, const int *smpl_faces, int n_smpl_faces, const float *obj_verts, int n_obj_verts,
+                      const int *obj_faces, int n_obj_faces, int B, float sigma, int max_collisions, float gscale, double *term,
+                      float *d_obj_t, int *pairs_per_frame, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Ragged contact Chamfer.  Replaces pytorch3d.loss.chamfer_distance(Pointclouds, Pointclouds)[0]
  * (recon/recon_fit_trivis_full.py:454-457; pytorch3d defaults, see DESIGN.md "unpinned").
  * x (nx_total,3), y (ny_total,3), offx/offy (P+1) int32 device.  *term += value.

@@ -391,7 +391,7 @@ def smplt_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, pose, bet
 # weights of ReconFitterTriVisFull.get_loss_weights (recon_fit_trivis_full.py:124-153): c * cst / (1 + decay)
 FIT_WEIGHTS = {"pose": 1e-5, "hand": 1e-5, "j2d": 0.09, "object": 900.0, "part": 0.0025, "contact": 900.0,
                "scale": 100.0, "df_h": 100.0, "mask": 0.0009, "ocent": 0.0, "pinit": 25.0, "rot": 100.0,
-               "trans": 100.0, "stemp": 10000.0, "otemp": 225.0, "ovtemp": 2500.0}
+               "trans": 100.0, "stemp": 10000.0, "otemp": 225.0, "ovtemp": 2500.0, "collide": 9.0}
 
 
 def smplfit_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, net: SifNet, part_labels, pose, betas, trans,
@@ -514,11 +514,30 @@ def objfit_loss_and_grad(net: SifNet, obj_points, obj_R, obj_t, obj_s, noise, cr
                 terms["contact"] = val
                 for k, (b, ih, io) in enumerate(sel):
                     np.add.at(dX[b], io, gy[offy[k]:offy[k + 1]])
+    if phase == "joint" and extra is not None and extra.get("collide") is not None:
+        # prevent interpenetration (recon_fit_trivis_full.py:260-264; PARITY UNPINNED)
+        c = extra["collide"]
+        Vc = rigid(c["verts"], R, obj_t, obj_s)
+        val, gdt, _ = collision_loss(extra["smpl_verts"], c["smpl_faces"], Vc, c["faces"], 0.5, 8, w["collide"])
+        terms["collide"] = val
+        dt += gdt
     gR, gt = rigid_bwd(obj_points, R, obj_t, obj_s, dX)
     dR += gR; dt += gt
     dM = so3_project_bwd(M, dR)
     total = sum(w[k] * terms[k] for k in terms)
     return total, terms, dM, dt
+
+
+def collision_loss(smpl_verts, smpl_faces, obj_verts, obj_faces, sigma=0.5, max_coll=8, gscale=0.0):
+    """RegistrationBase.smpl_obj_collision (recon/recon_fit_base.py:736-765) -- PARITY UNPINNED (mesh_intersection): mean over frames of the conic
+    distance-field penetration of the human-object triangle pairs; returns (value, d value / d obj_t * gscale (B,3), pairs per frame)."""
+    sv, svp = _f(smpl_verts); ov, ovp = _f(obj_verts)
+    sf = np.ascontiguousarray(smpl_faces, np.int32); of = np.ascontiguousarray(obj_faces, np.int32)
+    B = sv.shape[0]; dt = np.zeros((B, 3), np.float32); npairs = np.zeros(B, np.int32)
+    fn = lib().vto_collision_loss; fn.restype = C.c_double
+    val = fn(svp, C.c_int(sv.shape[1]), sf.ctypes.data_as(C.c_void_p), C.c_int(len(sf)), ovp, C.c_int(ov.shape[1]), of.ctypes.data_as(C.c_void_p), C.c_int(len(of)),
+             C.c_int(B), C.c_float(sigma), C.c_int(max_coll), C.c_float(gscale), _fp(dt), npairs.ctypes.data_as(C.c_void_p))
+    return float(val), dt, npairs
 
 
 def contact_pairs(df_hum_o, df_obj_h, parts_obj, part_labels, thres=0.08):

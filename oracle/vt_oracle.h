@@ -70,4 +70,7 @@ int vto_num_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* A21 interpenetration term (PARITY UNPINNED: mesh_intersection is un-vendored): returns mean_b P_b; dt (B,3) += gscale / B dP_b/dt; npairs (B) */
+double vto_collision_loss(const float *sv, int NVs, const int *sf, int NFs, const float *ov, int NVo, const int *of, int NFo, int B, float sigma,
+                          int max_coll, float gscale, float *dt, int *npairs);
 #endif

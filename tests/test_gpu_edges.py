@@ -245,3 +245,79 @@ def test_activation_range_fallback_to_fp32(synth):
     # a second fit on the same context goes straight to fp32: no warning, no repeat
     res2 = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
     assert ctx.fp32_fallbacks == 1 and np.isfinite(res2.losses).all()
+
+
+def _collision_case(synth, B=3, seed=4):
+    """an object template pushed half-way into the SMPL body of every frame"""
+    from oracle import oracle as O
+    from vistracker_amd import synthetic as syn
+    rng = np.random.default_rng(seed)
+    seq = syn.sequence_params(B, seed=5)
+    m = O.SmplModel(synth["model"]); sverts, jtr, _ = m.forward(seq["pose"], seq["betas"], seq["trans"])
+    ov, of = syn.object_template()
+    R = syn.random_rotations(B, rng)
+    t = (jtr[:, 3] + rng.normal(0, 0.03, (B, 3)) + [0.25, 0.0, 0.0]).astype(np.float32)          # around a torso joint
+    Vo = (np.einsum("nc,bcd->bnd", 0.5 * ov, R) + t[:, None]).astype(np.float32)
+    return sverts.astype(np.float32), np.asarray(synth["model"]["f"]).astype(np.int32), Vo, of.astype(np.int32)
+
+
+def test_collision_term_vs_oracle(synth):
+    """vt_collision_loss (A21; PARITY UNPINNED: mesh_intersection) against the independent CPU restatement -- double precision, separating-axis
+    triangle test, brute-force pairs, central-difference gradient: same pair counts up to borderline triangle pairs, value and d/dt to 1e-3."""
+    from oracle import oracle as O
+    from vistracker_amd import ops
+    sv, sf, Vo, of = _collision_case(synth)
+    val_o, dt_o, np_o = O.collision_loss(sv, sf, Vo, of, 0.5, 8, 1.0)
+    val, dt, npairs = ops.collision_loss(cu(sv), cu(sf), cu(Vo), cu(of), 0.5, 8, 1.0, want_pairs=True)
+    npairs = npairs.cpu().numpy()
+    assert np_o.sum() > 200 and np.abs(npairs - np_o).max() <= max(2, 0.01 * np_o.max()), (npairs, np_o)
+    assert val_o > 0 and abs(val.item() - val_o) < 2e-3 * val_o, (val.item(), val_o)
+    assert np.abs(dt.cpu().numpy() - dt_o).max() < 5e-3 * np.abs(dt_o).max(), (dt.cpu().numpy(), dt_o)
+    # bit-reproducible (fixed-point accumulation), zero for meshes that do not touch, linear in gscale
+    val2, dt2 = ops.collision_loss(cu(sv), cu(sf), cu(Vo), cu(of), 0.5, 8, 1.0)
+    assert torch.equal(val, val2) and torch.equal(dt, dt2)
+    far = Vo + np.float32(5.0)
+    v0, d0, n0 = ops.collision_loss(cu(sv), cu(sf), cu(far), cu(of), 0.5, 8, 1.0, want_pairs=True)
+    assert v0.item() == 0.0 and float(d0.abs().max()) == 0.0 and int(n0.sum()) == 0
+    _, dt3 = ops.collision_loss(cu(sv), cu(sf), cu(Vo), cu(of), 0.5, 8, 3.0)
+    assert torch.allclose(dt3, 3.0 * dt, rtol=1e-5, atol=1e-9)
+    # max_collisions caps the pairs of an object face
+    _, _, n2 = ops.collision_loss(cu(sv), cu(sf), cu(Vo), cu(of), 0.5, 2, 1.0, want_pairs=True)
+    assert int(n2.sum()) < int(npairs.sum()) and int(n2.max()) <= 2 * len(of)
+
+
+def test_joint_phase_with_collision_term_vs_oracle(synth):
+    """phase 'joint' with the host-gated interpenetration term switched on: 10 Adam steps on the translation vs the oracle stepping the same
+    objective ('collide' weight 3^2 / (1 + decay), recon_fit_trivis_full.py:139,260-264)."""
+    from oracle import oracle as O
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext
+    B, N = 4, 500
+    rng = np.random.default_rng(3)
+    ov, of = syn.object_template(); ov = (0.5 * ov).astype(np.float32); pts = syn.sample_surface(ov, of, N, seed=3)
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], ov, of, pts)
+    ctx.collision_loss = True
+    mp = syn.feature_maps(B, 31, res_scale=1 / 8, smooth=4)
+    seq = syn.sequence_params(B, seed=5)
+    m = O.SmplModel(synth["model"]); sverts, jtr, _ = m.forward(seq["pose"], seq["betas"], seq["trans"])
+    cc = np.tile(np.array([[1018.952, 779.486]], np.float32), (B, 1)); bc = seq["trans"].copy(); occ = seq["occ_ratios"].astype(np.float32)
+    R0 = syn.random_rotations(B, rng).astype(np.float32); t0 = (jtr[:, 3] + [0.22, 0.0, 0.0]).astype(np.float32)
+    noise = rng.uniform(0, 1, (10, B, 3, 3)).astype(np.float32); sc = np.ones(B, np.float32)
+    maps = ops.FeatureMaps.from_nchw(mp)
+    R, t = cu(R0.copy()), cu(t0.copy())
+    res = ctx.optimize_smpl_object(maps, cu(sverts), R, t, torch.ones(B, device="cuda"), cu(cc), cu(bc), cu(occ), noise=cu(noise), iter_for_obj=0, iter_for_sil=0,
+                                   it_range=(0, 1))
+    assert res.steps == 10 and torch.equal(R, cu(R0))                    # phase 'joint' moves the translation only
+    net = O.SifNet(synth["decoders"], mp); cpts = ctx.obj_points.cpu().numpy()
+    Ro, to = R0.copy(), t0.copy(); opt = O.Adam([to], 0.002); losses = []; extra = None
+    for i in range(10):
+        if extra is None:
+            X = O.rigid(cpts, O.so3_project((Ro + np.float32(1e-4) * noise[0]).astype(np.float32)), to, sc)
+            df_o, _, parts_o, _, _ = net.query(X, cc, bc); df_h = net.query(sverts, cc, bc)[0]
+            extra = {"smpl_verts": sverts, "df_hum_o": df_h[:, 1], "df_obj_h": df_o[:, 0], "parts_obj": parts_o.argmax(1), "part_labels": synth["labels"],
+                     "collide": {"verts": ov, "faces": of, "smpl_faces": np.asarray(synth["model"]["f"]).astype(np.int32)}}
+        total, terms, dM, dt = O.objfit_loss_and_grad(net, cpts, Ro, to, sc, noise[i], cc, bc, occ, np.zeros((B, 3), np.float32), "joint", (0 - 0 + 1) / 3, extra)
+        losses.append(total); opt.step([dt])
+    assert terms["collide"] > 0
+    assert np.abs(res.losses[:10] - np.array(losses)).max() < 2e-3 * np.abs(losses).max(), (res.losses[:10], losses)
+    assert np.abs(t.cpu().numpy() - to).max() < 1e-3

@@ -69,6 +69,8 @@ SIGNATURES = {
     "vt_kpts_loss": (ci, [fp, fp, fp, ci, ci, ci, vp, cf, cf, fp, fp, vp]),
     "vt_sqdiff_loss": (ci, [fp, ci, fp, ci, ci, ci, cf, cf, fp, fp, vp]),
     "vt_chamfer_ragged": (ci, [fp, fp, fp, fp, ci, cf, fp, fp, fp, vp]),
+    "vt_collision_workspace_bytes": (cl, [ci, ci]),
+    "vt_collision_loss": (ci, [fp, ci, fp, ci, fp, ci, fp, ci, ci, cf, ci, cf, fp, fp, fp, fp, vp]),
     "vt_nn_distance": (ci, [fp, ci, fp, ci, ci, fp, vp]),
     "vt_sil_workspace_floats": (cl, [ci, ci, ci, ci]),
     "vt_sil_forward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, vp]),

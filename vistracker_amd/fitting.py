@@ -24,7 +24,7 @@ from . import ops
 # c * cst / (1 + decay) -- ReconFitterTriVisFull.get_loss_weights (recon_fit_trivis_full.py:124-153)
 FIT_WEIGHTS = {"pose": 1e-5, "hand": 1e-5, "j2d": 0.09, "object": 900.0, "part": 0.0025, "contact": 900.0, "scale": 100.0,
                "df_h": 100.0, "mask": 0.0009, "ocent": 0.0, "pinit": 25.0, "rot": 100.0, "trans": 100.0,
-               "stemp": 10000.0, "otemp": 225.0, "ovtemp": 2500.0}
+               "stemp": 10000.0, "otemp": 225.0, "ovtemp": 2500.0, "collide": 9.0}
 # SMPLHFitter30fps.get_loss_weights (fit_SMPLH_30fps.py:55-66); BaseFitter uses pinit 100 (fit_SMPLH_kpts.py:57-65)
 SMPLT_WEIGHTS = {"pose": 1e-5, "hand": 1e-5, "kpts": 0.09, "temp": 900.0, "ptemp": 25.0, "pinit": 900.0}
 # joint_weights of compute_Jaccel_loss (fit_SMPLH_30fps.py:26-51)
@@ -163,6 +163,9 @@ class FitContext:
     use_projection = True
     sort_object_points = True
     sort_query_points = True
+    # human / object interpenetration term of phase 'joint' (recon_fit_base.py:736-765).  The reference computes it only on two machines of its
+    # authors' cluster (hostname test, recon_fit_base.py:106); off here too unless switched on.
+    collision_loss = False
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -185,6 +188,7 @@ class FitContext:
             # (L2 hits instead of HBM round trips in the gather: -6 % on the object-stage query kernel)
             obj_points = np.asarray(obj_points, np.float32)[morton_order(obj_points)]
         self.obj_verts = t(obj_verts); self.obj_faces = t(obj_faces, torch.int32); self.obj_points = t(obj_points)
+        self.smpl_faces = t(np.asarray(smpl_model["f"]).astype(np.int32), torch.int32) if "f" in smpl_model else None
         self.jw66 = t(JOINT_WEIGHTS_66)
 
     # ---- shared pieces ----------------------------------------------------------------------------------
@@ -408,7 +412,7 @@ class FitContext:
             noise = _as_input(noise, dev)
         if self.use_projection and self.net.precision != "fp32":
             maps.build_projection(self.net)
-        names = ["object", "otemp", "ovtemp", "mask", "trans", "contact", "scale"]
+        names = ["object", "otemp", "ovtemp", "mask", "trans", "contact", "collide", "scale"]
         terms = Terms(names, dev)
         total = joint_iter + iter_for_obj + max_iter + iter_for_sil
         start, end = it_range if it_range is not None else (0, total)
@@ -426,7 +430,7 @@ class FitContext:
             fidx = torch.empty(B, sil.size, sil.size, dtype=torch.int32, device=dev)
             sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0], sil.size), device=dev)
             dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
-        adam = None; res = FitResult(); contact = None; trans_init = None
+        adam = None; res = FitResult(); contact = None; trans_init = None; cws = None; Vc = None
         # 'scale' = mean((obj_s - 1)^2) (recon_fit_trivis_full.py:161,227): obj_s is never optimised, so the term is a constant of the call
         # -- zero for the obj_s == 1 that fit_recon passes -- but it is part of the summed loss the stop rule looks at
         ones = torch.ones_like(obj_s)
@@ -451,7 +455,7 @@ class FitContext:
             for i in range(10):
                 k = (it - start) * 10 + i
                 nz = noise[k]
-                terms.zero(0, 6)
+                terms.zero(0, 7)
                 _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
                 _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
                 acc = 0
@@ -488,6 +492,15 @@ class FitContext:
                                                       contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), L.stream_ptr()))
                         dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
                 _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
+                if phase == "joint" and self.collision_loss:
+                    # prevent interpenetration (recon_fit_trivis_full.py:260-264): SMPL mesh vs the transformed object template
+                    if cws is None:
+                        Vc = torch.empty(B, NV, 3, device=dev)
+                        cws = torch.empty((_lib().vt_collision_workspace_bytes(B, self.smpl_faces.shape[0]) + 7) // 8, dtype=torch.int64, device=dev)
+                    _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vc.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_collision_loss(smpl_verts.data_ptr(), smpl_verts.shape[1], self.smpl_faces.data_ptr(), self.smpl_faces.shape[0], Vc.data_ptr(), NV,
+                                                  self.obj_faces.data_ptr(), self.obj_faces.shape[0], B, 0.5, 8, float(w[6]), terms.ptr("collide"), dt.data_ptr(), None,
+                                                  cws.data_ptr(), L.stream_ptr()))
                 _chk(_lib().vt_so3_project_backward(obj_R.data_ptr(), nz.data_ptr(), B, dR.data_ptr(), dM.data_ptr(), L.stream_ptr()))
                 adam.step()
                 _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(early_stop and phase == "joint" and it > 0.25 * max_iter),

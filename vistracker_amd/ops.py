@@ -423,6 +423,23 @@ def chamfer_ragged(x, y, offx, offy):
 
 
 # --------------------------------------------------------------------------------------------------
+# human / object interpenetration (host-gated off in the reference; PARITY UNPINNED: mesh_intersection)
+# --------------------------------------------------------------------------------------------------
+def collision_loss(smpl_verts, smpl_faces, obj_verts, obj_faces, sigma=0.5, max_collisions=8, gscale=0.0, want_pairs=False):
+    """RegistrationBase.smpl_obj_collision (recon_fit_base.py:736-765) on transformed object vertices: returns (value, d value / d obj_t * gscale (B,3))
+    [+ colliding pairs per frame].  No autograd graph: the gradient w.r.t. the object translation is what phase 'joint' needs."""
+    sv, ov = _f32(smpl_verts), _f32(obj_verts)
+    sf = smpl_faces.to(torch.int32).contiguous(); of = obj_faces.to(torch.int32).contiguous()
+    B = sv.shape[0]; dev = sv.device
+    ws = torch.empty((L.lib().vt_collision_workspace_bytes(B, sf.shape[0]) + 7) // 8, dtype=torch.int64, device=dev)
+    term = torch.zeros(1, dtype=torch.float64, device=dev); dt = torch.zeros(B, 3, device=dev)
+    npairs = torch.zeros(B, dtype=torch.int32, device=dev) if want_pairs else None
+    L.check(L.lib().vt_collision_loss(L.dptr(sv), sv.shape[1], L.dptr(sf), sf.shape[0], L.dptr(ov), ov.shape[1], L.dptr(of), of.shape[0], B, float(sigma),
+                                      int(max_collisions), float(gscale), L.dptr(term), L.dptr(dt), L.dptr(npairs), L.dptr(ws), L.stream_ptr()))
+    return (term.float().reshape(()), dt, npairs) if want_pairs else (term.float().reshape(()), dt)
+
+
+# --------------------------------------------------------------------------------------------------
 # silhouette
 # --------------------------------------------------------------------------------------------------
 class _SilFn(torch.autograd.Function):

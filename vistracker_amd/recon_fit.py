@@ -74,13 +74,17 @@ class ReconFitterTriVisFull(ReconFitterBase):
         verts, faces = (scan.v, scan.f) if hasattr(scan, "v") else scan
         self.scan = (np.asarray(verts, np.float32), np.asarray(faces))
         self.ctx = FitContext(smpl_model, regressors, priors, decoders, part_labels, self.scan[0], self.scan[1], obj_points, device=device)
+        # the reference evaluates the interpenetration term only on two machines of its authors' cluster (recon_fit_base.py:106-108); same gate,
+        # and ``fitter.collision_loss = True`` switches it on anywhere
+        import socket
+        self.collision_loss = "gpu20" in socket.gethostname() or "gpu16" in socket.gethostname()
         self.last = {}          # FitResult of the last optimize_* call (loss history, step counts, early-stop flag)
         self.profile = False    # True: fit_recon_batch records synchronised wall-clock per part in self.last["seconds"]
 
     # ---- schedules / weights (Appendix A.2 of SURVEY.md) ---------------------------------------------------
     def get_loss_weights(self):
         """name -> ``lambda cst, it: w * cst / (1 + it)`` for every term of recon_fit_trivis_full.py:124-153 (terms the fit path never
-        evaluates -- beta, smplz, collide -- included for dict compatibility); the fused loops use the same numbers (FIT_WEIGHTS)."""
+        evaluates -- beta, smplz -- included for dict compatibility; 'collide' is host-gated like in the reference); the fused loops use the same numbers (FIT_WEIGHTS)."""
         table = dict(FIT_WEIGHTS); table.update({"beta": 1.0, "smplz": 900.0, "collide": 9.0})
         return {k: (lambda cst, it, w=w: w * cst / (1 + it)) for k, w in table.items()}
 
@@ -285,6 +289,7 @@ class ReconFitterTriVisFull(ReconFitterBase):
             verts = smpl()[0].detach().contiguous()
             f32 = lambda t: t.data.to(device=self.device, dtype=torch.float32).contiguous().clone()
             obj_R, obj_t = f32(data_dict["obj_R"]), f32(data_dict["obj_t"])
+            self.ctx.collision_loss = bool(self.collision_loss)
             res = self.ctx.optimize_smpl_object(self._maps(model), verts, obj_R, obj_t, data_dict["obj_s"].data, q["crop_center"], q["body_center"],
                                                 data_dict["occ_ratios"], sil=sil.setup(), iter_for_obj=iters["object"], iter_for_sil=iters["sil"], joint_iter=joint_iter)
             data_dict["obj_R"].data.copy_(obj_R); data_dict["obj_t"].data.copy_(obj_t)
