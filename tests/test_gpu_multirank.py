@@ -37,7 +37,9 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
     outs = []
     for n, port in ((1, 29551), (2, 29552)):
         f = tmp_path / f"r{n}.npz"
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        # hermetic MIOpen state: a fresh user database per run, so that find results recorded by earlier processes on this box (other tests
+        # benchmark convolution algorithms in the default find mode) cannot steer the two runs to different convolution kernels
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                script, str(f), "100"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)

@@ -84,12 +84,14 @@ class Generator:
         which rank processes it or what ran before (an N-rank run reproduces the 1-rank run)"""
         self.rng.manual_seed((int(self.seed) * 1000003 + int(key)) % (2 ** 63 - 1))
 
-    def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=True, filter_images=True):
+    def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=True, filter_images=True, targets=("human", "object")):
+        """``targets``: which distance fields to sample (the reference always does both, generator.py:129-147; the in-memory pipeline asks for the
+        object only -- nothing downstream of it reads the human cloud)"""
         if filter_images:
             self.filter(data)
         batch_size = (data.get("images") if data.get("images") is not None else data.get("crop_center")).shape[0]
         samples = self.get_grid_samples(30000, batch_size=batch_size, body_center=data.get("body_center", None))
-        return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute) for t in ("human", "object")}
+        return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute) for t in targets}
 
     def gen_pc_batch(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter=100, mute=True):
         """iterate: project -> keep points with target < filter_val and z > 1 -> resample 20 000 around the kept points (generator.py:149-212).

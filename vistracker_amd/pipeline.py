@@ -152,7 +152,9 @@ class SequencePipeline:
             if resident:
                 self.net.filter(batch["images"], out={k: t[s:e] for k, t in big.items()})
                 bm = self.net.maps
-            pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm)
+            # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
+            # neural-only pass is written to disk and never read again by steps 5-6 (work whose result is unused)
+            pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm, targets=("object",))
             o = pc["object"]
             rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
         local = torch.cat(rows, 0) if rows else torch.zeros(0, 16, device=self.device)

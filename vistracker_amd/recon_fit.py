@@ -123,7 +123,7 @@ class ReconFitterTriVisFull(ReconFitterBase):
     # ---- batch-level orchestration of fit_recon (recon_fit_triplane.py:29-111), compute steps only --------------------------
     MINI_BATCH = 16             # recon_fit_behave.py:123-124
 
-    def generate_all(self, args, data, generator, num_points=4000, maps=None):
+    def generate_all(self, args, data, generator, num_points=4000, maps=None, targets=("human", "object")):
         """surface points + neural predictions of a whole batch, 16 frames at a time, cut to the common sample count
         (recon_fit_behave.py:121-150); per-mini-batch results are NOT written to disk here (save_neural_recon is IO).
         ``maps``: feature maps of the whole batch if they are already resident (then the images are not encoded again)."""
@@ -134,15 +134,15 @@ class ReconFitterTriVisFull(ReconFitterBase):
             mini = {k: (v[s0:s0 + self.MINI_BATCH] if hasattr(v, "__getitem__") and not isinstance(v, (str, bytes, dict)) else v) for k, v in data.items()}
             if maps is not None:
                 generator.model.maps = maps.slice(s0, min(batch_size, s0 + self.MINI_BATCH))
-            pc = generator.generate_pclouds_batch(mini, num_points=num_points, num_steps=10, mute=True, filter_images=maps is None)
-            samples_count = int(min(pc["human"]["points"].shape[1], pc["object"]["points"].shape[1], samples_count))
+            pc = generator.generate_pclouds_batch(mini, num_points=num_points, num_steps=10, mute=True, filter_images=maps is None, targets=targets)
+            samples_count = int(min([pc[t]["points"].shape[1] for t in targets] + [samples_count]))
             outs.append(pc)
         return self.combine_mini_batches(outs, samples_count)
 
     @staticmethod
     def combine_mini_batches(pc_generated_all, samples_count):
         """recon_fit_behave.py:152-183: points / parts cut to ``samples_count`` and concatenated over the mini batches, the rest concatenated"""
-        comb = {"human": {}, "object": {}}
+        comb = {t: {} for t in pc_generated_all[0]}
         for pc in pc_generated_all:
             for target in comb:
                 for k, v in pc[target].items():
@@ -177,7 +177,8 @@ class ReconFitterTriVisFull(ReconFitterBase):
         object_init = self.ctx.obj_points[None].repeat(batch_size, 1, 1)
         return obj_R.contiguous(), obj_s, obj_t.contiguous(), object_init
 
-    def fit_recon_batch(self, args, data, generator, smpl, body_kpts, obj_rots=None, pca_init=None, neural_only=False, maps=None, pc_generated=None):
+    def fit_recon_batch(self, args, data, generator, smpl, body_kpts, obj_rots=None, pca_init=None, neural_only=False, maps=None, pc_generated=None,
+                        targets=("human", "object")):
         """one iteration of the ``fit_recon`` loop on an in-memory batch: ``data`` = the dataloader's dict (images (B,8,H,W), crop_center,
         body_center, ...), ``smpl`` = the SMPL-T initialisation of the batch (get_smpl_init), ``body_kpts`` (B,25,3) already in
         network-input pixels.  Returns ``(pc_generated, smpl, obj_R, obj_t, obj_s)``; with ``neural_only`` the fit is skipped."""
@@ -189,7 +190,7 @@ class ReconFitterTriVisFull(ReconFitterBase):
                 torch.cuda.synchronize(); now = time.perf_counter(); sec[name] = sec.get(name, 0.0) + now - t_last[0]; t_last[0] = now
         # in-memory extras: ``maps`` = resident feature maps of this batch (skips both encoder passes), ``pc_generated`` = neural predictions
         # of an earlier pass over the same frames (skips the second surface-point generation the reference does in its separate process)
-        pc = pc_generated if pc_generated is not None else self.generate_all(args, data, generator, maps=maps)
+        pc = pc_generated if pc_generated is not None else self.generate_all(args, data, generator, maps=maps, targets=targets)
         lap("generate_all")
         if neural_only:
             return pc, None, None, None, None
