@@ -4,7 +4,7 @@
 tag=${1:-run}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( time timeout 3000 python -m pytest tests -m gpu -x -q --durations=15 ) > gpurun_out/${tag}_pytest.log 2>&1
+( time timeout 3000 python -m pytest tests -m gpu -q --durations=15 ) > gpurun_out/${tag}_pytest.log 2>&1; python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/${tag}_pytest.log 2>&1
 tail -30 gpurun_out/${tag}_pytest.log
 ( time timeout 900 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 3000 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err
