@@ -157,6 +157,17 @@ int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *p
                          const float *body_center, int B, int N, const float *occ, float w_obj,
                          float *dpts, double *terms, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 bias-free convolution of the HGFilter encoders (model/HGFilters.py:56-203, model/net_util.py:346-396 ConvBlock) as a
+ * split-f16 implicit GEMM (fp32 accumulate, same operand format as the point query).  weight (Cout, Cin, 3, 3) fp32 host, Cout in {64, 128},
+ * Cin a multiple of 32.  in (B,H,W,Cin) NHWC fp32 device, H % 8 == 0, W % 16 == 0; the result goes to channels [out_coff, out_coff + Cout) of an
+ * NHWC tensor with out_cstride channels (a ConvBlock's concatenation can be written in place).  A value beyond the operand range yields NaN.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct vt_conv3x3 vt_conv3x3;
+int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout, int cin, void *stream);
+void vt_conv3x3_destroy(vt_conv3x3 *h);
+int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
+
 /* Arithmetic of the decoder GEMMs behind every vt_query_* call of a handle:
  *   VT_PRECISION_SPLIT_F16 (default): 22-bit split-f16 operands on the f16 MFMA, fp32 accumulate (5.3x the f32-input MFMA rate; forward within
  *       ~1e-6 of the fp32 reference); activations must satisfy |x| < 1023, beyond that the result is inf/NaN;

@@ -616,3 +616,31 @@ def test_surface_sampling_is_area_weighted_and_seeded(hip):
     assert abs(a[:, 0].mean() - 2 / 3) < 0.02 and abs(a[:, 1].mean() - 1 / 3) < 0.01               # centroid of the first triangle
     batch = E.surface_sampling(np.stack([v, v + 1]), f, 100, ga)
     assert batch.shape == (2, 100, 3) and np.abs(npy(batch[1] - batch[0]) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (256, 128), (32, 64)])
+def test_conv3x3_split_f16_vs_float64(hip, cin, cout):
+    """vt_conv3x3_forward (split-f16 implicit GEMM, csrc/conv.hip) against torch's float64 convolution on the host: fp32-level agreement (the 3 x 22-bit
+    products drop ~3 * 2^-22 per term), zero padding at the image border, channel-offset output, loud NaN beyond the operand range."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vistracker_amd import _lib as L
+    g = torch.Generator().manual_seed(cin + cout)
+    B, H, W = 2, 16, 32
+    x = torch.randn(B, cin, H, W, generator=g) * 2.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).numpy()                     # NHWC
+    h = C.c_void_p()
+    wh = np.ascontiguousarray(w.numpy().reshape(cout, cin, 9))
+    L.check(L.lib().vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ctot, coff = cout + 32, 16
+    out = torch.full((B, H, W, ctot), 7.0, device="cuda")
+    L.check(L.lib().vt_conv3x3_forward(h, L.dptr(xn), B, H, W, L.dptr(out), ctot, coff, L.stream_ptr()))
+    got = npy(out)
+    assert np.abs(got[..., coff:coff + cout] - ref).max() < 2e-6 * np.abs(ref).max()
+    assert (got[..., :coff] == 7.0).all() and (got[..., coff + cout:] == 7.0).all()                     # nothing outside the channel slice is touched
+    xn[0, 3, 5, 7] = 5000.0                                                                            # 5000 * 2^4 > 65504
+    L.check(L.lib().vt_conv3x3_forward(h, L.dptr(xn), B, H, W, L.dptr(out), ctot, coff, L.stream_ptr()))
+    assert torch.isnan(out[0, 0:8, 0:16, coff:coff + cout]).all() and torch.isfinite(out[1]).all()       # the tiles that saw it are poisoned, others fine
+    L.lib().vt_conv3x3_destroy(h)

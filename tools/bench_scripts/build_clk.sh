@@ -6,4 +6,4 @@ cd "$(dirname "$0")/../../vistracker_amd/csrc"
 suf=$1; shift || true
 F="-O3 -fno-slp-vectorize -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -ffp-contract=off"
 /opt/rocm/bin/hipcc $F -DPHASE_CLK "$@" -c query.hip -o /tmp/query_clk$suf.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvistracker_hip_clk$suf.so /tmp/query_clk$suf.o misc.o smplh.o query_f32.o chamfer.o collide.o sil.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvistracker_hip_clk$suf.so /tmp/query_clk$suf.o misc.o smplh.o query_f32.o chamfer.o collide.o conv.o sil.o

@@ -1,0 +1,196 @@
+// conv.hip -- 3x3 / stride 1 / pad 1 convolution of the HGFilter encoders (model/HGFilters.py:56-203,
+// model/net_util.py:346-396 ConvBlock: three pre-activated 3x3 convolutions, bias-free) as an implicit GEMM on the split-f16 MFMA path of
+// the point query: D[cout][pixel] = sum over (tap, cin) W[cout][cin][tap] . X[cin][pixel + tap], fp32 accumulate, operands carried as
+// hi = fp16(x), lo = fp16(x - hi) with three MFMAs per product (hi.hi + hi.lo + lo.hi; query.hip).  MIOpen's fp32 convolutions run at
+// ~120 TFLOP/s (76 % of the f32-input MFMA peak); this path prices against 839 TFLOP/s.
+//   * workgroup = an 8 x 16 pixel tile of one frame x ALL output channels (64 or 128), 4 waves; wave w owns cout 32 w .. +31 (Cout = 128) or
+//     16 w .. +15 (Cout = 64) for the 128 pixels = 8 MFMA column tiles (one image row of 16 pixels each): the weight stream, the larger one at
+//     1.15 MB per 64 pixels, is amortised over 128 pixels;
+//   * per 32-channel chunk the 10 x 18 pixel halo patch is loaded ONCE (NHWC: 128 contiguous bytes per pixel), split and stored as K-block-major
+//     planes [4 kb][180 px][8 halves]; the nine taps then read their B fragments from LDS at shifted pixel indices (one conflict-free
+//     ds_read_b128 per fragment): 9x fewer global loads and splits than a per-tap gather; double buffered, one barrier per chunk;
+//   * weights are packed once per layer in fragment order [chunk][tap][4 waves][NT][hi|lo][64 lanes] and requested one tap ahead;
+//   * epilogue: one float4 (4 consecutive output channels of a pixel) per lane and tile, written at a channel offset of a wider NHWC tensor
+//     -- the ConvBlock's torch.cat of its three outputs is free.
+// Activations are scaled by 2^4 (|x| < 4094; a value beyond the fp16 range poisons the tile's output with NaN -- loud), weights per layer to
+// [2^13, 2^14); both scales are powers of two and undone exactly in the epilogue.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define CV_ACT_SCALE 16.0f
+#define CV_TH 8
+#define CV_TW 16
+#define CV_PW (CV_TW + 2)
+#define CV_PX ((CV_TH + 2) * CV_PW)         /* 180 halo pixels */
+#define CV_SPLIT_MAX 65504.0f
+
+struct vt_conv3x3 {
+    uint4 *w;           // [Cin / 32][9][4 waves][NT][hi|lo][64 lanes]
+    int cin, cout, nt;
+    float inv_scale;    // 1 / (CV_ACT_SCALE * s_W)
+};
+
+__device__ __forceinline__ h8 cv_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
+__device__ __forceinline__ void cv_split2(float x0, float x1, unsigned &hi, unsigned &lo, float &rmax)
+{
+    float r0, r1;
+    rmax = fmaxf(fmaxf(rmax, fabsf(x0)), fabsf(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int H, int W, int Cin, const uint4 *__restrict__ wpk,
+                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale)
+{
+    // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
+    __shared__ __attribute__((aligned(16))) uint4 patch[2][2 * 4 * CV_PX];
+    __shared__ int sOvf;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    const int tiles_x = W / CV_TW, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+    const int y0 = ty * CV_TH - 1, x0 = tx * CV_TW - 1;            // image position of halo pixel (0, 0)
+    const float *__restrict__ inb = in + (size_t)b * H * W * Cin;
+    const int nchunk = Cin >> 5;
+    if (tid == 0) sOvf = 0;
+    float rmax = 0.f;
+
+    f32x4 acc[NT][CV_TH];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int p = 0; p < CV_TH; p++) acc[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // halo patch of one chunk: 180 px x 8 pieces of 16 B = 1440 items, 6 per thread (the last round partly idle)
+    float4 ld[6];
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
+            const int yy = y0 + px / CV_PW, xx = x0 + px % CV_PW;
+            const bool inside = it < CV_PX * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(inb + ((size_t)yc * W + xc) * Cin + c * 32 + piece * 4);
+            ld[r] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+        uint2 *hi8 = reinterpret_cast<uint2 *>(patch[buf]), *lo8 = reinterpret_cast<uint2 *>(patch[buf] + 4 * CV_PX);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
+            if (it < CV_PX * 8) {
+                uint2 hi, lo;
+                cv_split2(ld[r].x * CV_ACT_SCALE, ld[r].y * CV_ACT_SCALE, hi.x, lo.x, rmax);
+                cv_split2(ld[r].z * CV_ACT_SCALE, ld[r].w * CV_ACT_SCALE, hi.y, lo.y, rmax);
+                const int idx = (((piece >> 1) * CV_PX + px) << 1) + (piece & 1);
+                hi8[idx] = hi; lo8[idx] = lo;
+            }
+        }
+    };
+    const unsigned wvo = (unsigned)(wave * NT * 128 + lane);
+    uint4 wf[2][NT][2];
+#define CV_LOAD_W(slot_, step_)                                                                                      \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                \
+        _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
+    issue(0);
+    CV_LOAD_W(0, 0)
+    stage(0);
+    if (nchunk > 1) issue(1);
+    for (int c = 0; c < nchunk; c++) {
+        const uint4 *Xhi = patch[c & 1], *Xlo = Xhi + 4 * CV_PX;
+        __syncthreads();                                        // patch of chunk c visible; the other buffer's readers are done
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3, dx = t % 3, step = c * 9 + t;
+            if (step + 1 < nchunk * 9) { CV_LOAD_W((t + 1) & 1, step + 1) }          // 9 taps: slots alternate with t, chunk c + 1 starts on slot (9 & 1) = 1 ...
+            // ... so the slot of (c, t) is (c + t) & 1: handled by indexing with the running parity below
+            const int sl = t & 1;
+#pragma unroll
+            for (int ph = 0; ph < 2; ph++) {                    // two halves of four image rows: 8 B fragments live at a time
+                h8 xh[4], xl[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int px = (4 * ph + p + dy) * CV_PW + j + dx;
+                    xh[p] = cv_h8(Xhi[q * CV_PX + px]); xl[p] = cv_h8(Xlo[q * CV_PX + px]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][0]), xh[p], acc[nt][4 * ph + p]);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][0]), xl[p], acc[nt][4 * ph + p]);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][1]), xh[p], acc[nt][4 * ph + p]);
+            }
+        }
+        // nine taps flip the slot parity once per chunk: re-align so that tap 0 of the next chunk finds its fragments in slot 0
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int hl = 0; hl < 2; hl++) wf[0][nt][hl] = wf[1][nt][hl];
+        if (c + 1 < nchunk) stage((c + 1) & 1);
+        if (c + 2 < nchunk) issue(c + 2);
+    }
+#undef CV_LOAD_W
+    if (rmax > CV_SPLIT_MAX) sOvf = 1;
+    __syncthreads();
+    const bool ovf = sOvf != 0;
+    float *__restrict__ ob = out + (size_t)b * H * W * out_cstride + out_coff;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int p = 0; p < CV_TH; p++) {
+            const int y = ty * CV_TH + p, x = tx * CV_TW + j, co = (wave * NT + nt) * 16 + 4 * q;
+            float4 v = make_float4(acc[nt][p][0] * inv_scale, acc[nt][p][1] * inv_scale, acc[nt][p][2] * inv_scale, acc[nt][p][3] * inv_scale);
+            if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
+        }
+}
+
+extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout, int cin, void *stream)
+{
+    VT_REQUIRE(out && weight && (cout == 64 || cout == 128) && cin >= 32 && cin % 32 == 0, "vt_conv3x3_create: needs Cout in {64, 128} and Cin a multiple of 32");
+    const int nt = cout / 64, nchunk = cin / 32;
+    float m = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * 9; i++) m = fmaxf(m, fabsf(weight[i]));
+    float sw = 1.0f;
+    if (m > 0.f && std::isfinite(m)) { int e; frexpf(m, &e); sw = ldexpf(1.0f, 14 - e); }
+    const size_t n16 = (size_t)nchunk * 9 * 4 * nt * 2 * 64;            // uint4 count
+    _Float16 *host = new _Float16[n16 * 8];
+    // fragment (step = chunk * 9 + tap, wave, nt, hi|lo, lane) halves t: W[cout = (wave nt_count + nt) 16 + (lane & 15)][cin = 32 chunk + 8 (lane >> 4) + t][tap]
+    for (int c = 0; c < nchunk; c++) for (int t = 0; t < 9; t++) for (int w = 0; w < 4; w++) for (int n = 0; n < nt; n++) for (int l = 0; l < 64; l++) for (int k = 0; k < 8; k++) {
+        const int co = (w * nt + n) * 16 + (l & 15), ci = 32 * c + 8 * (l >> 4) + k;
+        const float x = weight[((size_t)co * cin + ci) * 9 + t] * sw;          // (Cout, Cin, 3, 3): tap = 3 ky + kx
+        const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+        const size_t base = ((((size_t)(c * 9 + t) * 4 + w) * nt + n) * 2) * 64;
+        host[(base + l) * 8 + k] = hi; host[(base + 64 + l) * 8 + k] = lo;
+    }
+    vt_conv3x3 *h = new vt_conv3x3();
+    VT_HIP(hipMalloc(reinterpret_cast<void **>(&h->w), n16 * 16));
+    VT_HIP(hipMemcpyAsync(h->w, host, n16 * 16, hipMemcpyHostToDevice, vt_stream(stream)));
+    VT_HIP(hipStreamSynchronize(vt_stream(stream)));
+    delete[] host;
+    h->cin = cin; h->cout = cout; h->nt = nt; h->inv_scale = 1.0f / (CV_ACT_SCALE * sw);
+    *out = h;
+    return VT_OK;
+}
+extern "C" void vt_conv3x3_destroy(vt_conv3x3 *h) { if (!h) return; (void)hipFree(h->w); delete h; }
+
+extern "C" int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
+{
+    VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
+               "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and a 16-byte aligned channel slice");
+    const dim3 grid((H / CV_TH) * (W / CV_TW), B);
+    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, H, W, h->cin, h->w, out, out_cstride, out_coff, h->inv_scale);
+    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, H, W, h->cin, h->w, out, out_cstride, out_coff, h->inv_scale);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

@@ -52,6 +52,10 @@ def _gn(x, sd, p, groups=32, relu=False):
 
 
 class HGFilterEncoder:
+    # 3x3 convolutions with 64 / 128 output channels and Cin % 32 == 0 (all but five of the 79 3x3 layers of an encoder: 2 x 9.4 of the
+    # 9.8 TFLOP per 16 frames) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_*); everything else stays on MIOpen
+    use_hip_conv = True
+
     def __init__(self, sd: dict, prefix: str, num_stack=3, num_hourglass=2, norm="group", hg_down="ave_pool", device="cuda:0"):
         """``sd``: state dict (tensors or arrays); ``prefix`` e.g. 'image_filter.' or 'triplane_encoder.' (a leading 'module.' is stripped)"""
         if norm != "group" or hg_down != "ave_pool":
@@ -67,13 +71,41 @@ class HGFilterEncoder:
         if "conv1.weight" not in self.sd:
             raise KeyError(f"no encoder weights under prefix '{prefix}'")
         self.in_channels = self.sd["conv1.weight"].shape[1]
+        self._conv_handles = {}
+
+    def __del__(self):
+        try:
+            for h in getattr(self, "_conv_handles", {}).values():
+                L.lib().vt_conv3x3_destroy(h)
+        except Exception:
+            pass
+
+    def _conv3x3(self, x, name):
+        """3x3 / stride 1 / pad 1, no bias: split-f16 implicit GEMM on the HIP path when the shape allows, MIOpen otherwise"""
+        w = self.sd[name]
+        cout, cin = w.shape[:2]
+        B, _, H, W = x.shape
+        if not (self.use_hip_conv and x.is_cuda and cout in (64, 128) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0):
+            return F.conv2d(x, w, None, 1, 1)
+        import ctypes as C
+        h = self._conv_handles.get(name)
+        if h is None:
+            h = C.c_void_p()
+            wh = np.ascontiguousarray(w.permute(0, 1, 2, 3).contiguous().cpu().numpy().reshape(cout, cin, 9), np.float32)     # (Cout, Cin, ky * 3 + kx)
+            with torch.cuda.device(x.device):
+                L.check(L.lib().vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
+            self._conv_handles[name] = h
+        x = x.contiguous(memory_format=torch.channels_last)                      # NHWC in memory
+        y = torch.empty(B, cout, H, W, device=x.device).contiguous(memory_format=torch.channels_last)
+        L.check(L.lib().vt_conv3x3_forward(h, x.data_ptr(), B, H, W, y.data_ptr(), cout, 0, L.stream_ptr()))
+        return y
 
     # ---- blocks ------------------------------------------------------------------------------------------------
     def _conv_block(self, x, p):
         sd = self.sd
-        o1 = F.conv2d(_gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
-        o2 = F.conv2d(_gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
-        o3 = F.conv2d(_gn(o2, sd, p + "bn3", relu=True), sd[p + "conv3.weight"], None, 1, 1)
+        o1 = self._conv3x3(_gn(x, sd, p + "bn1", relu=True), p + "conv1.weight")
+        o2 = self._conv3x3(_gn(o1, sd, p + "bn2", relu=True), p + "conv2.weight")
+        o3 = self._conv3x3(_gn(o2, sd, p + "bn3", relu=True), p + "conv3.weight")
         out = torch.cat((o1, o2, o3), 1)
         if p + "downsample.2.weight" in sd:
             # downsample = Sequential(bn4, ReLU, conv1x1): the norm is the module the state dict also lists as "bn4" (same tensors in a
