@@ -167,6 +167,13 @@ typedef struct vt_conv3x3 vt_conv3x3;
 int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout, int cin, void *stream);
 void vt_conv3x3_destroy(vt_conv3x3 *h);
 int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
+/* The pre-activated form of the ConvBlock (GroupNorm -> ReLU -> conv, model/net_util.py:374-388) in one pass: the input is channels
+ * [in_coff, in_coff + Cin) of an NHWC tensor with in_cstride channels; with gn_stats != NULL (the (B, groups) {mean, rstd} pairs of
+ * vt_groupnorm_stats) max((x - mean) rstd gamma + beta, 0) is applied while the operand planes are staged (zero padding pads the rectified value). */
+int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                          const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
+/* GroupNorm statistics of a channel slice: ws needs 2 B C doubles + B groups float pairs; the {mean, rstd} pairs start at ws + 2 B C doubles */
+int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream);
 
 /* Arithmetic of the decoder GEMMs behind every vt_query_* call of a handle:
  *   VT_PRECISION_SPLIT_F16 (default): 22-bit split-f16 operands on the f16 MFMA, fp32 accumulate (5.3x the f32-input MFMA rate; forward within

@@ -44,7 +44,8 @@ __device__ __forceinline__ void cv_split2(float x0, float x1, unsigned &hi, unsi
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int H, int W, int Cin, const uint4 *__restrict__ wpk,
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
+                                                         const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
                                                          float *__restrict__ out, int out_cstride, int out_coff, float inv_scale)
 {
     // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int tiles_x = W / CV_TW, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
     const int y0 = ty * CV_TH - 1, x0 = tx * CV_TW - 1;            // image position of halo pixel (0, 0)
-    const float *__restrict__ inb = in + (size_t)b * H * W * Cin;
+    const float *__restrict__ inb = in + (size_t)b * H * W * in_cstride + in_coff;
+    const int cg = gn_stats ? Cin / groups : 1;
     const int nchunk = Cin >> 5;
     if (tid == 0) sOvf = 0;
     float rmax = 0.f;
@@ -66,26 +68,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 
     // halo patch of one chunk: 180 px x 8 pieces of 16 B = 1440 items, 6 per thread (the last round partly idle)
     float4 ld[6];
+    unsigned inmask = 0;        // which of this thread's six halo pixels lie inside the image (the same for every chunk)
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const int it = tid + 256 * r, px = it >> 3, yy = y0 + px / CV_PW, xx = x0 + px % CV_PW;
+        inmask |= (unsigned)(it < CV_PX * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W) << r;
+    }
     auto issue = [&](int c) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
             const int yy = y0 + px / CV_PW, xx = x0 + px % CV_PW;
-            const bool inside = it < CV_PX * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W;
             const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
-            const float4 v = *reinterpret_cast<const float4 *>(inb + ((size_t)yc * W + xc) * Cin + c * 32 + piece * 4);
-            ld[r] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4 *>(inb + ((size_t)yc * W + xc) * in_cstride + c * 32 + piece * 4);
+            ld[r] = v;          // outside pixels are read from a clamped address and zeroed in stage(): the padding pads the RECTIFIED activation
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int c) {
         uint2 *hi8 = reinterpret_cast<uint2 *>(patch[buf]), *lo8 = reinterpret_cast<uint2 *>(patch[buf] + 4 * CV_PX);
+        // fused GroupNorm + ReLU prologue (the pre-activated ConvBlock: GN -> ReLU -> conv): y = max(x * a + s, 0) with a = rstd gamma,
+        // s = beta - mean a of this thread's four channels of the chunk (the piece index of a thread is the same in every round)
+        float ga[4] = {CV_ACT_SCALE, CV_ACT_SCALE, CV_ACT_SCALE, CV_ACT_SCALE}, gs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gn_stats) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ch = c * 32 + (tid & 7) * 4 + k;
+                const float2 st = gn_stats[b * groups + ch / cg];
+                const float a_ = st.y * gamma[ch];
+                ga[k] = a_ * CV_ACT_SCALE; gs[k] = (beta[ch] - st.x * a_) * CV_ACT_SCALE;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 6; r++) {
             const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
             if (it < CV_PX * 8) {
                 uint2 hi, lo;
-                cv_split2(ld[r].x * CV_ACT_SCALE, ld[r].y * CV_ACT_SCALE, hi.x, lo.x, rmax);
-                cv_split2(ld[r].z * CV_ACT_SCALE, ld[r].w * CV_ACT_SCALE, hi.y, lo.y, rmax);
+                const bool inside = (inmask >> r) & 1u;
+                float v0 = __builtin_fmaf(ld[r].x, ga[0], gs[0]), v1 = __builtin_fmaf(ld[r].y, ga[1], gs[1]), v2 = __builtin_fmaf(ld[r].z, ga[2], gs[2]), v3 = __builtin_fmaf(ld[r].w, ga[3], gs[3]);
+                if (gn_stats) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (!inside) v0 = v1 = v2 = v3 = 0.f;
+                cv_split2(v0, v1, hi.x, lo.x, rmax);
+                cv_split2(v2, v3, hi.y, lo.y, rmax);
                 const int idx = (((piece >> 1) * CV_PX + px) << 1) + (piece & 1);
                 hi8[idx] = hi; lo8[idx] = lo;
             }
@@ -98,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
         _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
     issue(0);
     CV_LOAD_W(0, 0)
-    stage(0);
+    stage(0, 0);
     if (nchunk > 1) issue(1);
     for (int c = 0; c < nchunk; c++) {
         const uint4 *Xhi = patch[c & 1], *Xlo = Xhi + 4 * CV_PX;
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int hl = 0; hl < 2; hl++) wf[0][nt][hl] = wf[1][nt][hl];
-        if (c + 1 < nchunk) stage((c + 1) & 1);
+        if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
         if (c + 2 < nchunk) issue(c + 2);
     }
 #undef CV_LOAD_W
@@ -184,13 +207,22 @@ extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout
 }
 extern "C" void vt_conv3x3_destroy(vt_conv3x3 *h) { if (!h) return; (void)hipFree(h->w); delete h; }
 
-extern "C" int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
+extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                     const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
 {
-    VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0,
-               "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and a 16-byte aligned channel slice");
+    VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0
+                   && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
+               "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and 16-byte aligned channel slices");
+    VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv3x3_forward_gn: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
     const dim3 grid((H / CV_TH) * (W / CV_TW), B);
-    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, H, W, h->cin, h->w, out, out_cstride, out_coff, h->inv_scale);
-    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, H, W, h->cin, h->w, out, out_cstride, out_coff, h->inv_scale);
+    const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
+    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale);
+    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale);
     VT_LAUNCH_CHECK();
     return VT_OK;
+}
+extern "C" int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
+{
+    VT_REQUIRE(h, "vt_conv3x3_forward: null handle");
+    return vt_conv3x3_forward_gn(h, in, h->cin, 0, nullptr, nullptr, nullptr, 0, B, H, W, out, out_cstride, out_coff, stream);
 }

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void upsample2x_bicubic_add_kernel(const float
 // separate element-wise kernel): pass 1 accumulates per-(frame, channel) sum / sum of squares in fp64, pass 2 normalises with the
 // group statistics and clamps.  The pre-activated blocks of the encoder are GN -> ReLU -> conv (model/net_util.py:374-388).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int HW, int C, int rows_per_block, double *__restrict__ sums)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int cstride, int HW, int C, int rows_per_block, double *__restrict__ sums)
 {
     // thread = (pixel row slot, float4 of channels): C/4 float4 per pixel, 256 / (C/4) pixels per sweep
     const int C4 = C >> 2, b = blockIdx.y, c4 = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (slot < nslot)
         for (int p = p0 + slot; p < p1; p += nslot) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)b * HW + p) * C + 4 * c4);
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)b * HW + p) * cstride + 4 * c4);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
         }
@@ -516,13 +516,30 @@ extern "C" int vt_groupnorm_nhwc(const float *x, const float *gamma, const float
     hipStream_t st = vt_stream(stream);
     VT_HIP(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)B * C * 2, st));
     const int nblk = min(max(HW / 256, 1), 128), rows = (HW + nblk - 1) / nblk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x, HW, C, rows, ws);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x, C, HW, C, rows, ws);
     VT_LAUNCH_CHECK();
     float2 *stats = reinterpret_cast<float2 *>(ws + (size_t)B * C * 2);      // (B, groups) after the channel sums
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, ws, B, HW, C, groups, eps, stats);
     VT_LAUNCH_CHECK();
     const long total = (long)B * HW * (C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, gamma, beta, stats, B, HW, C, groups, relu, y);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// statistics only, on a channel slice [coff, coff + C) of an NHWC tensor with cstride channels: (B, groups) x {mean, 1 / sqrt(var + eps)} as floats
+// at ws + 2 B C doubles -- the GroupNorm + ReLU itself is applied by the consumer (vt_conv3x3_forward_gn stages it into its operand planes)
+extern "C" int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream)
+{
+    VT_REQUIRE(x && ws && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && groups > 0 && C % groups == 0 && C <= 1024 && cstride >= coff + C && cstride % 4 == 0 && coff % 4 == 0,
+               "vt_groupnorm_stats: bad argument");
+    hipStream_t st = vt_stream(stream);
+    VT_HIP(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)B * C * 2, st));
+    const int nblk = min(max(HW / 256, 1), 128), rows = (HW + nblk - 1) / nblk;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x + coff, cstride, HW, C, rows, ws);
+    VT_LAUNCH_CHECK();
+    float2 *stats = reinterpret_cast<float2 *>(ws + (size_t)B * C * 2);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, ws, B, HW, C, groups, eps, stats);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

@@ -80,33 +80,54 @@ class HGFilterEncoder:
         except Exception:
             pass
 
-    def _conv3x3(self, x, name):
-        """3x3 / stride 1 / pad 1, no bias: split-f16 implicit GEMM on the HIP path when the shape allows, MIOpen otherwise"""
-        w = self.sd[name]
-        cout, cin = w.shape[:2]
-        B, _, H, W = x.shape
-        if not (self.use_hip_conv and x.is_cuda and cout in (64, 128) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0):
-            return F.conv2d(x, w, None, 1, 1)
+    def _conv_handle(self, name, device):
         import ctypes as C
         h = self._conv_handles.get(name)
         if h is None:
+            w = self.sd[name]; cout, cin = w.shape[:2]
             h = C.c_void_p()
-            wh = np.ascontiguousarray(w.permute(0, 1, 2, 3).contiguous().cpu().numpy().reshape(cout, cin, 9), np.float32)     # (Cout, Cin, ky * 3 + kx)
-            with torch.cuda.device(x.device):
+            wh = np.ascontiguousarray(w.contiguous().cpu().numpy().reshape(cout, cin, 9), np.float32)          # (Cout, Cin, ky * 3 + kx)
+            with torch.cuda.device(device):
                 L.check(L.lib().vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
             self._conv_handles[name] = h
-        x = x.contiguous(memory_format=torch.channels_last)                      # NHWC in memory
-        y = torch.empty(B, cout, H, W, device=x.device).contiguous(memory_format=torch.channels_last)
-        L.check(L.lib().vt_conv3x3_forward(h, x.data_ptr(), B, H, W, y.data_ptr(), cout, 0, L.stream_ptr()))
-        return y
+        return h
+
+    def _hip_conv_ok(self, name, H, W, cuda):
+        cout, cin = self.sd[name].shape[:2]
+        return self.use_hip_conv and cuda and cout in (64, 128) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0
 
     # ---- blocks ------------------------------------------------------------------------------------------------
     def _conv_block(self, x, p):
+        """ConvBlock (model/net_util.py:346-396): three pre-activated 3x3 convolutions (GN -> ReLU -> conv), outputs concatenated, + (projected)
+        residual.  On the GPU every convolution writes its channel slice of ONE NHWC buffer (the concatenation is free) and reads its input from
+        the previous slice; supported shapes run GroupNorm statistics + the fused GN/ReLU/conv kernel (vt_groupnorm_stats, vt_conv3x3_forward_gn),
+        the others (32 output channels) normalise with vt_groupnorm_nhwc and convolve on MIOpen."""
         sd = self.sd
-        o1 = self._conv3x3(_gn(x, sd, p + "bn1", relu=True), p + "conv1.weight")
-        o2 = self._conv3x3(_gn(o1, sd, p + "bn2", relu=True), p + "conv2.weight")
-        o3 = self._conv3x3(_gn(o2, sd, p + "bn3", relu=True), p + "conv3.weight")
-        out = torch.cat((o1, o2, o3), 1)
+        B, Cin, H, W = x.shape
+        couts = [sd[p + f"conv{i}.weight"].shape[0] for i in (1, 2, 3)]
+        if not (x.is_cuda and any(self._hip_conv_ok(p + f"conv{i}.weight", H, W, True) for i in (1, 2, 3))):
+            o1 = F.conv2d(_gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
+            o2 = F.conv2d(_gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
+            o3 = F.conv2d(_gn(o2, sd, p + "bn3", relu=True), sd[p + "conv3.weight"], None, 1, 1)
+            out = torch.cat((o1, o2, o3), 1)
+        else:
+            x = x.contiguous(memory_format=torch.channels_last)
+            Ct = sum(couts)
+            out = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)          # NHWC in memory
+            src, cstride, coff, C = x, Cin, 0, Cin
+            off = 0
+            for i, co in zip((1, 2, 3), couts):
+                wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
+                if self._hip_conv_ok(wn, H, W, True):
+                    ws = torch.empty(2 * B * C + B * 32, dtype=torch.float64, device=x.device)
+                    L.check(L.lib().vt_groupnorm_stats(src.data_ptr(), cstride, coff, B, H * W, C, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+                    L.check(L.lib().vt_conv3x3_forward_gn(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr() + 16 * B * C,
+                                                          sd[gn + ".weight"].data_ptr(), sd[gn + ".bias"].data_ptr(), 32, B, H, W, out.data_ptr(), Ct, off, L.stream_ptr()))
+                else:
+                    xin = src if (cstride == C and coff == 0) else src[:, coff:coff + C]
+                    out[:, off:off + co] = F.conv2d(_gn(xin, sd, gn, relu=True), sd[wn], None, 1, 1)
+                src, cstride, coff, C = out, Ct, off, co
+                off += co
         if p + "downsample.2.weight" in sd:
             # downsample = Sequential(bn4, ReLU, conv1x1): the norm is the module the state dict also lists as "bn4" (same tensors in a
             # real checkpoint); "downsample.0" is the name that is loaded last, i.e. the one the reference ends up using
