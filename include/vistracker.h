@@ -172,7 +172,8 @@ int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W
  * vt_groupnorm_stats) max((x - mean) rstd gamma + beta, 0) is applied while the operand planes are staged (zero padding pads the rectified value). */
 int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
                           const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
-/* GroupNorm statistics of a channel slice: ws needs 2 B C doubles + B groups float pairs; the {mean, rstd} pairs start at ws + 2 B C doubles */
+/* GroupNorm statistics of a channel slice: ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles; the (B, groups) {mean, rstd} float pairs
+ * are written at the START of ws (pass `(const float *)ws` as gn_stats) */
 int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream);
 
 /* Arithmetic of the decoder GEMMs behind every vt_query_* call of a handle:
@@ -309,7 +310,9 @@ int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h,
 
 /* GroupNorm (+ ReLU) of an NHWC fp32 tensor, the `bnK -> F.relu` prologue of every pre-activated convolution of the encoder
  * (model/net_util.py:374-388, model/HGFilters.py:176,192-193): y = [relu]((x - mean_g) / sqrt(var_g + eps) * gamma + beta) with the
- * biased variance over (H, W, C/groups), exactly torch.nn.functional.group_norm.  x, y (B,HW,C); gamma, beta (C); ws >= 2*B*C + B*groups doubles. */
+ * biased variance over (H, W, C/groups), exactly torch.nn.functional.group_norm.  x, y (B,HW,C); gamma, beta (C); ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles
+ * ((B, groups) float pairs {mean, rstd} first, then per-block fp64 partial sums: no atomics, deterministic). */
+long vt_groupnorm_workspace_doubles(int B, int HW, int C, int groups);
 int vt_groupnorm_nhwc(const float *x, const float *gamma, const float *beta, int B, int HW, int C, int groups, float eps,
                       int relu, double *ws, float *y, void *stream);
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vt_conv3x3_forward": (ci, [vp, fp, ci, ci, ci, fp, ci, ci, vp]),
     "vt_conv3x3_forward_gn": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, vp]),
     "vt_groupnorm_stats": (ci, [fp, ci, ci, ci, ci, ci, ci, cf, fp, vp]),
+    "vt_groupnorm_workspace_doubles": (C.c_long, [ci, ci, ci, ci]),
     "vt_triplane_render": (ci, [fp, fp, ci, ci, fp, ci, ci, fp, fp, fp, vp]),
     "vt_query_project_step": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, ci, cf, fp, fp, vp]),
     "vt_query_projection_floats": (C.c_long, [C.POINTER(VtMaps), ci]),

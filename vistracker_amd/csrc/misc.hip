@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void upsample2x_bicubic_add_kernel(const float
 // separate element-wise kernel): pass 1 accumulates per-(frame, channel) sum / sum of squares in fp64, pass 2 normalises with the
 // group statistics and clamps.  The pre-activated blocks of the encoder are GN -> ReLU -> conv (model/net_util.py:374-388).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int cstride, int HW, int C, int rows_per_block, double *__restrict__ sums)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int cstride, int HW, int C, int rows_per_block, double *__restrict__ part)
 {
     // thread = (pixel row slot, float4 of channels): C/4 float4 per pixel, 256 / (C/4) pixels per sweep
     const int C4 = C >> 2, b = blockIdx.y, c4 = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4;
@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
         }
-    // combine the pixel slots of a channel through LDS, one fp64 atomic per (channel, statistic) and block
+    // combine the pixel slots of a channel through LDS; one fp64 partial per (block, frame, channel, statistic): no atomics, nothing to zero,
+    // and the result does not depend on the order in which the blocks ran
     __shared__ float red[256 * 8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = q[k]; }
@@ -471,23 +472,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
         for (int sl = 0; sl < nslot; sl++)
 #pragma unroll
             for (int k = 0; k < 4; k++) { ds[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + k]; dq[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + 4 + k]; }
+        double *o = part + (((size_t)blockIdx.x * gridDim.y + b) * C + 4 * threadIdx.x) * 2;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            atomicAdd(sums + ((size_t)b * C + 4 * threadIdx.x + k) * 2, ds[k]);
-            atomicAdd(sums + ((size_t)b * C + 4 * threadIdx.x + k) * 2 + 1, dq[k]);
-        }
+        for (int k = 0; k < 4; k++) { o[2 * k] = ds[k]; o[2 * k + 1] = dq[k]; }
     }
 }
-// per (frame, group): mean and 1/sqrt(var + eps) from the channel sums (fp64), written as two floats over the first channel pair's slot
-__global__ void gn_finalize_kernel(const double *__restrict__ sums, int B, int HW, int C, int groups, float eps, float2 *__restrict__ stats)
+// per (frame, group), one wave: mean and 1 / sqrt(var + eps) from the block partials (fp64, fixed order), two floats at stats[b * groups + g]
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const double *__restrict__ part, int nblk, int B, int HW, int C, int groups, float eps, float2 *__restrict__ stats)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * groups) return;
-    const int b = i / groups, g = i - b * groups, cg = C / groups;
+    const int i = blockIdx.x, b = i / groups, g = i - b * groups, cg = C / groups, lane = threadIdx.x;
     double sm = 0, sq = 0;
-    for (int k = 0; k < cg; k++) { sm += sums[((size_t)b * C + g * cg + k) * 2]; sq += sums[((size_t)b * C + g * cg + k) * 2 + 1]; }
-    const double n = (double)HW * cg, mean = sm / n, var = fmax(sq / n - mean * mean, 0.0);
-    stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    for (int e = lane; e < nblk * cg; e += 64) {
+        const int blk = e / cg, k = e - blk * cg;
+        const double *p = part + (((size_t)blk * B + b) * C + g * cg + k) * 2;
+        sm += p[0]; sq += p[1];
+    }
+    for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); sq += __shfl_xor(sq, o, 64); }
+    if (lane == 0) {
+        const double n = (double)HW * cg, mean = sm / n, var = fmax(sq / n - mean * mean, 0.0);
+        stats[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
 }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        const float2 *__restrict__ stats, int B, int HW, int C, int groups, int relu,
@@ -508,40 +512,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     }
     *reinterpret_cast<float4 *>(y + pix * C + 4 * c4) = make_float4(out[0], out[1], out[2], out[3]);
 }
+static int gn_blocks(int HW) { return min(max(HW / 256, 1), 128); }
+// workspace of vt_groupnorm_nhwc / vt_groupnorm_stats in doubles: (B, groups) x {mean, rstd} as float pairs FIRST, then the block partials
+extern "C" long vt_groupnorm_workspace_doubles(int B, int HW, int C, int groups)
+{
+    if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
+    return (long)B * groups + (long)gn_blocks(HW) * B * C * 2;
+}
+static int gn_statistics(const float *x, int cstride, int B, int HW, int C, int groups, float eps, double *ws, hipStream_t st)
+{
+    const int nblk = gn_blocks(HW), rows = (HW + nblk - 1) / nblk;
+    double *part = ws + (size_t)B * groups;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x, cstride, HW, C, rows, part);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, nblk, B, HW, C, groups, eps, reinterpret_cast<float2 *>(ws));
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
 extern "C" int vt_groupnorm_nhwc(const float *x, const float *gamma, const float *beta, int B, int HW, int C, int groups, float eps, int relu,
                                  double *ws, float *y, void *stream)
 {
     VT_REQUIRE(x && gamma && beta && ws && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && C <= 1024 && groups > 0 && C % groups == 0,
                "vt_groupnorm_nhwc: bad argument (C must be a multiple of 4 and of groups, C <= 1024)");
     hipStream_t st = vt_stream(stream);
-    VT_HIP(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)B * C * 2, st));
-    const int nblk = min(max(HW / 256, 1), 128), rows = (HW + nblk - 1) / nblk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x, C, HW, C, rows, ws);
-    VT_LAUNCH_CHECK();
-    float2 *stats = reinterpret_cast<float2 *>(ws + (size_t)B * C * 2);      // (B, groups) after the channel sums
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, ws, B, HW, C, groups, eps, stats);
-    VT_LAUNCH_CHECK();
+    if (int e = gn_statistics(x, C, B, HW, C, groups, eps, ws, st)) return e;
     const long total = (long)B * HW * (C / 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, gamma, beta, stats, B, HW, C, groups, relu, y);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, gamma, beta, reinterpret_cast<const float2 *>(ws), B, HW, C, groups, relu, y);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
 
 // statistics only, on a channel slice [coff, coff + C) of an NHWC tensor with cstride channels: (B, groups) x {mean, 1 / sqrt(var + eps)} as floats
-// at ws + 2 B C doubles -- the GroupNorm + ReLU itself is applied by the consumer (vt_conv3x3_forward_gn stages it into its operand planes)
+// at the START of ws (vt_groupnorm_workspace_doubles) -- the GroupNorm + ReLU itself is applied by the consumer (vt_conv3x3_forward_gn stages it into
+// its operand planes)
 extern "C" int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream)
 {
     VT_REQUIRE(x && ws && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && groups > 0 && C % groups == 0 && C <= 1024 && cstride >= coff + C && cstride % 4 == 0 && coff % 4 == 0,
                "vt_groupnorm_stats: bad argument");
-    hipStream_t st = vt_stream(stream);
-    VT_HIP(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)B * C * 2, st));
-    const int nblk = min(max(HW / 256, 1), 128), rows = (HW + nblk - 1) / nblk;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk, B), dim3(256), 0, st, x + coff, cstride, HW, C, rows, ws);
-    VT_LAUNCH_CHECK();
-    float2 *stats = reinterpret_cast<float2 *>(ws + (size_t)B * C * 2);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, st, ws, B, HW, C, groups, eps, stats);
-    VT_LAUNCH_CHECK();
-    return VT_OK;
+    return gn_statistics(x + coff, cstride, B, HW, C, groups, eps, ws, vt_stream(stream));
 }
 
 extern "C" int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream)

@@ -413,38 +413,49 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     for (int g = 0; g < G; g++) acc_zero(acc1[g]);
 #ifndef PJ_NOFWD
     if (USEP) {
-        // the im_feat part of the layer-1 pre-activations, straight in the D-fragment layout: lane (q, j) holds hidden units
-        // 32 wave + 16 nt + 4 q .. +3 (one float4 of a P row) of the points 16 p + j
+        // The im_feat part of the layer-1 pre-activations: blend of the 4 tap rows of P (fp32).  Gathered with the four lanes of a point ADJACENT
+        // (thread = (point, 16-byte column group): 4 lanes read 64 contiguous bytes of a row per instruction) -- in the D-fragment layout the
+        // lanes of one instruction sit on 64 different rows (16 points x 4 groups 16 lanes apart) and the texture addresser takes twice as long
+        // for the same bytes (tools/bench_scripts/gather_patterns.hip: 9.4 vs 19.7 TB/s; -8 % on this kernel).  The blended rows go through
+        // LDS ([point][column] fp32, row stride = columns + 4: both sides near conflict-free) into the accumulator fragments: lane (q, j) holds
+        // hidden units 32 wave + 16 nt + 4 q .. +3 of the points 16 p + j.
+        constexpr int PS = G * 128 + 4;                         // floats per staged row (G = 2: runs 1 KB into the Go buffer, unused until layer 4)
+        float *stage = reinterpret_cast<float *>(lds);
+        static_assert(64 * PS * 4 <= 16 * (R0 + 256), "the staged rows must fit region 0 + Go");
         const int R = a.res[0];
         const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
+        {
+            const int spt = tid >> 2, seg = tid & 3;
+            unsigned o[4]; float w[4], unused[4];
+            proj_geom(sUV, spt, R, a.pw, o, w, unused, false);
 #pragma unroll
-        for (int p2 = 0; p2 < 4; p2 += 2) {
-            // two points per round: 32 independent 16-byte loads in flight before the first blend (the phase is latency-bound)
-            unsigned o[2][4]; float w[2][4], unused[4];
-            float4 t[2][G][2][4];
+            for (int g = 0; g < G; g++) {
+                // 32 independent 16-byte loads in flight before the first blend (the phase is latency-bound)
+                float4 t[8][4];
 #pragma unroll
-            for (int pp = 0; pp < 2; pp++) {
-                proj_geom(sUV, 16 * (p2 + pp) + j, R, a.pw, o[pp], w[pp], unused, false);
+                for (int i = 0; i < 8; i++) {
+                    const unsigned col = (unsigned)(a.hw[g].pcol + 16 * i + 4 * seg);
 #pragma unroll
-                for (int g = 0; g < G; g++)
+                    for (int k = 0; k < 4; k++) t[i][k] = *reinterpret_cast<const float4 *>(Pb + o[k] + col);
+                }
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const unsigned col = (unsigned)(a.hw[g].pcol + 32 * wave + 16 * nt + 4 * q);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) t[pp][g][nt][k] = *reinterpret_cast<const float4 *>(Pb + o[pp][k] + col);
-                    }
+                for (int i = 0; i < 8; i++) {
+                    const float4 nw = t[i][0], ne = t[i][1], sw = t[i][2], se = t[i][3];
+                    *reinterpret_cast<float4 *>(stage + spt * PS + g * 128 + 16 * i + 4 * seg) = make_float4(TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w));
+                }
             }
-#pragma unroll
-            for (int pp = 0; pp < 2; pp++)
-#pragma unroll
-                for (int g = 0; g < G; g++)
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const float4 nw = t[pp][g][nt][0], ne = t[pp][g][nt][1], sw = t[pp][g][nt][2], se = t[pp][g][nt][3];
-                        const float *wq = w[pp];
-                        acc1[g].v[nt][p2 + pp] = (f32x4){TAPSUM_(x, wq), TAPSUM_(y, wq), TAPSUM_(z, wq), TAPSUM_(w, wq)};
-                    }
         }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const float4 v = *reinterpret_cast<const float4 *>(stage + (16 * p + j) * PS + g * 128 + 32 * wave + 16 * nt + 4 * q);
+                    acc1[g].v[nt][p] = (f32x4){v.x, v.y, v.z, v.w};
+                }
+        __syncthreads();                        // the chunk double buffer takes region 0 over
     }
 #endif
     PCLK(0);
@@ -701,8 +712,66 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     }
     const int mypt = 16 * wave + j;
     const float px_ = sPt[mypt * 3], py_ = sPt[mypt * 3 + 1], iz_ = 1.0f / sPt[mypt * 3 + 2];
-    __syncthreads();        // region 0 changes role again: activation planes -> tap-difference buffers + weight slab
+    const float kx = 2.0f / a.crop * a.fx, ky = 2.0f / a.crop * a.fy;
+    const float j0x = kx * iz_, j0y = ky * iz_, j0zu = -kx * px_ * iz_ * iz_, j0zv = -ky * py_ * iz_ * iz_;
     float gx = 0.f, gy = 0.f, gz = 0.f;     // coordinate-gradient partials of point mypt over the channels this lane sees
+#ifndef PJ_NOBWD
+    if (USEP) {
+        // im_feat part of the coordinate gradient: d/du = sum_t cu_t <d(hidden-1), P row of tap t> (and cv for d/dv).  Same lane layout as the
+        // forward blend -- thread = (point, 8-column block group): the four lanes of a point are adjacent and read 128 contiguous bytes of a row
+        // per pair of instructions -- with d(hidden-1) taken straight from the operand planes (hi + lo), which are [k block][point] already.
+        // Lane 4 j' + seg of wave w works on point 16 w + j': the owner lane (q = 0, j = j') of the SAME wave picks the sums up with one shuffle.
+        const int R = a.res[0];
+        const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
+        const int spt = tid >> 2, seg = tid & 3;
+        unsigned o[4]; float cu[4], cv[4];
+        proj_geom(sUV, spt, R, a.pw, o, cu, cv, true);
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            float dg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2 += 2) {
+                // two 8-column blocks per round: 16 independent 16-byte loads in flight, then 64 multiply-adds
+                float4 pr[2][4][2];
+                uint4 xh[2], xl[2];
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const int kb = 4 * (i2 + ii) + seg;
+                    const unsigned col = (unsigned)(a.hw[g].pcol + 8 * kb);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        pr[ii][k][0] = *reinterpret_cast<const float4 *>(Pb + o[k] + col); pr[ii][k][1] = *reinterpret_cast<const float4 *>(Pb + o[k] + col + 4);
+                    }
+                    xh[ii] = Hp[g * 2048 + kb * 64 + spt]; xl[ii] = Hp[g * 2048 + 1024 + kb * 64 + spt];
+                }
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const h8 hh = as_h8(xh[ii]), hl = as_h8(xl[ii]);
+                    float x[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x[t] = (float)hh[t] + (float)hl[t];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float4 p0 = pr[ii][k][0], p1 = pr[ii][k][1];
+                        dg[k] = __builtin_fmaf(x[7], p1.w, __builtin_fmaf(x[6], p1.z, __builtin_fmaf(x[5], p1.y, __builtin_fmaf(x[4], p1.x,
+                                __builtin_fmaf(x[3], p0.w, __builtin_fmaf(x[2], p0.z, __builtin_fmaf(x[1], p0.y, __builtin_fmaf(x[0], p0.x, dg[k]))))))));
+                    }
+                }
+            }
+            const float ks = sInv[g * 64 + spt] * a.hw[g].cb[0] * (1.0f / ACT_SCALE);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dot[k] = __builtin_fmaf(ks, dg[k], dot[k]);
+        }
+        float su = cu[0] * dot[0] + cu[1] * dot[1] + cu[2] * dot[2] + cu[3] * dot[3];
+        float sv = cv[0] * dot[0] + cv[1] * dot[1] + cv[2] * dot[2] + cv[3] * dot[3];
+        su += __shfl_xor(su, 1, 64); sv += __shfl_xor(sv, 1, 64);
+        su += __shfl_xor(su, 2, 64); sv += __shfl_xor(sv, 2, 64);
+        su = __shfl(su, 4 * j, 64); sv = __shfl(sv, 4 * j, 64);
+        if (q == 0) { gx = su * j0x; gy = sv * j0y; gz = __builtin_fmaf(sv, j0zv, su * j0zu); }
+    }
+#endif
+    __syncthreads();        // region 0 changes role again: activation planes -> tap-difference buffers + weight slab
     // Every wave needs the whole weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
     // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
     float *bu = reinterpret_cast<float *>(lds), *bv = bu + 64 * TS;      // tap differences of the current chunk
@@ -716,55 +785,6 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     TapGeom<2> tgb;
     { int mi, co; chunk_info(C0, mi, co); taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
     __syncthreads();
-    const float kx = 2.0f / a.crop * a.fx, ky = 2.0f / a.crop * a.fy;
-    const float j0x = kx * iz_, j0y = ky * iz_, j0zu = -kx * px_ * iz_ * iz_, j0zv = -ky * py_ * iz_ * iz_;
-#ifndef PJ_NOBWD
-    if (USEP) {
-        // im_feat part of the coordinate gradient: d/du = sum_t cu_t <d(hidden-1), P row of tap t> (and cv for d/dv), the dot products over the
-        // 8 hidden units per K32 step this lane holds; the other lane groups q add theirs in the final reduction
-        const int R = a.res[0];
-        const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
-        unsigned o[4]; float cu[4], cv[4];
-        proj_geom(sUV, mypt, R, a.pw, o, cu, cv, true);
-        float dot[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            float dg[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; s2 += 2) {
-                // two K32 steps per round: 16 independent 16-byte loads in flight, then 64 multiply-adds
-                float4 pr[2][4][2];
-#pragma unroll
-                for (int ss = 0; ss < 2; ss++) {
-                    const unsigned col = (unsigned)(a.hw[g].pcol + 32 * (s2 + ss) + 8 * q);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        pr[ss][k][0] = *reinterpret_cast<const float4 *>(Pb + o[k] + col); pr[ss][k][1] = *reinterpret_cast<const float4 *>(Pb + o[k] + col + 4);
-                    }
-                }
-#pragma unroll
-                for (int ss = 0; ss < 2; ss++) {
-                    const h8 hh = as_h8(dh[g][s2 + ss][0]), hl = as_h8(dh[g][s2 + ss][1]);
-                    float x[8];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) x[t] = (float)hh[t] + (float)hl[t];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float4 p0 = pr[ss][k][0], p1 = pr[ss][k][1];
-                        dg[k] = __builtin_fmaf(x[7], p1.w, __builtin_fmaf(x[6], p1.z, __builtin_fmaf(x[5], p1.y, __builtin_fmaf(x[4], p1.x,
-                                __builtin_fmaf(x[3], p0.w, __builtin_fmaf(x[2], p0.z, __builtin_fmaf(x[1], p0.y, __builtin_fmaf(x[0], p0.x, dg[k]))))))));
-                    }
-                }
-            }
-            const float ks = kscale[g] * (1.0f / ACT_SCALE);
-#pragma unroll
-            for (int k = 0; k < 4; k++) dot[k] = __builtin_fmaf(ks, dg[k], dot[k]);
-        }
-        const float su = cu[0] * dot[0] + cu[1] * dot[1] + cu[2] * dot[2] + cu[3] * dot[3];
-        const float sv = cv[0] * dot[0] + cv[1] * dot[1] + cv[2] * dot[2] + cv[3] * dot[3];
-        gx = su * j0x; gy = sv * j0y; gz = __builtin_fmaf(sv, j0zv, su * j0zu);
-    }
-#endif
     PCLK(3);
     for (int ci = C0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);

@@ -43,7 +43,7 @@ def _gn(x, sd, p, groups=32, relu=False):
         B, C, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
         y = torch.empty_like(x, memory_format=torch.channels_last)
-        ws = torch.empty(2 * B * C + B * groups, dtype=torch.float64, device=x.device)
+        ws = torch.empty(L.lib().vt_groupnorm_workspace_doubles(B, H * W, C, groups), dtype=torch.float64, device=x.device)
         L.check(L.lib().vt_groupnorm_nhwc(x.data_ptr(), sd[p + ".weight"].data_ptr(), sd[p + ".bias"].data_ptr(), B, H * W, C, groups, 1e-5, int(relu),
                                           ws.data_ptr(), y.data_ptr(), L.stream_ptr()))
         return y
@@ -119,9 +119,9 @@ class HGFilterEncoder:
             for i, co in zip((1, 2, 3), couts):
                 wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
                 if self._hip_conv_ok(wn, H, W, True):
-                    ws = torch.empty(2 * B * C + B * 32, dtype=torch.float64, device=x.device)
+                    ws = torch.empty(L.lib().vt_groupnorm_workspace_doubles(B, H * W, C, 32), dtype=torch.float64, device=x.device)
                     L.check(L.lib().vt_groupnorm_stats(src.data_ptr(), cstride, coff, B, H * W, C, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
-                    L.check(L.lib().vt_conv3x3_forward_gn(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr() + 16 * B * C,
+                    L.check(L.lib().vt_conv3x3_forward_gn(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(),
                                                           sd[gn + ".weight"].data_ptr(), sd[gn + ".bias"].data_ptr(), 32, B, H, W, out.data_ptr(), Ct, off, L.stream_ptr()))
                 else:
                     xin = src if (cstride == C and coff == 0) else src[:, coff:coff + C]
