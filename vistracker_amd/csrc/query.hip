@@ -131,6 +131,30 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 //   Taps    -- per CHUNK: the 4 x 2 float4 tap loads, in flight in registers while the previous chunk's MFMAs run
 template <int NC> struct TapGeom { unsigned o[2][4]; float c[NC][2][4]; };
 struct Taps { float4 t[2][4]; };
+// Buffer loads (MUBUF): a 128-bit resource descriptor in SGPRs (uniform base + size) + a 32-bit byte offset per lane + an SGPR offset + a 12-bit
+// immediate.  The flat/global form needs a 64-bit address per lane -- one or two VALU instructions per load (v_lshl_add_u64 / v_add_co + v_addc:
+// 26 M INT64 + part of the 71 M INT32 of the 462 M VALU wave-instructions of a launch, profiles/r02_experiments.md) -- the buffer form none, and
+// a read beyond the size returns zeros instead of faulting.
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    // base and size are workgroup-uniform at every call site, but hipcc cannot always prove it (pointers picked from the by-value argument
+    // struct with a run-time map index) and would wrap EVERY load in a waterfall loop: pin the descriptor to SGPRs
+    const unsigned long long p = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ float4 bload_f4(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0)); }
+__device__ __forceinline__ uint4 bload_u4(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0)); }
+#ifdef GATHER_LDS_ABL      /* TIMING ABLATION (wrong results): gathers served from a 16 KB LDS window instead of the vector memory path; 1 = taps, 2 = P rows */
+extern __shared__ __attribute__((aligned(16))) float4 lds_abl_[];
+#define GATHER_F4(r_, voff_, soff_) ((GATHER_LDS_ABL & 1) ? lds_abl_[((voff_) >> 4) & 1023] : bload_f4(r_, voff_, soff_))
+#define GATHER_P4(r_, voff_, soff_) ((GATHER_LDS_ABL & 2) ? lds_abl_[((voff_) >> 4) & 1023] : bload_f4(r_, voff_, soff_))
+#else
+#define GATHER_F4(r_, voff_, soff_) bload_f4(r_, voff_, soff_)
+#define GATHER_P4(r_, voff_, soff_) bload_f4(r_, voff_, soff_)
+#endif
 
 template <int NC>
 __device__ __forceinline__ void taps_geom(const QArgs &a, int mi, const float *sUV, int tid, TapGeom<NC> &g)
@@ -170,11 +194,11 @@ template <int NC>
 __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const TapGeom<NC> &g, Taps &r)
 {
     const int R = a.res[mi], C = map_channels(mi);
-    const char *__restrict__ fb = reinterpret_cast<const char *>(a.maps[mi] + (size_t)b * R * R * C + co);
+    const rsrc_t fb = make_rsrc(a.maps[mi] + (size_t)b * R * R * C, (unsigned)(R * R * C) * 4u);
 #pragma unroll
     for (int pass = 0; pass < 2; pass++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) r.t[pass][k] = *reinterpret_cast<const float4 *>(fb + g.o[pass][k]);
+        for (int k = 0; k < 4; k++) r.t[pass][k] = GATHER_F4(fb, g.o[pass][k], (unsigned)co * 4u);
 }
 #define TAPSUM_(c_, w_) __builtin_fmaf(se.c_, (w_)[3], __builtin_fmaf(sw.c_, (w_)[2], __builtin_fmaf(ne.c_, (w_)[1], nw.c_ * (w_)[0])))
 // blend the taps to (scaled) features, split, and store into the K-block-major chunk planes [4 kb][64 pt][8 halves] (forward) ...
@@ -316,15 +340,23 @@ __device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *l
 }
 // out[32 rows of this wave][64 pts] = M[128 x 128] (A, T-pack fragments from L2) x X[128 x 64 pts] (B, LDS planes), K = 128.
 // The weights do not depend on the LDS contents: all 16 fragments are requested BEFORE the barrier that publishes X (wprefetch).
+#ifndef WPF_BUF
+#define WPF_BUF 0     /* hidden-layer weight fragments as buffer loads: measured 0.5 % SLOWER than the saddr global form the compiler already finds there */
+#endif
 struct WPre { uint4 v[4][2][2]; };
 __device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp, int wave, int lane)
 {
+    const rsrc_t wr = make_rsrc(Wp, 4u * 1024u * 16u);          // [4 K32 steps][4 waves][2 nt][hi|lo][64 lanes] uint4
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
+#if WPF_BUF
+            for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = bload_u4(wr, (unsigned)(wave * 256 + lane) * 16u + (unsigned)((nt * 2 + hl) * 1024), (unsigned)s * 16384u);
+#else
             for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[(unsigned)(wave * 256 + lane) + (unsigned)(s * 1024 + (nt * 2 + hl) * 64)];
+#endif
 }
 __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
 {
@@ -379,6 +411,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         const int tiles = (a.N + 63) >> 6, L = blockIdx.x;
         if ((a.B & 7) == 0) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / tiles); tile = slot % tiles; }
         else { b = L / tiles; tile = L % tiles; }
+        // the integer division runs on the VALU: without this the frame index -- and every base address and buffer descriptor derived from
+        // it -- lives in VGPRs and each use pays v_readfirstlane
+        b = __builtin_amdgcn_readfirstlane(b); tile = __builtin_amdgcn_readfirstlane(tile);
     }
     const int n0 = tile * 64;
 #ifdef PHASE_CLK
@@ -423,21 +458,22 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         float *stage = reinterpret_cast<float *>(lds);
         static_assert(64 * PS * 4 <= 16 * (R0 + 256), "the staged rows must fit region 0 + Go");
         const int R = a.res[0];
-        const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
+        const rsrc_t Pb = make_rsrc(a.proj + (size_t)b * R * R * a.pw, (unsigned)(R * R * a.pw) * 4u);
         {
             const int spt = tid >> 2, seg = tid & 3;
             unsigned o[4]; float w[4], unused[4];
             proj_geom(sUV, spt, R, a.pw, o, w, unused, false);
 #pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = (o[k] + 4u * seg) * 4u;         // byte offset of this thread's first column group in tap row k
+#pragma unroll
             for (int g = 0; g < G; g++) {
                 // 32 independent 16-byte loads in flight before the first blend (the phase is latency-bound)
                 float4 t[8][4];
+                const unsigned pc = (unsigned)a.hw[g].pcol * 4u;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const unsigned col = (unsigned)(a.hw[g].pcol + 16 * i + 4 * seg);
+                for (int i = 0; i < 8; i++)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) t[i][k] = *reinterpret_cast<const float4 *>(Pb + o[k] + col);
-                }
+                    for (int k = 0; k < 4; k++) t[i][k] = GATHER_P4(Pb, o[k] + 64u * i, pc);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const float4 nw = t[i][0], ne = t[i][1], sw = t[i][2], se = t[i][3];
@@ -466,9 +502,10 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     const unsigned wvo = (unsigned)(wave * 256 + lane);       // per-lane part of a T-pack fragment index; the rest is uniform / immediate
 #define LOAD_W1(step_)                                                                                                       \
     _Pragma("unroll") for (int g = 0; g < G; g++) {                                                                          \
-        const uint4 *__restrict__ wp_ = a.hw[g].w1p + (size_t)(step_) * 1024;                                                \
+        const rsrc_t wp_ = make_rsrc(a.hw[g].w1p, 0x40000000u);                                                              \
         _Pragma("unroll") for (int nt = 0; nt < 2; nt++)                                                                     \
-            _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[g][nt][hl] = wp_[wvo + (nt * 2 + hl) * 64];                  \
+            _Pragma("unroll") for (int hl = 0; hl < 2; hl++)                                                                 \
+                wf[g][nt][hl] = bload_u4(wp_, wvo * 16u + (unsigned)((nt * 2 + hl) * 1024), (unsigned)(step_) * 16384u);     \
     }
     LOAD_W1(C0)
     // software pipeline: the features of chunk ci+1 are blended / split / stored (VALU + LDS stores) in the same barrier interval
@@ -722,10 +759,12 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         // per pair of instructions -- with d(hidden-1) taken straight from the operand planes (hi + lo), which are [k block][point] already.
         // Lane 4 j' + seg of wave w works on point 16 w + j': the owner lane (q = 0, j = j') of the SAME wave picks the sums up with one shuffle.
         const int R = a.res[0];
-        const float *__restrict__ Pb = a.proj + (size_t)b * R * R * a.pw;
+        const rsrc_t Pb = make_rsrc(a.proj + (size_t)b * R * R * a.pw, (unsigned)(R * R * a.pw) * 4u);
         const int spt = tid >> 2, seg = tid & 3;
         unsigned o[4]; float cu[4], cv[4];
         proj_geom(sUV, spt, R, a.pw, o, cu, cv, true);
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = (o[k] + 8u * seg) * 4u;             // byte offset of this thread's first 8-column block in tap row k
         float dot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -738,10 +777,10 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #pragma unroll
                 for (int ii = 0; ii < 2; ii++) {
                     const int kb = 4 * (i2 + ii) + seg;
-                    const unsigned col = (unsigned)(a.hw[g].pcol + 8 * kb);
+                    const unsigned pc = (unsigned)a.hw[g].pcol * 4u;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        pr[ii][k][0] = *reinterpret_cast<const float4 *>(Pb + o[k] + col); pr[ii][k][1] = *reinterpret_cast<const float4 *>(Pb + o[k] + col + 4);
+                        pr[ii][k][0] = GATHER_P4(Pb, o[k] + 128u * (i2 + ii), pc); pr[ii][k][1] = GATHER_P4(Pb, o[k] + 128u * (i2 + ii) + 16u, pc);
                     }
                     xh[ii] = Hp[g * 2048 + kb * 64 + spt]; xl[ii] = Hp[g * 2048 + 1024 + kb * 64 + spt];
                 }
@@ -864,8 +903,8 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             dz[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const uint4 *f = a.hw[g].w1c + (size_t)NCHUNK * 1024 + ((s * 2) * 2) * 64 + lane;
-                const h8 wh = as_h8(f[0]), wl = as_h8(f[64]);
+                const rsrc_t fr = make_rsrc(a.hw[g].w1c + (size_t)NCHUNK * 1024, 1024u * 16u);
+                const h8 wh = as_h8(bload_u4(fr, (unsigned)lane * 16u + (unsigned)(s * 4096), 0u)), wl = as_h8(bload_u4(fr, (unsigned)lane * 16u + (unsigned)(s * 4096 + 1024), 0u));
                 const h8 xh = as_h8(dh[g][s][0]), xl = as_h8(dh[g][s][1]);
                 dz[g] = MFMAH(wh, xh, dz[g]); dz[g] = MFMAH(wh, xl, dz[g]); dz[g] = MFMAH(wl, xh, dz[g]);
             }
@@ -1086,6 +1125,9 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
         const int tiles = (a.N + 63) >> 6, L = blockIdx.x;
         if ((a.B & 7) == 0) { const int slot = L >> 3; b = (L & 7) + 8 * (slot / tiles); tile = slot % tiles; }
         else { b = L / tiles; tile = L % tiles; }
+        // the integer division runs on the VALU: without this the frame index -- and every base address and buffer descriptor derived from
+        // it -- lives in VGPRs and each use pays v_readfirstlane
+        b = __builtin_amdgcn_readfirstlane(b); tile = __builtin_amdgcn_readfirstlane(tile);
     }
     const int n0 = tile * 64;
 #ifdef PHASE_CLK
