@@ -1,11 +1,11 @@
 """A/B of the two kernels behind vt_query_human_loss at the bench shape (B=96, SMPL vertices, 2-D Morton order, hoisted projection):
-time per launch and agreement of terms / coordinate gradients.  usage: qab.py [reps=20]"""
+time per launch and agreement of terms / coordinate gradients.  usage: qab.py [reps=20] [B=96]"""
 import sys, ctypes as C; sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import torch.nn.functional as F
 from vistracker_amd import ops, synthetic as syn, _lib as L
 from vistracker_amd.fitting import morton_order_device
-B, N = 96, 6890
+B, N = (int(sys.argv[2]) if len(sys.argv) > 2 else 96), 6890
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = "cuda"; g = torch.Generator(device=dev); g.manual_seed(0)
 maps = {}

@@ -100,27 +100,43 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
     fbox[(size_t)b * 2 * NF + f2] = make_int2((x0 & 0xffff) | (x1 << 16), (y0 & 0xffff) | (y1 << 16));
 }
 
-// Rasterisation by SCATTER: one wave per (frame, front face) visits only the pixels of the face's box (a 2500-face object covers
+// Rasterisation by SCATTER: a group of SIL_G lanes per ORIGINAL face visits only the pixels of the face's box (a 2500-face object covers
 // each pixel ~twice, so this is ~35x fewer point-in-triangle tests than testing every pixel against a per-tile face list) and
 // resolves visibility with a 64-bit atomicMin on key = (bits of z) << 32 | face id: nearest face wins, ties go to the smaller id.
+// Of a face's two orientations (f, f + NF) at most one faces the camera; the record of f + NF is that of f with the last two corners
+// swapped (load_face).  A wave is ONE dependent chain record -> box -> pixels -> atomics -> retire, ~4 us of latency at 32 waves per CU
+// whatever its contents (measured: with one face per wave the kernel ran at 3.3 waves / ns, the same as the backward kernel; halving the
+// number of waves by pairing the orientations changed little) -- so the latency is shared by 64 / SIL_G faces per wave, whose boxes
+// (~40 pixels for the fit's object at 256^2) also fill the lanes better than one box per 64 lanes.
+#ifndef SIL_G
+#define SIL_G 16
+#endif
 __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
                                                           unsigned long long *__restrict__ zbuf)
 {
-    // the face index is wave-uniform: say so (readfirstlane), and the box + corner record become scalar loads that are all in flight
-    // together -- one memory round trip per wave instead of box -> branch -> corners
-    const int f2 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;
-    if (f2 >= 2 * NF) return;
-    float fc[9];
+    constexpr int FPW = 64 / SIL_G;
+    const int lane = threadIdx.x & 63, gl = lane % SIL_G, b = blockIdx.y;
+    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + lane / SIL_G;
+    if (f >= NF) return;
+    float fa[9];
 #pragma unroll
-    for (int e = 0; e < 9; e++) fc[e] = fcbuf[((size_t)b * 2 * NF + f2) * 9 + e];
-    const int2 bb = fbox[(size_t)b * 2 * NF + f2];
+    for (int e = 0; e < 9; e++) fa[e] = fcbuf[((size_t)b * 2 * NF + f) * 9 + e];
+    const int2 bbA = fbox[(size_t)b * 2 * NF + f], bbB = fbox[(size_t)b * 2 * NF + NF + f];
+    const bool useA = (bbA.x & 0xffff) <= (bbA.x >> 16);
+    const int2 bb = useA ? bbA : bbB;
+    const int f2 = useA ? f : f + NF;
+    const float fc[9] = {fa[0], fa[1], fa[2], useA ? fa[3] : fa[6], useA ? fa[4] : fa[7], useA ? fa[5] : fa[8], useA ? fa[6] : fa[3], useA ? fa[7] : fa[4], useA ? fa[8] : fa[5]};
     const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
     if (x0 > x1) return;
     const float den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
     if (den == 0.f) return;
     const int w = x1 - x0 + 1, npx = w * (y1 - y0 + 1);
-    for (int p = lane; p < npx; p += 64) {
-        const int xi = x0 + p % w, yi = y0 + p / w;
+    const float rw = 1.0f / (float)w;
+    for (int p = gl; p < npx; p += SIL_G) {
+        // p = q w + r without the ~40-instruction integer division: float estimate (p < 2^16 is exact in fp32), corrected by at most one
+        int q = (int)((float)p * rw), r = p - q * w;
+        if (r >= w) { q++; r -= w; } else if (r < 0) { q--; r += w; }
+        const int xi = x0 + r, yi = y0 + q;
         const float xp = (2.0f * xi + 1 - is) / is, yp = (2.0f * yi + 1 - is) / is;
         if (((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
             ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
@@ -177,18 +193,21 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
                                     const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj)
 {
-    const int f2 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;   // wave-uniform
-    if (f2 >= 2 * NF) return;
-    // visibility flag, vertex ids and corners: independent scalar loads, requested before the first branch
-    const int vis = visible[(size_t)b * 2 * NF + f2];
-    const int f = f2 < NF ? f2 : f2 - NF;
+    // one wave per ORIGINAL face (see sil_scatter_kernel): at most one of its two orientations won pixels
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;   // wave-uniform
+    if (f >= NF) return;
+    // visibility flags, vertex ids and corners: independent scalar loads, requested before the first branch
+    const int visA = visible[(size_t)b * 2 * NF + f], visB = visible[(size_t)b * 2 * NF + NF + f];
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-    float P[3][2];          // corners in pixel units
+    float PA[3][2];         // corners of orientation f in pixel units
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        P[k][0] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k] * is + is - 1);
-        P[k][1] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f2) * 9 + 3 * k + 1] * is + is - 1);
+        PA[k][0] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f) * 9 + 3 * k] * is + is - 1);
+        PA[k][1] = 0.5f * (fcbuf[((size_t)b * 2 * NF + f) * 9 + 3 * k + 1] * is + is - 1);
     }
+    const int vis = visA | visB;
+    const int f2 = visA ? f : f + NF;
+    const float P[3][2] = {{PA[0][0], PA[0][1]}, {visA ? PA[1][0] : PA[2][0], visA ? PA[1][1] : PA[2][1]}, {visA ? PA[2][0] : PA[1][0], visA ? PA[2][1] : PA[1][1]}};
     if (!vis) return;
     if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
     const int *fim = face_index + (size_t)b * is * is;
@@ -345,7 +364,7 @@ extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *face
     hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible);
     VT_LAUNCH_CHECK();
@@ -365,7 +384,7 @@ extern "C" int vt_triplane_render(const float *verts, const float *center, int B
     hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B3), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B3 * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((2 * NF + 3) / 4, B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B3), dim3(256), 0, st, w.zbuf, NF, size, masks, face_index, w.visible);
     VT_LAUNCH_CHECK();
@@ -381,7 +400,7 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
     VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(double) * (size_t)B * NV * 2, st));
     hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3(size / 64, size, B), dim3(64), 0, st, face_index, d_image, size, w.rowmask, w.colmask);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((2 * NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
                        w.rowmask, w.colmask, eps, w.gproj);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts);
