@@ -111,29 +111,14 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
 #ifndef SIL_G
 #define SIL_G 16
 #endif
-__global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
-                                                          unsigned long long *__restrict__ zbuf)
+#define SIL_BIG (8 * SIL_G)     /* boxes above this many pixels are rasterised by the whole wave (64 lanes), not by the face's lane group */
+// pixels start, start + stride, ... < npx of the box (x0, y0, width w) of face f2 with corners fc
+__device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den, int f2, int x0, int y0, int w, int npx, int start, int stride, int is,
+                                                unsigned long long *__restrict__ zrow)
 {
-    constexpr int FPW = 64 / SIL_G;
-    const int lane = threadIdx.x & 63, gl = lane % SIL_G, b = blockIdx.y;
-    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + lane / SIL_G;
-    if (f >= NF) return;
-    float fa[9];
-#pragma unroll
-    for (int e = 0; e < 9; e++) fa[e] = fcbuf[((size_t)b * 2 * NF + f) * 9 + e];
-    const int2 bbA = fbox[(size_t)b * 2 * NF + f], bbB = fbox[(size_t)b * 2 * NF + NF + f];
-    const bool useA = (bbA.x & 0xffff) <= (bbA.x >> 16);
-    const int2 bb = useA ? bbA : bbB;
-    const int f2 = useA ? f : f + NF;
-    const float fc[9] = {fa[0], fa[1], fa[2], useA ? fa[3] : fa[6], useA ? fa[4] : fa[7], useA ? fa[5] : fa[8], useA ? fa[6] : fa[3], useA ? fa[7] : fa[4], useA ? fa[8] : fa[5]};
-    const int x0 = bb.x & 0xffff, x1 = bb.x >> 16, y0 = bb.y & 0xffff, y1 = bb.y >> 16;
-    if (x0 > x1) return;
-    const float den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
-    if (den == 0.f) return;
-    const int w = x1 - x0 + 1, npx = w * (y1 - y0 + 1);
     const float rw = 1.0f / (float)w;
-    for (int p = gl; p < npx; p += SIL_G) {
-        // p = q w + r without the ~40-instruction integer division: float estimate (p < 2^16 is exact in fp32), corrected by at most one
+    for (int p = start; p < npx; p += stride) {
+        // p = q w + r without the ~40-instruction integer division: float estimate (p < 2^20 is exact in fp32), corrected by at most one
         int q = (int)((float)p * rw), r = p - q * w;
         if (r >= w) { q++; r -= w; } else if (r < 0) { q--; r += w; }
         const int xi = x0 + r, yi = y0 + q;
@@ -149,7 +134,46 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
         const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);
         if (!(zp > SIL_NEAR && zp < SIL_FAR)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f2;     // zp > 0: float order == uint order
-        atomicMin(zbuf + ((size_t)b * is + yi) * is + xi, key);
+        atomicMin(zrow + (size_t)yi * is + xi, key);
+    }
+}
+__global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
+                                                          unsigned long long *__restrict__ zbuf)
+{
+    constexpr int FPW = 64 / SIL_G;
+    const int lane = threadIdx.x & 63, gl = lane % SIL_G, b = blockIdx.y;
+    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + lane / SIL_G;
+    unsigned long long *zrow = zbuf + (size_t)b * is * is;
+    float fc[9]; float den = 0.f; int f2 = 0, x0 = 0, y0 = 0, w = 1, npx = 0;
+    if (f < NF) {
+        float fa[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) fa[e] = fcbuf[((size_t)b * 2 * NF + f) * 9 + e];
+        const int2 bbA = fbox[(size_t)b * 2 * NF + f], bbB = fbox[(size_t)b * 2 * NF + NF + f];
+        const bool useA = (bbA.x & 0xffff) <= (bbA.x >> 16);
+        const int2 bb = useA ? bbA : bbB;
+        f2 = useA ? f : f + NF;
+        fc[0] = fa[0]; fc[1] = fa[1]; fc[2] = fa[2];
+        fc[3] = useA ? fa[3] : fa[6]; fc[4] = useA ? fa[4] : fa[7]; fc[5] = useA ? fa[5] : fa[8];
+        fc[6] = useA ? fa[6] : fa[3]; fc[7] = useA ? fa[7] : fa[4]; fc[8] = useA ? fa[8] : fa[5];
+        x0 = bb.x & 0xffff; y0 = bb.y & 0xffff;
+        const int x1 = bb.x >> 16, y1 = bb.y >> 16;
+        den = fc[0] * (fc[4] - fc[7]) + fc[3] * (fc[7] - fc[1]) + fc[6] * (fc[1] - fc[4]);
+        if (x0 <= x1 && den != 0.f) { w = x1 - x0 + 1; npx = w * (y1 - y0 + 1); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 9; e++) fc[e] = 0.f;
+    }
+    const bool big = npx > SIL_BIG;
+    if (!big) sil_scatter_box(fc, den, f2, x0, y0, w, npx, gl, SIL_G, is, zrow);
+    // large boxes (a close-up mesh, a long sliver): all 64 lanes of the wave take the face, its record broadcast from the group's first lane
+    unsigned long long todo = __ballot(big && gl == 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
+        float fb[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) fb[e] = __shfl(fc[e], src, 64);
+        sil_scatter_box(fb, __shfl(den, src, 64), __shfl(f2, src, 64), __shfl(x0, src, 64), __shfl(y0, src, 64), __shfl(w, src, 64), __shfl(npx, src, 64), lane, 64, is, zrow);
     }
 }
 

@@ -122,10 +122,13 @@ def smplh_model(seed: int = 0) -> dict:
     shapedirs[:, 0, 1] += verts[:, 0] * 0.03
     shapedirs[:, 2, 1] += verts[:, 2] * 0.03
     posedirs = rng.normal(0, 0.001, size=(NUM_VERTS, 3, NUM_POSEDIRS))
-    # closed-ish triangle list (topology is irrelevant to the fit; only the count matters)
-    faces = np.stack([np.arange(13776) % NUM_VERTS,
-                      (np.arange(13776) * 7 + 1) % NUM_VERTS,
-                      (np.arange(13776) * 13 + 5) % NUM_VERTS], 1).astype(np.int32)
+    # triangle list with the real count (13776) and LOCAL faces: every vertex spans two triangles with its three nearest neighbours (edges of a
+    # centimetre or two, like the real mesh).  The topology is irrelevant to the fit itself, but the triplane renderer and the collision term
+    # rasterise / intersect these faces: random long-range connectivity (faces with 0.7 m edges, 1400 x the image in box pixels) made them
+    # ~100 x slower than on a body mesh.
+    from scipy.spatial import cKDTree
+    nn = cKDTree(verts).query(verts, k=4)[1]
+    faces = np.concatenate([np.stack([nn[:, 0], nn[:, 1], nn[:, 2]], 1), np.stack([nn[:, 0], nn[:, 2], nn[:, 3]], 1)], 0)[:13776].astype(np.int32)
     kintree = np.stack([np.where(par < 0, 2 ** 32 - 1, par).astype(np.int64), np.arange(52)], 0)
     return {
         "v_template": verts.astype(np.float32),
