@@ -46,6 +46,10 @@ class PipelineConfig:
     # reference does both twice only because its two passes are separate processes.  Above the budget the maps are recomputed per batch.
     resident_maps_bytes: float = 160e9
     reuse_neural: bool = True
+    # batches of the joint fit in flight per GPU (one host thread + one HIP stream each, like bench.py): the launch-latency-bound small kernels of
+    # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
+    # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
+    fit_streams: int = 2
     args: SimpleNamespace = field(default_factory=lambda: SimpleNamespace(net_img_size=[512, 512], loadSize=1200, camera_params=None))
 
 
@@ -170,19 +174,56 @@ class SequencePipeline:
         obj_rots = out["hvop"]["obj_angles"] if out["hvop_applied"] else out["obj_smooth"]["obj_angles"]
         lap("5_objrot_smooth_infill")
         # 6  joint optimisation of this rank's batches, gather, pack
-        rows = []
-        for s, e in self._shard(T, cfg.fit_bs):
+        shards = list(self._shard(T, cfg.fit_bs))
+        rows = [None] * len(shards); steps = [None] * len(shards)
+
+        def fit_one(idx, fitter, generator):
+            s, e = shards[idx]
             smpl = SMPLHGenerator.get_smplh(poses[s:e], betas[s:e], trans[s:e], gender, self.device, model_root=self.model_dict)
-            self.generator.reseed(s)
+            if not cfg.reuse_neural:            # the random stream is only drawn from when the surface points are generated again
+                generator.reseed(s)
             bm = ops.FeatureMaps({k: t[s:e] for k, t in big.items()}) if resident else None
             pcg = None
             if cfg.reuse_neural:
                 tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
                 pcg = {"object": {"pca_axis": tt(neural_dict["pca_axis"][s:e]), "centers": tt(neural_dict["centers"][s:e]), "visibility": tt(neural_dict["visibility"][s:e])}}
-            pc, smpl, oR, ot, osc = self.fitter.fit_recon_batch(cfg.args, {k: v[s:e] for k, v in data.items()}, self.generator, smpl, self._t(seq["kpts_crop"][s:e]),
-                                                               obj_rots=np.asarray(obj_rots[s:e], np.float32), maps=bm, pc_generated=pcg)
-            self.log.setdefault("fit_steps", []).append((self.fitter.last["smpl"].steps, self.fitter.last["object"].steps))
-            rows.append(packing.to_rows(smpl.pose.data, smpl.betas.data, smpl.trans.data, oR.data, ot.data, osc))
+            pc, smpl, oR, ot, osc = fitter.fit_recon_batch(cfg.args, {k: v[s:e] for k, v in data.items()}, generator, smpl, self._t(seq["kpts_crop"][s:e]),
+                                                          obj_rots=np.asarray(obj_rots[s:e], np.float32), maps=bm, pc_generated=pcg)
+            steps[idx] = (fitter.last["smpl"].steps, fitter.last["object"].steps)
+            rows[idx] = packing.to_rows(smpl.pose.data, smpl.betas.data, smpl.trans.data, oR.data, ot.data, osc)
+
+        nstream = cfg.fit_streams if (resident and cfg.reuse_neural and not self.fitter.profile) else 1
+        if nstream <= 1 or len(shards) <= 1:
+            for idx in range(len(shards)):
+                fit_one(idx, self.fitter, self.generator)
+        else:
+            import copy, threading
+            streams = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
+            errors = []
+
+            def worker(k):
+                # the network object carries "the feature maps of the current batch" (the reference's filter() -> query() protocol): every
+                # worker gets its own shallow view of the fitter / generator / network (handles and weights are shared)
+                try:
+                    torch.cuda.set_device(self.device)
+                    fitter = copy.copy(self.fitter); fitter.last = {}
+                    generator = copy.copy(self.generator); generator.model = copy.copy(self.generator.model)
+                    with torch.cuda.stream(streams[k]):
+                        for idx in range(k, len(shards), nstream):
+                            fit_one(idx, fitter, generator)
+                except BaseException as ex:      # re-raised in the caller's thread
+                    errors.append(ex)
+
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(nstream)]
+            for t_ in th: t_.start()
+            for t_ in th: t_.join()
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            if errors:
+                raise errors[0]
+        self.log.setdefault("fit_steps", []).extend(steps)
         local = torch.cat(rows, 0) if rows else torch.zeros(0, packing.ROW_WIDTH, device=self.device)
         full = self._gather(local, T, cfg.fit_bs)
         out["recon"] = packing.pack_recon(full, frames, gender, cfg.save_name, self.ctx.smpl, neural=neural_dict)
