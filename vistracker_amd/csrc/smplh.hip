@@ -13,6 +13,7 @@
 //   * forward = 2 launches (pose/chain, vertices); backward = 2 launches (vertex tile partials, per-frame
 //     reduce + chain VJP).  Reductions are two-stage and deterministic (no float atomics).
 #include "common.h"
+#include <cstring>
 
 #define V_ VT_SMPL_V
 #define J_ VT_SMPL_J
@@ -41,8 +42,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SmplParents { int p[J_]; };
 
+#define SP_K 8                          /* most non-zero skinning weights per vertex the sparse LBS takes (SMPL / SMPL-H: 4) */
 struct vt_smplh {
     float *Q_kcv, *Q_t, *W_jv, *W_v64, *J_t, *J_s;
+    float *W_sp;                        // [2][SP_K][VP]: joint index (as int bits) | weight of the k-th non-zero of a vertex, ascending joints, zero padded
+    int nnz;                            // max non-zeros per vertex if <= SP_K (sparse LBS), else 0 (dense LBS)
     SmplParents par;
 };
 
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ Q_kcv, const float *__restrict__ W_jv,
                                                           const float *__restrict__ betas, const float *__restrict__ trans,
                                                           const float *__restrict__ ws, int B,
-                                                          float *__restrict__ verts, float *__restrict__ v_posed)
+                                                          float *__restrict__ verts, float *__restrict__ v_posed, const float *__restrict__ W_sp, int nnz)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sAx = lds;                       // [16][AXS] extended pose rows (GEMM phase) ...
@@ -196,7 +200,13 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
         else val = (k == NP_ + NB_) ? 1.f : 0.f;
         sAx[f * AXS + k] = val;
     }
-    for (int i = tid; i < J_ * 64; i += 256) sW[i] = W_jv[(i >> 6) * VP_ + blockIdx.x * 64 + (i & 63)];
+    if (nnz > 0) {                          // sparse LBS: sW = [nnz][64] joint indices | [nnz][64] weights of the tile
+        for (int i = tid; i < nnz * 64; i += 256) {
+            sW[i] = W_sp[(size_t)(i >> 6) * VP_ + blockIdx.x * 64 + (i & 63)];
+            sW[SP_K * 64 + i] = W_sp[(size_t)(SP_K + (i >> 6)) * VP_ + blockIdx.x * 64 + (i & 63)];
+        }
+    } else
+        for (int i = tid; i < J_ * 64; i += 256) sW[i] = W_jv[(i >> 6) * VP_ + blockIdx.x * 64 + (i & 63)];
     if (tid < FWD_FB * 3) { const int f = tid / 3, b = min(b0 + f, B - 1); sTr[tid] = trans[b * 3 + tid % 3]; }
     __syncthreads();
 
@@ -235,13 +245,27 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
 #pragma unroll
         for (int e = 0; e < 12; e++) T[e] = 0.f;
         const float4 *Af = reinterpret_cast<const float4 *>(sA + f * SAS);
+        // T = sum_j w_j A_j in ascending joint order.  The dense sum spends 52 x 12 multiply-adds per (vertex, frame) on 4 non-zero weights --
+        // two thirds of this kernel's arithmetic; the sparse sum adds the same non-zero terms in the same order (a skipped term is w_j A_j = +-0
+        // and leaves the partial sum unchanged), so both give identical bits.
+        if (nnz > 0) {
+            for (int k = 0; k < nnz; k++) {
+                const int jj = __float_as_int(sW[k * 64 + vv]);
+                const float wj = sW[(SP_K + k) * 64 + vv];
+                const float4 a0 = Af[jj * 3], a1 = Af[jj * 3 + 1], a2 = Af[jj * 3 + 2];
+                T[0] += wj * a0.x; T[1] += wj * a0.y; T[2] += wj * a0.z; T[3] += wj * a0.w;
+                T[4] += wj * a1.x; T[5] += wj * a1.y; T[6] += wj * a1.z; T[7] += wj * a1.w;
+                T[8] += wj * a2.x; T[9] += wj * a2.y; T[10] += wj * a2.z; T[11] += wj * a2.w;
+            }
+        } else {
 #pragma unroll 4
-        for (int jj = 0; jj < J_; jj++) {
-            const float wj = sW[jj * 64 + vv];
-            const float4 a0 = Af[jj * 3], a1 = Af[jj * 3 + 1], a2 = Af[jj * 3 + 2];
-            T[0] += wj * a0.x; T[1] += wj * a0.y; T[2] += wj * a0.z; T[3] += wj * a0.w;
-            T[4] += wj * a1.x; T[5] += wj * a1.y; T[6] += wj * a1.z; T[7] += wj * a1.w;
-            T[8] += wj * a2.x; T[9] += wj * a2.y; T[10] += wj * a2.z; T[11] += wj * a2.w;
+            for (int jj = 0; jj < J_; jj++) {
+                const float wj = sW[jj * 64 + vv];
+                const float4 a0 = Af[jj * 3], a1 = Af[jj * 3 + 1], a2 = Af[jj * 3 + 2];
+                T[0] += wj * a0.x; T[1] += wj * a0.y; T[2] += wj * a0.z; T[3] += wj * a0.w;
+                T[4] += wj * a1.x; T[5] += wj * a1.y; T[6] += wj * a1.z; T[7] += wj * a1.w;
+                T[8] += wj * a2.x; T[9] += wj * a2.y; T[10] += wj * a2.z; T[11] += wj * a2.w;
+            }
         }
         if (b < B && vg < V_) {
             const float p0 = sVp[(f * 64 + vv) * 3], p1 = sVp[(f * 64 + vv) * 3 + 1], p2 = sVp[(f * 64 + vv) * 3 + 2];
@@ -531,6 +555,20 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
     }
     float *W_v64 = new float[(size_t)VP_ * 64]();
     for (int v = 0; v < V_; v++) { for (int j = 0; j < J_; j++) { W_jv[(size_t)j * VP_ + v] = weights[(size_t)v * J_ + j]; W_v64[(size_t)v * 64 + j] = weights[(size_t)v * J_ + j]; } W_v64[(size_t)v * 64 + J_] = 1.0f; }
+    // sparse form of the skinning weights (ascending joints, zero padded) when no vertex has more than SP_K non-zeros
+    float *W_sp = new float[(size_t)2 * SP_K * VP_]();
+    int nnz = 0;
+    for (int v = 0; v < V_; v++) {
+        int k = 0;
+        for (int j = 0; j < J_; j++) {
+            const float w = weights[(size_t)v * J_ + j];
+            if (w == 0.0f) continue;
+            if (k < SP_K) { const int jj = j; memcpy(&W_sp[(size_t)k * VP_ + v], &jj, 4); W_sp[(size_t)(SP_K + k) * VP_ + v] = w; }
+            k++;
+        }
+        nnz = k > nnz ? k : nnz;
+    }
+    h->nnz = nnz <= SP_K ? (nnz > 0 ? nnz : 1) : 0;
     for (int j = 0; j < J_; j++) for (int c = 0; c < 3; c++) {
         double a = 0; double sb[NB_] = {0};
         for (int v = 0; v < V_; v++) {
@@ -545,11 +583,12 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
     int rc = VT_OK;
     if ((rc = vt_upload(&h->Q_kcv, Q_kcv, (size_t)KQ_ * 3 * VP_, st)) || (rc = vt_upload(&h->Q_t, Q_t, (size_t)VP_ * 3 * NQ_, st)) ||
         (rc = vt_upload(&h->W_jv, W_jv, (size_t)J_ * VP_, st)) || (rc = vt_upload(&h->W_v64, W_v64, (size_t)VP_ * 64, st)) ||
-        (rc = vt_upload(&h->J_t, J_t, (size_t)J_ * 3, st)) || (rc = vt_upload(&h->J_s, J_s, (size_t)J_ * 3 * NB_, st))) {
+        (rc = vt_upload(&h->J_t, J_t, (size_t)J_ * 3, st)) || (rc = vt_upload(&h->J_s, J_s, (size_t)J_ * 3 * NB_, st)) ||
+        (rc = vt_upload(&h->W_sp, W_sp, (size_t)2 * SP_K * VP_, st))) {
         return rc;
     }
     VT_HIP(hipStreamSynchronize(st));  // host staging buffers are freed below
-    delete[] Q_kcv; delete[] Q_t; delete[] W_jv; delete[] W_v64; delete[] J_t; delete[] J_s;
+    delete[] Q_kcv; delete[] Q_t; delete[] W_jv; delete[] W_v64; delete[] J_t; delete[] J_s; delete[] W_sp;
     *out = h;
     return VT_OK;
 }
@@ -557,7 +596,7 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
 extern "C" void vt_smplh_destroy(vt_smplh *h)
 {
     if (!h) return;
-    hipFree(h->Q_kcv); hipFree(h->Q_t); hipFree(h->W_jv); hipFree(h->W_v64); hipFree(h->J_t); hipFree(h->J_s);
+    hipFree(h->Q_kcv); hipFree(h->Q_t); hipFree(h->W_jv); hipFree(h->W_v64); hipFree(h->J_t); hipFree(h->J_s); hipFree(h->W_sp);
     delete h;
 }
 
@@ -576,7 +615,7 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
     const size_t lds_f = sizeof(float) * (FWD_FB * SAS + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3);
     VT_LDS_LIMIT(smplh_verts_kernel, lds_f);
     hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
-                       verts, v_posed);
+                       verts, v_posed, h->W_sp, h->nnz);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
