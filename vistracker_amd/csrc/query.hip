@@ -268,6 +268,21 @@ __device__ __forceinline__ void acc_zero(Acc8 &c)
 #pragma unroll
         for (int p = 0; p < 4; p++) c.v[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
+// s_setprio around the MFMA clusters (cdna_hip_programming.md T5): Q_PRIO = 1 raises the wave's priority while it issues matrix instructions, 2 lowers
+// it instead (the partner wave's VALU epilogue goes first).  MEASURED: see profiles/r02_experiments.md; off by default.
+#ifndef Q_PRIO
+#define Q_PRIO 0
+#endif
+#if Q_PRIO == 1
+#define Q_PRIO_MFMA_BEGIN __builtin_amdgcn_s_setprio(2);
+#define Q_PRIO_MFMA_END __builtin_amdgcn_s_setprio(1);
+#elif Q_PRIO == 2
+#define Q_PRIO_MFMA_BEGIN __builtin_amdgcn_s_setprio(0);
+#define Q_PRIO_MFMA_END __builtin_amdgcn_s_setprio(1);
+#else
+#define Q_PRIO_MFMA_BEGIN
+#define Q_PRIO_MFMA_END
+#endif
 // one K32 step of the wave tile: weights (A) w[nt][hi|lo], activations (B) from the planes; hi.hi, hi.lo, lo.hi
 __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const uint4 *Xhi, const uint4 *Xlo, int kb_base, int lane)
 {
@@ -275,6 +290,7 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
     h8 xh[4], xl[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[(kb_base + q) * 64 + 16 * p + j]); xl[p] = as_h8(Xlo[(kb_base + q) * 64 + 16 * p + j]); }
+    Q_PRIO_MFMA_BEGIN
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -287,6 +303,7 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
         for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
+    Q_PRIO_MFMA_END
 }
 // scale + bias + ReLU on the D fragments, result left in the ACT_SCALE-d units the next layer's operands use (bias = ACT_SCALE * b,
 // sc = ACT_SCALE * cf); returns the mask of positive pre-activations, bit 31 - ((nt*4 + p)*4 + r)  (shift-in order)
