@@ -189,6 +189,58 @@ __device__ __forceinline__ void taps_geom(const QArgs &a, int mi, const float *s
         }
     }
 }
+// Shared geometry: taps_geom above is evaluated by all 256 threads -- 8 threads (the 16-byte pieces of a texel) times 2 passes per point -- for
+// every map in BOTH layer-1 loops: ~150 VALU instructions per thread and map, 17 % of the kernel's VALU stream, 8-fold redundant.  Instead ONE
+// wave computes the 64 points of a map (lane = point), writes {4 texel byte offsets, 4 + 4 coefficients} to a two-slot LDS ring a map ahead, and
+// every thread picks up the entries of its two points (3 + 3 ds_read_b128, 8 integer adds for its piece).  Slot = map index & 1; the maps
+// follow each other in index order and every iteration of the loops has a barrier between the ring's writes and reads (see the call sites).
+#define GEO_STRIDE 12
+template <int NC>
+__device__ __forceinline__ void geom_compute(const QArgs &a, int mi, const float *sUV, int pt, float *sGeo)
+{
+    const int R = a.res[mi], C = map_channels(mi), pr = map_proj(mi);
+    const float sc = 0.5f * (float)(R - 1);
+    const float u = sUV[(pr * 64 + pt) * 2], v = sUV[(pr * 64 + pt) * 2 + 1];
+    // grid_sample, bilinear, align_corners=True, zeros padding (geometry.py:12) -- the arithmetic of taps_geom, piece 0
+    float ix = (u + 1.0f) * 0.5f * (float)(R - 1), iy = (v + 1.0f) * 0.5f * (float)(R - 1);
+    ix = fminf(fmaxf(ix, -2.0f), (float)(R + 1)); iy = fminf(fmaxf(iy, -2.0f), (float)(R + 1));
+    const float fxl = floorf(ix), fyl = floorf(iy);
+    const int x0 = (int)fxl, y0 = (int)fyl, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fxl, wy1 = iy - fyl;
+    const bool bx0 = x0 >= 0 && x0 < R, bx1 = x1 >= 0 && x1 < R, by0 = y0 >= 0 && y0 < R, by1 = y1 >= 0 && y1 < R;
+    const bool i0 = bx0 && by0, i1 = bx1 && by0, i2 = bx0 && by1, i3 = bx1 && by1;
+    const int xc0 = min(max(x0, 0), R - 1), xc1 = min(max(x1, 0), R - 1), yc0 = min(max(y0, 0), R - 1), yc1 = min(max(y1, 0), R - 1);
+    const unsigned r0 = (unsigned)(yc0 * R) * (unsigned)C, r1 = (unsigned)(yc1 * R) * (unsigned)C;
+    uint4 o = make_uint4((r0 + (unsigned)(xc0 * C)) * 4u, (r0 + (unsigned)(xc1 * C)) * 4u, (r1 + (unsigned)(xc0 * C)) * 4u, (r1 + (unsigned)(xc1 * C)) * 4u);
+    float4 c0, c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NC == 1) {
+        const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
+        c0 = make_float4(i0 ? wx0 * wy0s : 0.f, i1 ? wx1 * wy0s : 0.f, i2 ? wx0 * wy1s : 0.f, i3 ? wx1 * wy1s : 0.f);
+    } else {
+        const float sx1 = wx1 * sc, sy1 = wy1 * sc, sx0 = sc - sx1, sy0 = sc - sy1;
+        c0 = make_float4(i0 ? -sy0 : 0.f, i1 ? sy0 : 0.f, i2 ? -sy1 : 0.f, i3 ? sy1 : 0.f);
+        c1 = make_float4(i0 ? -sx0 : 0.f, i1 ? -sx1 : 0.f, i2 ? sx0 : 0.f, i3 ? sx1 : 0.f);
+    }
+    float *e = sGeo + (mi & 1) * 64 * GEO_STRIDE + pt * GEO_STRIDE;
+    *reinterpret_cast<uint4 *>(e) = o; *reinterpret_cast<float4 *>(e + 4) = c0;
+    if (NC == 2) *reinterpret_cast<float4 *>(e + 8) = c1;
+}
+template <int NC>
+__device__ __forceinline__ void geom_fetch(int mi, const float *sGeo, int tid, TapGeom<NC> &g)
+{
+    const int sub = tid & 7, pp = tid >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const float *e = sGeo + (mi & 1) * 64 * GEO_STRIDE + (pp + 32 * pass) * GEO_STRIDE;
+        const uint4 o = *reinterpret_cast<const uint4 *>(e);
+        g.o[pass][0] = o.x + (unsigned)(sub * 16); g.o[pass][1] = o.y + (unsigned)(sub * 16); g.o[pass][2] = o.z + (unsigned)(sub * 16); g.o[pass][3] = o.w + (unsigned)(sub * 16);
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float4 c = *reinterpret_cast<const float4 *>(e + 4 + 4 * n);
+            g.c[n][pass][0] = c.x; g.c[n][pass][1] = c.y; g.c[n][pass][2] = c.z; g.c[n][pass][3] = c.w;
+        }
+    }
+}
 // issue the tap loads of chunk (mi, co): uniform base = frame b of map mi + channel offset, per-lane 32-bit byte offsets from the geometry
 template <int NC>
 __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co, const TapGeom<NC> &g, Taps &r)
@@ -273,6 +325,9 @@ __device__ __forceinline__ void acc_zero(Acc8 &c)
 #ifndef Q_PRIO
 #define Q_PRIO 0
 #endif
+#ifndef HID_FUSE
+#define HID_FUSE 0     /* interleave head 1 layer-1 epilogue with head 0 layer-2 GEMM inside a wave (gemm128_epi): MEASURED 0.8 % slower, off */
+#endif
 #if Q_PRIO == 1
 #define Q_PRIO_MFMA_BEGIN __builtin_amdgcn_s_setprio(2);
 #define Q_PRIO_MFMA_END __builtin_amdgcn_s_setprio(1);
@@ -310,6 +365,9 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
 __device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__ bias, float sc, int wave, int lane)
 {
     unsigned m = 0;
+#ifdef HID_ABL      /* TIMING ABLATION (wrong results): no bias / ReLU / mask in the hidden-layer epilogues */
+    return m;
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
         const float4 bb = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4));
@@ -330,6 +388,9 @@ __device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__
 // backward: scale and apply the ReLU mask (bit 31 - k of m belongs to element k)
 __device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
 {
+#ifdef HID_ABL
+    return;
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -382,10 +443,82 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
 }
 
+// ---- a hidden-layer GEMM of one head with the epilogue of ANOTHER fragment set in its shadow -------------------------------------------------
+// The 96 MFMAs of gemm128 keep the matrix pipe busy 16 cycles each but need only 4 issue cycles; the epilogue of a layer (bias, ReLU, mask bit,
+// split, plane store: 6.5 VALU instructions per value) has nothing to do with them when it belongs to the OTHER head.  Source order = schedule:
+// after every 6 MFMAs one pair-step of the epilogue (2 values = ~13 VALU instructions), fenced with sched_barrier(0) so that hipcc neither clusters
+// the MFMAs nor sinks the VALU work behind them.  EPI_FWD: x = fma(e, sc, bias) -> mask bit -> ReLU; EPI_BWD: x = e * sc masked with bit k of `m`.
+struct EpiArgs { const float *bias; float sc; unsigned m; uint2 *hi8, *lo8; };
+template <bool FWD>
+__device__ __forceinline__ void epi_pair(Acc8 &e, int k, EpiArgs &ea, float (&bv)[2][4], uint2 &hi, uint2 &lo, int wave, int lane, float &rmax)
+{
+    // pair k = fragment (nt, p) = k >> 1, values r = 2 (k & 1), 2 (k & 1) + 1
+    const int f = k >> 1, nt = f >> 2, p = f & 3, r0 = 2 * (k & 1);
+    float y[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int r = r0 + t;
+        if (FWD) {
+            const float x = __builtin_fmaf(e.v[nt][p][r], ea.sc, bv[nt][r]);
+            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ea.m) : "v"(x) : "vcc");      // m = 2 m + (x > 0), see bias_relu
+            y[t] = fmaxf(x, 0.f);
+        } else {
+            const int kk = f * 4 + r;
+            const unsigned keep = (unsigned)((int)(ea.m << kk) >> 31);
+            y[t] = __uint_as_float(__float_as_uint(e.v[nt][p][r] * ea.sc) & keep);
+        }
+    }
+    if ((k & 1) == 0) split2(y[0], y[1], hi.x, lo.x, rmax);
+    else {
+        split2(y[0], y[1], hi.y, lo.y, rmax);
+        const int q = lane >> 4, j = lane & 15;
+        const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
+        ea.hi8[idx] = hi; ea.lo8[idx] = lo;
+    }
+}
+template <bool FWD>
+__device__ __forceinline__ void gemm128_epi(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &w, Acc8 &e, EpiArgs &ea, int wave, int lane, float &rmax)
+{
+    const int q = lane >> 4, j = lane & 15;
+    float bv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (FWD) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const float4 bb = *reinterpret_cast<const float4 *>(ea.bias + 32 * wave + 16 * nt + 4 * q);
+            bv[nt][0] = bb.x; bv[nt][1] = bb.y; bv[nt][2] = bb.z; bv[nt][3] = bb.w;
+        }
+    }
+    acc_zero(c);
+    uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        h8 xh[4], xl[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[(4 * s + q) * 64 + 16 * p + j]); xl[p] = as_h8(Xlo[(4 * s + q) * 64 + 16 * p + j]); }
+#pragma unroll
+        for (int ph = 0; ph < 3; ph++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    c.v[nt][p] = MFMAH(as_h8(w.v[s][nt][ph == 2 ? 1 : 0]), ph == 1 ? xl[p] : xh[p], c.v[nt][p]);
+                // 4 MFMAs issued; after every 6th (= every 1.5 of these groups) one pair-step: pairs 4 s .. 4 s + 3 over the 24 MFMAs of step s
+                if ((ph * 2 + nt) == 1 || (ph * 2 + nt) == 2 || (ph * 2 + nt) == 4 || (ph * 2 + nt) == 5) {
+                    const int kq = (ph * 2 + nt) == 1 ? 0 : ((ph * 2 + nt) == 2 ? 1 : ((ph * 2 + nt) == 4 ? 2 : 3));
+                    __builtin_amdgcn_sched_barrier(0);
+                    epi_pair<FWD>(e, 4 * s + kq, ea, bv, hi, lo, wave, lane, rmax);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    }
+}
+
 // Compile-time interleave of the MFMAs of one chunk with the independent VALU work of the next (blend / split of the taps): left to itself
 // hipcc issues the 24 G MFMAs of a K32 step back to back (the wave then waits 16 cycles per MFMA with empty VALU slots) and the ~100 VALU
 // instructions of the blend afterwards (with an idle matrix pipe).  MEASURED: no effect (2.033 vs 2.039 ms per launch of the SMPL-stage kernel; the
 // ISA does interleave 1 MFMA : 2 VALU) -- the second workgroup's wave on the SIMD already fills those slots.  Off by default, -DQ_SGB=1 to repeat.
+// always available: n_ times (1 MFMA, v_ VALU) in the scheduling region that ends here
+#define SCHED_INTERLEAVE(n_, v_) _Pragma("unroll") for (int i_ = 0; i_ < (n_); i_++) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, (v_), 0); }
 #ifndef Q_SGB
 #define Q_SGB 0
 #endif
@@ -405,6 +538,9 @@ template <int G, int MODE, bool USEP>
 __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArgs a)
 {
     constexpr int C0 = USEP ? PROJ_C0 : 0;      // first chunk of the layer-1 loops
+    // shared tap geometry (geom_compute / geom_fetch): -1.9 % on the two-head kernel; the one-head kernels (168 VGPRs, three workgroups per CU)
+    // spill with it and lose 3 %: they keep the per-thread geometry
+    constexpr bool SHGEO = (G == 2);
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden-activation planes per head -> tap-difference
     // buffers + weight slab (layer-1 backward, after the d(hidden-1) fragments moved to registers).
@@ -418,6 +554,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     int *sIn = reinterpret_cast<int *>(sDf + 64);   // [64]
     double *sRed = reinterpret_cast<double *>(sIn + 64);     // [8]
     int *sOvf = reinterpret_cast<int *>(sRed + 8);           // [1] some split operand of this workgroup left the fp16 range
+    float *sGeo = reinterpret_cast<float *>(sOvf + 4);       // [2 slots][64 points][GEO_STRIDE] tap geometry of a map, shared by the workgroup
     float rmax = 0.f;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
@@ -514,7 +651,17 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     PCLK(0);
     Taps tp;
     TapGeom<1> tg;
-    { int mi, co; chunk_info(C0, mi, co); taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
+    {   // geometry of the first two maps of the loop (waves 0 and 1), then every thread fetches its entries of the first
+        int mi, co; chunk_info(C0, mi, co);
+        if (SHGEO) {
+            if (wave == 0) geom_compute<1>(a, mi, sUV, lane, sGeo);
+            if (wave == 1 && mi + 1 < 8) geom_compute<1>(a, mi + 1, sUV, lane, sGeo);
+            __syncthreads();
+            geom_fetch<1>(mi, sGeo, tid, tg);
+        } else
+            taps_geom(a, mi, sUV, tid, tg);
+        taps_issue(a, b, mi, co, tg, tp);
+    }
     uint4 wf[G][2][2];
     const unsigned wvo = (unsigned)(wave * 256 + lane);       // per-lane part of a T-pack fragment index; the rest is uniform / immediate
 #define LOAD_W1(step_)                                                                                                       \
@@ -528,7 +675,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // software pipeline: the features of chunk ci+1 are blended / split / stored (VALU + LDS stores) in the same barrier interval
     // as the MFMAs of chunk ci, so the two interleave; the taps of chunk ci+2 are requested as soon as the tap registers are free
     taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512), reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512 + 256), tid, rmax);
-    { int mi, co; chunk_info(C0 + 1, mi, co); if (co == 0) taps_geom(a, mi, sUV, tid, tg); taps_issue(a, b, mi, co, tg, tp); }
+    { int mi, co; chunk_info(C0 + 1, mi, co); taps_issue(a, b, mi, co, tg, tp); }      // the first map of the loop (im_feat or tmpx) has >= 2 chunks: same geometry
     for (int ci = C0; ci < NCHUNK; ci++) {
         uint4 *buf = lds + (ci & 1) * 512, *nbuf = lds + ((ci + 1) & 1) * 512;      // {hi [4 kb][64], lo [4 kb][64]}
         __syncthreads();                        // chunk ci visible; the other buffer's readers (MFMAs of chunk ci-1) are done
@@ -541,7 +688,15 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         LOAD_W1(ci + 1)
         if (ci + 2 < NCHUNK) {
             int mi, co; chunk_info(ci + 2, mi, co);
-            if (co == 0) taps_geom(a, mi, sUV, tid, tg);            // a new map: new texel offsets / coefficients (uniform branch)
+            if (co == 0) {
+                // a new map (uniform branch): its ring slot was written an iteration or more ago (barrier at the top of the loop); the other slot
+                // was last read when the previous map started, so one wave may now fill it with the map after this one
+                if (SHGEO) {
+                    geom_fetch<1>(mi, sGeo, tid, tg);
+                    if (mi + 1 < 8 && wave == (mi & 3)) geom_compute<1>(a, mi + 1, sUV, lane, sGeo);
+                } else
+                    taps_geom(a, mi, sUV, tid, tg);
+            }
             taps_issue(a, b, mi, co, tg, tp);
         }
     }
@@ -575,7 +730,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // while another head runs its layers 2..4 and backward
     unsigned m1s[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
+    for (int g = 0; g < (HID_FUSE && G == 2 ? 1 : G); g++) {
         m1s[g] = bias_relu(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave, lane);
         store_planes(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane, rmax); OVF_PUBLISH();
     }
@@ -592,7 +747,15 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         wprefetch(wp, hw.w2p, wave, lane);
         const unsigned m1 = m1s[g];
         if (g == 0) __syncthreads();           // hidden-1 planes of all heads visible
-        gemm128(c, Hhi, Hlo, wp, lane);
+        if (HID_FUSE && G == 2 && g == 0) {
+            // layer 2 of head 0 on the matrix pipe WHILE the VALU does the layer-1 epilogue of head 1 (bias, ReLU, mask, split, plane stores): two
+            // independent instruction streams of ONE wave, interleaved 1 MFMA : 3 VALU (an MFMA occupies its pipe 16 cycles, issues in 4)
+            EpiArgs ea = {a.hw[G - 1].b1, a.hw[G - 1].cf[0], 0u, reinterpret_cast<uint2 *>(Hp + (G - 1) * 2048), reinterpret_cast<uint2 *>(Hp + (G - 1) * 2048 + 1024)};
+            gemm128_epi<true>(c, Hhi, Hlo, wp, acc1[G - 1], ea, wave, lane, rmax);
+            m1s[G - 1] = ea.m;
+            OVF_PUBLISH();
+        } else
+            gemm128(c, Hhi, Hlo, wp, lane);
         wprefetch(wp, hw.w3p, wave, lane);
         const unsigned m2 = bias_relu(c, hw.b2, hw.cf[1], wave, lane);
         __syncthreads();
@@ -827,6 +990,11 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         if (q == 0) { gx = su * j0x; gy = sv * j0y; gz = __builtin_fmaf(sv, j0zv, su * j0zu); }
     }
 #endif
+    {   // tap geometry (d/du, d/dv coefficient form) of the first two maps of the backward loop into the ring, ahead of the barrier below
+        int mi, co; chunk_info(C0, mi, co);
+        if (SHGEO && wave == 0) geom_compute<2>(a, mi, sUV, lane, sGeo);
+        if (SHGEO && wave == 1 && mi + 1 < 8) geom_compute<2>(a, mi + 1, sUV, lane, sGeo);
+    }
     __syncthreads();        // region 0 changes role again: activation planes -> tap-difference buffers + weight slab
     // Every wave needs the whole weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
     // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
@@ -839,7 +1007,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                                              (__attribute__((address_space(3))) void *)(Sl + g_ * 1024 + 256 * i_ + wave * 64), 16, 0, 0);
     SLAB_DMA(C0)
     TapGeom<2> tgb;
-    { int mi, co; chunk_info(C0, mi, co); taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
+    { int mi, co; chunk_info(C0, mi, co); if (SHGEO) geom_fetch<2>(mi, sGeo, tid, tgb); else taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
     __syncthreads();
     PCLK(3);
     for (int ci = C0; ci < NCHUNK; ci++) {
@@ -882,7 +1050,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             // stays in flight across it
             asm volatile("" ::: "memory");
             int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
-            if (c2o == 0) taps_geom(a, m2i, sUV, tid, tgb);
+            if (c2o == 0) {         // see the forward loop: fetch this map's slot, one wave refills the other with the next map
+                if (SHGEO) {
+                    geom_fetch<2>(m2i, sGeo, tid, tgb);
+                    if (m2i + 1 < 8 && wave == (m2i & 3)) geom_compute<2>(a, m2i + 1, sUV, lane, sGeo);
+                } else
+                    taps_geom(a, m2i, sUV, tid, tgb);
+            }
             taps_issue(a, b, m2i, c2o, tgb, tp);
         }
         float su = 0.f, sv = 0.f;
@@ -1681,7 +1855,7 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
         float *bp = reinterpret_cast<float *>(p + o);
         const float *bd = reinterpret_cast<const float *>(d + o * sizeof(_Float16));
         H.b1 = bd; H.b2 = bd + 128; H.b3 = bd + 256; H.b4 = bd + 384;
-        for (int l = 0; l < 3; l++) for (int i = 0; i < 128; i++) bp[l * 128 + i] = bvec[hd * 4 + l][i] * ACT_SCALE;   // hidden biases in operand units (exact)
+        for (int l = 0; l < 3; l++) for (int i = 0; i < 128; i++) bp[l * 128 + i] = bvec[hd * 4 + l][i] * ACT_SCALE + 0.0f;   // hidden biases in operand units (exact); -0 -> +0 (bias_relu's mask bit)
         memcpy(bp + 384, bvec[hd * 4 + 3], ko * sizeof(float));
     }
     VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5, hipMemcpyHostToDevice, st));
@@ -1779,7 +1953,7 @@ extern "C" int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps
 static size_t lds_bytes(int G)
 {
     const size_t r0 = (size_t)G * 2048 > (size_t)1152 + G * 1024 ? (size_t)G * 2048 : (size_t)1152 + G * 1024;
-    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64 + 64) + 8 * sizeof(double) + 8;
+    return 16 * (r0 + 256) + sizeof(float) * (64 * 3 + 4 * 64 * 2 + G * 64 + 64 + 64) + 8 * sizeof(double) + 16 + (G == 2 ? sizeof(float) * 2 * 64 * GEO_STRIDE : 0);      // + the geometry ring of the two-head kernels
 }
 
 template <int G, int MODE, bool USEP>
