@@ -99,6 +99,21 @@ __device__ __forceinline__ int map_proj(int mi) { return kMap[mi].y; }
 __device__ __forceinline__ void chunk_info(int i, int &mi, int &co) { const int2 c = kChunk[i]; mi = c.x; co = c.y; }
 
 __device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
+// All-reduce over the 16 lanes of a DPP row (lanes j = 0..15 of one lane group q) with data-parallel-primitive operands: xor 1, xor 2 inside the quads,
+// then row_half_mirror and row_mirror -- four VALU instructions with the cross-lane move folded in, instead of four ds_bpermute round trips through
+// the LDS crossbar (address VALU + LDS instruction + wait each), which is what __shfl_xor compiles to.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); return fmaxf(v, dpp_mov<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); return v + dpp_mov<0x140>(v);
+}
 // x (already scaled) -> hi = fp16(x), lo = fp16(x - hi); x - hi is exact in fp32.  Two elements cost 4 VALU instructions: one packed
 // RTN conversion, two mixed-precision FMAs (v_fma_mix_f32: -hi * 1 + x, reading hi straight from its packed half), one packed conversion.
 // `rmax` tracks max |x| of everything this thread ever splits (one v_max3_f32 per pair): a value beyond the fp16 range would become inf in
@@ -804,13 +819,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     }
                 } else {
                     // part = mean_B sum_N CE(parts, labels)  (recon_fit_behave.py:486): softmax over the 14 logits held by lanes j<14
-                    float mx = live ? val : -INFINITY;
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    const float mx = row16_max(live ? val : -INFINITY);
                     const float e = live ? expf(val - mx) : 0.f;
-                    float se = e;
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o, 64);
+                    const float se = row16_sum(e);
                     const int lab = a.labels[pn];
                     if (valid && live) {
                         go[r] = (e / se - (j == lab ? 1.f : 0.f)) * a.w1 / (float)a.B;
@@ -838,9 +849,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         //      max_o |go'| in [2^GO_EXP, 2^(GO_EXP+1)); the inverse is applied to d(features) in the layer-1 backward
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            float m = fabsf(go[r]);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float m = row16_max(fabsf(go[r]));
             const int eb = (int)((__float_as_uint(m) >> 23) & 255u);
             const bool ok = eb >= GO_EXP + 2 && eb < 255;       // zero / denormal-sized / non-finite gradients pass unscaled
             const float s = ok ? __uint_as_float((unsigned)(254 + GO_EXP - eb) << 23) : 1.0f;
@@ -984,8 +993,8 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         }
         float su = cu[0] * dot[0] + cu[1] * dot[1] + cu[2] * dot[2] + cu[3] * dot[3];
         float sv = cv[0] * dot[0] + cv[1] * dot[1] + cv[2] * dot[2] + cv[3] * dot[3];
-        su += __shfl_xor(su, 1, 64); sv += __shfl_xor(sv, 1, 64);
-        su += __shfl_xor(su, 2, 64); sv += __shfl_xor(sv, 2, 64);
+        su += dpp_mov<0xB1>(su); sv += dpp_mov<0xB1>(sv);          // the four column-block lanes of a point are one quad
+        su += dpp_mov<0x4E>(su); sv += dpp_mov<0x4E>(sv);
         su = __shfl(su, 4 * j, 64); sv = __shfl(sv, 4 * j, 64);
         if (q == 0) { gx = su * j0x; gy = sv * j0y; gz = __builtin_fmaf(sv, j0zv, su * j0zu); }
     }
