@@ -86,6 +86,51 @@ def test_smplh_vs_oracle_ragged_batches(hip, synth, B):
     assert rel(npy(p.grad), dp_o) < 3e-4 and rel(npy(b_.grad), db_o) < 3e-4 and rel(npy(t.grad), dt_o) < 3e-4
 
 
+def test_smplh_dense_weights_take_the_dense_lbs(hip, synth):
+    """vt_smplh_create stores the non-zero skinning weights of a vertex for the sparse LBS when no vertex has more than 8; a model with dense rows
+    must fall back to the dense loop and give the same result as the oracle -- and the SAME BITS as the sparse path on a 4-non-zero model whose
+    zeros are made explicit (adding w_j A_j = 0 terms changes nothing)."""
+    from oracle import oracle as O
+    from vistracker_amd import ops
+    rng = np.random.default_rng(3)
+    B = 5
+    pose = rng.normal(0, 0.3, (B, 156)).astype(np.float32); betas = rng.normal(0, 1, (B, 10)).astype(np.float32); trans = rng.normal(0, 0.3, (B, 3)).astype(np.float32)
+    dense = dict(synth["model"])
+    W = np.asarray(dense["weights"], np.float32).copy()
+    W[:100] = rng.dirichlet(np.ones(52), 100).astype(np.float32)            # 100 vertices with 52 non-zero weights -> dense LBS for the whole model
+    dense["weights"] = W
+    v_o, j_o, _ = O.SmplModel(dense).forward(pose, betas, trans)
+    verts, jtr, _ = ops.smplh_forward(ops.SmplhHandle(dense), cu(pose), cu(betas), cu(trans))
+    assert np.abs(npy(verts) - v_o).max() < 3e-5 and np.abs(npy(jtr) - j_o).max() < 3e-5
+    # the untouched vertices: dense loop == sparse loop, bit for bit
+    v_sparse, _, _ = ops.smplh_forward(hip["smpl"], cu(pose), cu(betas), cu(trans))
+    far = np.ones(6890, bool); far[:100] = False
+    # (the joint regressor couples every vertex to the changed rows through the joints only via v_template / shapedirs, which are unchanged)
+    assert np.array_equal(npy(verts)[:, far], npy(v_sparse)[:, far])
+
+
+def test_silhouette_large_faces_take_the_whole_wave(hip):
+    """faces whose pixel box exceeds 128 pixels are rasterised by all 64 lanes of the wave instead of the face's 16-lane group: a coarse mesh
+    (a cube close to the camera: 12 faces covering a third of the image) against the oracle"""
+    from oracle import oracle as O
+    ops = hip["ops"]
+    c = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], np.float32) * 0.3
+    f = np.array([[0, 1, 2], [0, 2, 3], [4, 6, 5], [4, 7, 6], [0, 4, 5], [0, 5, 1], [1, 5, 6], [1, 6, 2], [2, 6, 7], [2, 7, 3], [3, 7, 4], [3, 4, 0]], np.int32)
+    rng = np.random.default_rng(2)
+    from vistracker_amd import synthetic as syn
+    R = syn.random_rotations(4, rng)
+    verts = (np.einsum("nc,bcd->bnd", c, R) + np.array([0.05, -0.03, 1.6], np.float32)).astype(np.float32)
+    K = np.tile(np.array([[1.4, 0, 0.5, 0, 1.4, 0.5, 0, 0, 1]], np.float32), (4, 1))
+    img_o = O.sil_forward(verts, f, K, 256)
+    v = cu(verts).requires_grad_(True)
+    img = ops.silhouette(v, cu(f), cu(K), 256)
+    assert 0.1 < img_o.mean() < 0.9
+    assert np.abs(npy(img) - img_o).sum() <= 4
+    gimg = (2 * (img_o - np.roll(img_o, 7, axis=2))).astype(np.float32)
+    (img * cu(gimg)).sum().backward()
+    assert rel(npy(v.grad), O.sil_backward(verts, f, K, gimg, 256, 1e-4)) < 2e-3
+
+
 def test_landmarks(hip, synth):
     from oracle import oracle as O
     g = golden("landmarks"); s = golden("smplh"); ops = hip["ops"]
