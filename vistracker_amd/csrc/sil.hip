@@ -117,12 +117,17 @@ __device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den,
                                                 unsigned long long *__restrict__ zrow)
 {
     const float rw = 1.0f / (float)w;
+    // pixel centres in NDC are (2 i + 1 - is) / is: for a power-of-two image size the division is exactly a multiplication by 1 / is (same bits,
+    // a tenth of the instructions of an IEEE division); other sizes keep the division
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float ris = 1.0f / (float)is;
     for (int p = start; p < npx; p += stride) {
         // p = q w + r without the ~40-instruction integer division: float estimate (p < 2^20 is exact in fp32), corrected by at most one
         int q = (int)((float)p * rw), r = p - q * w;
         if (r >= w) { q++; r -= w; } else if (r < 0) { q--; r += w; }
         const int xi = x0 + r, yi = y0 + q;
-        const float xp = (2.0f * xi + 1 - is) / is, yp = (2.0f * yi + 1 - is) / is;
+        const float xn = 2.0f * xi + 1 - is, yn = 2.0f * yi + 1 - is;
+        const float xp = pow2 ? xn * ris : xn / is, yp = pow2 ? yn * ris : yn / is;
         if (((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
             ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
             ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7]))) continue;
@@ -248,6 +253,8 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
         from[w] = d0_from; start[w + 1] = start[w] + max(d0_to - d0_from + 1, 0);
     }
     float acc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float ris = 1.0f / (float)is;
 #define PIX(d0_, d1_, axis_) ((axis_) == 0 ? (size_t)(is - 1 - (d1_)) * is + (d0_) : (size_t)(is - 1 - (d0_)) * is + (d1_))
     for (int base = 0; base < start[6]; base += 64) {
         const int idx = base + lane;
@@ -276,8 +283,10 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
             if (d1_out < 0 || is <= d1_out) break;
             const size_t idx_in = PIX(d0, d1_in, axis), idx_out = PIX(d0, d1_out, axis);
             const float alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
-            const float sA = (p[1][0] != d0) ? (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f / is : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
-            const float sB = (p[0][0] != d0) ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f / is : 0.f;   // ... for corner 1
+            // (... * 2.0f / is): for a power-of-two image size the division is exactly a multiplication by 1 / is
+            const float tA = (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f, tB = (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f;
+            const float sA = (p[1][0] != d0) ? (pow2 ? tA * ris : tA / is) : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
+            const float sB = (p[0][0] != d0) ? (pow2 ? tB * ris : tB / is) : 0.f;   // ... for corner 1
             if (fim[idx_in] == f2) {   // sweep outwards from the edge: only flagged pixels have a non-zero term (alpha_in = 1)
                 const int d1_limit = (0 < direction) ? is - 1 : 0;
                 const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
