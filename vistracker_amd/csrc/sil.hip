@@ -229,6 +229,14 @@ __global__ __launch_bounds__(256) void sil_sweep_mask_kernel(const int *__restri
                                                      ((unsigned long long)sCol[2][lane] << 32) | ((unsigned long long)sCol[3][lane] << 48);
 }
 
+// sum over the SIL_G (= 16: one DPP row) lanes of a face's group, every lane gets the result
+__device__ __forceinline__ float group_sum(float v)
+{
+    static_assert(SIL_G == 16, "group_sum is written for 16-lane groups (one DPP row)");
+    auto mv = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true)); };
+    v += mv(v, std::integral_constant<int, 0xB1>{}); v += mv(v, std::integral_constant<int, 0x4E>{});
+    v += mv(v, std::integral_constant<int, 0x141>{}); return v + mv(v, std::integral_constant<int, 0x140>{});
+}
 // Kato et al. edge-sweep surrogate gradient, one wave per (frame, visible doubled face).  A face has six (edge, axis) walks of
 // a few positions d0 each; their positions are laid end to end and dealt to the lanes, so all six walks run concurrently (walking
 // them one after the other left ~10 of 64 lanes busy and chained six rounds of dependent loads).  The outward sweep of a position
@@ -238,10 +246,13 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
                                     const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj)
 {
-    // one wave per ORIGINAL face (see sil_scatter_kernel): at most one of its two orientations won pixels
-    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), b = blockIdx.y, lane = threadIdx.x & 63;   // wave-uniform
+    // a group of SIL_G lanes per ORIGINAL face (see sil_scatter_kernel): at most one of its two orientations won pixels.  A visible face is a chain
+    // of dependent memory round trips (record -> face index at the edge -> sweep masks -> image gradient), ~8 us at full occupancy whatever the lane
+    // count: four faces per wave share that latency (a face has ~40 walk positions: two or three rounds of 16 lanes instead of one of 64).
+    const int lane = threadIdx.x & (SIL_G - 1), b = blockIdx.y;
+    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / SIL_G) + ((threadIdx.x & 63) / SIL_G);
     if (f >= NF) return;
-    // visibility flags, vertex ids and corners: independent scalar loads, requested before the first branch
+    // visibility flags, vertex ids and corners: independent loads, requested before the first branch
     const int visA = visible[(size_t)b * 2 * NF + f], visB = visible[(size_t)b * 2 * NF + NF + f];
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     float PA[3][2];         // corners of orientation f in pixel units
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
     const bool pow2 = (is & (is - 1)) == 0;
     const float ris = 1.0f / (float)is;
 #define PIX(d0_, d1_, axis_) ((axis_) == 0 ? (size_t)(is - 1 - (d1_)) * is + (d0_) : (size_t)(is - 1 - (d0_)) * is + (d1_))
-    for (int base = 0; base < start[6]; base += 64) {
+    for (int base = 0; base < start[6]; base += SIL_G) {
         const int idx = base + lane;
         if (idx >= start[6]) continue;
         int w = 0, d0 = from[0] + idx;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const float g = wave_sum(acc[k][c]);
+            const float g = group_sum(acc[k][c]);
             // FIXED-POINT accumulation (2^-34 units in a 64-bit integer, |sum| < 5e8): integer addition is associative, so the per-vertex sum over
             // its faces is bit-identical whatever order the waves arrive in.  (fp64 atomics left a ~2^-29 chance per value that two runs round to
             // different floats -- enough, over 300 'sil' steps, to make one run in ten drift from another through Adam's amplification.)
@@ -449,7 +460,7 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
     VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(double) * (size_t)B * NV * 2, st));
     hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, face_index, d_image, size, w.rowmask, w.colmask);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 3) / 4, B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
                        w.rowmask, w.colmask, eps, w.gproj);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts);
