@@ -112,42 +112,60 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
 #define SIL_G 16
 #endif
 #define SIL_BIG (8 * SIL_G)     /* boxes above this many pixels are rasterised by the whole wave (64 lanes), not by the face's lane group */
-// pixels start, start + stride, ... < npx of the box (x0, y0, width w) of face f2 with corners fc
+// pixel p of the box (x0, y0, width w) -> image coordinates; p = q w + r without the ~40-instruction integer division: float estimate (p < 2^20 is
+// exact in fp32), corrected by at most one
+__device__ __forceinline__ void sil_box_pixel(int p, int x0, int y0, int w, float rw, int &xi, int &yi)
+{
+    int q = (int)((float)p * rw), r = p - q * w;
+    if (r >= w) { q++; r -= w; } else if (r < 0) { q--; r += w; }
+    xi = x0 + r; yi = y0 + q;
+}
+// pixel centres in NDC are (2 i + 1 - is) / is: for a power-of-two image size the division is exactly a multiplication by 1 / is (same bits, a tenth
+// of the instructions of an IEEE division); other sizes keep the division
+__device__ __forceinline__ void sil_ndc(int xi, int yi, int is, bool pow2, float ris, float &xp, float &yp)
+{
+    const float xn = 2.0f * xi + 1 - is, yn = 2.0f * yi + 1 - is;
+    xp = pow2 ? xn * ris : xn / is; yp = pow2 ? yn * ris : yn / is;
+}
+__device__ __forceinline__ bool sil_inside(const float (&fc)[9], float xp, float yp)
+{
+    return !(((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
+             ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
+             ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7])));
+}
+// depth of a covered pixel (neural_renderer's barycentric formula, division for division) and the visibility vote
+__device__ __forceinline__ void sil_vote(const float (&fc)[9], float den, int f2, float xp, float yp, int xi, int yi, int is, unsigned long long *__restrict__ zrow)
+{
+    float w0 = ((fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4])) / den;
+    float w1 = ((fc[7] - fc[1]) * xp + (fc[0] - fc[6]) * yp + (fc[6] * fc[1] - fc[0] * fc[7])) / den;
+    float w2 = ((fc[1] - fc[4]) * xp + (fc[3] - fc[0]) * yp + (fc[0] * fc[4] - fc[3] * fc[1])) / den;
+    w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
+    const float ws = w0 + w1 + w2;
+    const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);
+    if (!(zp > SIL_NEAR && zp < SIL_FAR)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f2;     // zp > 0: float order == uint order
+    atomicMin(zrow + (size_t)yi * is + xi, key);
+}
+// pixels start, start + stride, ... < npx of the box (x0, y0, width w) of face f2 with corners fc (the whole-wave path of large boxes)
 __device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den, int f2, int x0, int y0, int w, int npx, int start, int stride, int is,
                                                 unsigned long long *__restrict__ zrow)
 {
     const float rw = 1.0f / (float)w;
-    // pixel centres in NDC are (2 i + 1 - is) / is: for a power-of-two image size the division is exactly a multiplication by 1 / is (same bits,
-    // a tenth of the instructions of an IEEE division); other sizes keep the division
     const bool pow2 = (is & (is - 1)) == 0;
     const float ris = 1.0f / (float)is;
     for (int p = start; p < npx; p += stride) {
-        // p = q w + r without the ~40-instruction integer division: float estimate (p < 2^20 is exact in fp32), corrected by at most one
-        int q = (int)((float)p * rw), r = p - q * w;
-        if (r >= w) { q++; r -= w; } else if (r < 0) { q--; r += w; }
-        const int xi = x0 + r, yi = y0 + q;
-        const float xn = 2.0f * xi + 1 - is, yn = 2.0f * yi + 1 - is;
-        const float xp = pow2 ? xn * ris : xn / is, yp = pow2 ? yn * ris : yn / is;
-        if (((yp - fc[1]) * (fc[3] - fc[0]) < (xp - fc[0]) * (fc[4] - fc[1])) ||
-            ((yp - fc[4]) * (fc[6] - fc[3]) < (xp - fc[3]) * (fc[7] - fc[4])) ||
-            ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7]))) continue;
-        float w0 = ((fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4])) / den;
-        float w1 = ((fc[7] - fc[1]) * xp + (fc[0] - fc[6]) * yp + (fc[6] * fc[1] - fc[0] * fc[7])) / den;
-        float w2 = ((fc[1] - fc[4]) * xp + (fc[3] - fc[0]) * yp + (fc[0] * fc[4] - fc[3] * fc[1])) / den;
-        w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
-        const float ws = w0 + w1 + w2;
-        const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);
-        if (!(zp > SIL_NEAR && zp < SIL_FAR)) continue;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f2;     // zp > 0: float order == uint order
-        atomicMin(zrow + (size_t)yi * is + xi, key);
+        int xi, yi; sil_box_pixel(p, x0, y0, w, rw, xi, yi);
+        float xp, yp; sil_ndc(xi, yi, is, pow2, ris, xp, yp);
+        if (sil_inside(fc, xp, yp)) sil_vote(fc, den, f2, xp, yp, xi, yi, is, zrow);
     }
 }
 __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
                                                           unsigned long long *__restrict__ zbuf)
 {
     constexpr int FPW = 64 / SIL_G;
-    const int lane = threadIdx.x & 63, gl = lane % SIL_G, b = blockIdx.y;
-    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + lane / SIL_G;
+    __shared__ unsigned short sQ[4][FPW][SIL_BIG];              // per lane group: the box pixels that passed the inside test
+    const int lane = threadIdx.x & 63, gl = lane % SIL_G, grp = lane / SIL_G, b = blockIdx.y;
+    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + grp;
     unsigned long long *zrow = zbuf + (size_t)b * is * is;
     float fc[9]; float den = 0.f; int f2 = 0, x0 = 0, y0 = 0, w = 1, npx = 0;
     if (f < NF) {
@@ -170,7 +188,34 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
         for (int e = 0; e < 9; e++) fc[e] = 0.f;
     }
     const bool big = npx > SIL_BIG;
-    if (!big) sil_scatter_box(fc, den, f2, x0, y0, w, npx, gl, SIL_G, is, zrow);
+    const float rw = 1.0f / (float)w;
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float ris = 1.0f / (float)is;
+    // small boxes, phase 1: the cheap half of the work (index, NDC, three edge tests) for every pixel of the box; the pixels that are covered are
+    // compacted into the group's LDS list.  Half the pixels of a box lie outside its triangle: the expensive half (ten IEEE divisions of the
+    // depth formula) then runs on full lanes only.
+    unsigned short *qz = sQ[threadIdx.x >> 6][grp];
+    int n_in = 0;
+    const int nsmall = big ? 0 : npx;
+    for (int p0 = 0; p0 < nsmall; p0 += SIL_G) {
+        const int p = p0 + gl;
+        bool in = false;
+        if (p < nsmall) {
+            int xi, yi; sil_box_pixel(p, x0, y0, w, rw, xi, yi);
+            float xp, yp; sil_ndc(xi, yi, is, pow2, ris, xp, yp);
+            in = sil_inside(fc, xp, yp);
+        }
+        const unsigned bits = (unsigned)(__ballot(in) >> (SIL_G * grp)) & ((1u << SIL_G) - 1u);
+        if (in) qz[n_in + __popc(bits & ((1u << gl) - 1u))] = (unsigned short)p;
+        n_in += __popc(bits);
+    }
+    __syncthreads();
+    for (int i = gl; i < n_in; i += SIL_G) {
+        const int p = qz[i];
+        int xi, yi; sil_box_pixel(p, x0, y0, w, rw, xi, yi);
+        float xp, yp; sil_ndc(xi, yi, is, pow2, ris, xp, yp);
+        sil_vote(fc, den, f2, xp, yp, xi, yi, is, zrow);
+    }
     // large boxes (a close-up mesh, a long sliver): all 64 lanes of the wave take the face, its record broadcast from the group's first lane
     unsigned long long todo = __ballot(big && gl == 0);
     while (todo) {
