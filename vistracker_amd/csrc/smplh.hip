@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
 #define FWD_FB 16
 #define AXS 516   /* LDS stride of an extended pose row [pose_map | betas | 1 | 0 0]: 516 mod 64 = 4 -> conflict-free ds_read_b64 */
 #define SAS 628   /* LDS stride of a frame's 52 x 12 A matrices */
+#define FWD_R0 (FWD_FB * AXS > 8 * SAS ? FWD_FB * AXS : 8 * SAS)    /* floats of the time-shared region: pose rows, then 8 frames of A matrices */
 __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ Q_kcv, const float *__restrict__ W_jv,
                                                           const float *__restrict__ betas, const float *__restrict__ trans,
                                                           const float *__restrict__ ws, int B,
@@ -186,10 +187,10 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sAx = lds;                       // [16][AXS] extended pose rows (GEMM phase) ...
-    float *sA = lds;                        // ... then [16][SAS] A matrices (skinning phase)
-    float *sVp = lds + FWD_FB * SAS;        // [16][64][3] v_posed hand-over
-    float *sW = sVp + FWD_FB * 64 * 3;      // [52][64] skinning weights of the tile
-    float *sTr = sW + J_ * 64;              // [16][3]
+    float *sA = lds;                        // ... then [8][SAS] A matrices of HALF the frames at a time (skinning phase)
+    float *sVp = lds + FWD_R0;              // [16][64][3] v_posed hand-over
+    float *sW = sVp + FWD_FB * 64 * 3;      // [52][64] skinning weights of the tile, or [2][SP_K][64] in the sparse form
+    float *sTr = sW + (nnz > 0 ? 2 * SP_K * 64 : J_ * 64);     // [16][3]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int b0 = blockIdx.y * FWD_FB, v = blockIdx.x * 64 + wave * 16 + j;
     for (int i = tid; i < FWD_FB * KQ_; i += 256) {
@@ -235,16 +236,25 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int c = 0; c < 3; c++) sVp[((4 * q + r) * 64 + wave * 16 + j) * 3 + c] = acc[c][r];
-    for (int i = tid; i < FWD_FB * 624; i += 256) { const int f = i / 624, b = min(b0 + f, B - 1); sA[f * SAS + (i % 624)] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)]; }
-    __syncthreads();
     const int vv = tid & 63, vg = blockIdx.x * 64 + vv;
+    // The A matrices of the 16 frames (40 KB) are staged in two halves of 8 (slot 2 w + e <- frame 4 w + 2 half + e): with the sparse weights the
+    // workgroup then needs 49.5 KB of LDS and THREE fit a CU -- the 648 workgroups of a B = 96 launch run in one round of 768 slots instead of
+    // 1.27 rounds of 512.
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
+        if ((r & 1) == 0) {
+            if (r) __syncthreads();             // the readers of the first half are done
+            for (int i = tid; i < 8 * 624; i += 256) {
+                const int sl = i / 624, f = 4 * (sl >> 1) + r + (sl & 1), b = min(b0 + f, B - 1);
+                sA[sl * SAS + (i % 624)] = ws[(size_t)b * WS_FRAME + WS_A + (i % 624)];
+            }
+            __syncthreads();
+        }
         const int f = 4 * wave + r, b = b0 + f;
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; e++) T[e] = 0.f;
-        const float4 *Af = reinterpret_cast<const float4 *>(sA + f * SAS);
+        const float4 *Af = reinterpret_cast<const float4 *>(sA + (2 * wave + (r & 1)) * SAS);
         // T = sum_j w_j A_j in ascending joint order.  The dense sum spends 52 x 12 multiply-adds per (vertex, frame) on 4 non-zero weights --
         // two thirds of this kernel's arithmetic; the sparse sum adds the same non-zero terms in the same order (a skipped term is w_j A_j = +-0
         // and leaves the partial sum unchanged), so both give identical bits.
@@ -612,7 +622,7 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
     hipStream_t st = vt_stream(stream);
     hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
     VT_LAUNCH_CHECK();
-    const size_t lds_f = sizeof(float) * (FWD_FB * SAS + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3);
+    const size_t lds_f = sizeof(float) * (FWD_R0 + FWD_FB * 64 * 3 + (h->nnz > 0 ? 2 * SP_K * 64 : J_ * 64) + FWD_FB * 3);
     VT_LDS_LIMIT(smplh_verts_kernel, lds_f);
     hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
                        verts, v_posed, h->W_sp, h->nnz);
