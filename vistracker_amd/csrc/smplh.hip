@@ -613,7 +613,7 @@ extern "C" void vt_smplh_destroy(vt_smplh *h)
 extern "C" long vt_smplh_workspace_floats(int B) { return (long)B * WS_FRAME; }
 extern "C" long vt_smplh_bwd_scratch_floats(int B) { return (long)NVT_ * B * PT_N + (long)B * KTOT_ + (long)NKS_ * B * NQ_; }
 
-#define BWD_FB 8
+#define BWD_FB 6      /* frames per workgroup of the backward tile kernel: 27 x 16 = 432 workgroups at B = 96 fill the 512 slots better than 27 x 12 (8 frames): 141 -> 131 us */
 
 extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const float *betas, const float *trans, int B,
                                 float *verts, float *jtr, float *v_posed, float *ws, void *stream)
