@@ -623,7 +623,7 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
     hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
     VT_LAUNCH_CHECK();
     const size_t lds_f = sizeof(float) * (FWD_R0 + FWD_FB * 64 * 3 + (h->nnz > 0 ? 2 * SP_K * 64 : J_ * 64) + FWD_FB * 3);
-    VT_LDS_LIMIT(smplh_verts_kernel, lds_f);
+    VT_LDS_LIMIT(smplh_verts_kernel, sizeof(float) * (FWD_R0 + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3));     // the limit is set once per device: the dense-weights size
     hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
                        verts, v_posed, h->W_sp, h->nnz);
     VT_LAUNCH_CHECK();
