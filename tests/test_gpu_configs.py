@@ -88,3 +88,27 @@ def test_demo_pipeline_reference_schedules(synth):
     assert len(pipe.log["smplt_steps"]) == 2 and pipe.log["smplt_steps"][0] > 300          # one 200-frame batch per SMPL-T stage: 100 / 30 outer iterations allowed
     sec = pipe.log["seconds"]
     print("stage seconds:", {k: round(v, 2) for k, v in sec.items()}, steps)
+
+
+def test_generator_frames_that_sit_out_do_not_change_the_result(synth):
+    """Generator.skip_done_frames: frames that already hold 1.5 x the requested points take no part in the following rounds.  The reference counts
+    progress by the minimum over the frames of the points a round keeps (recon/gen/generator.py:180-186); a frame that is far ahead is never that
+    minimum, so every output must be what it is with all frames in every round -- bit for bit (same random stream, same kernels)."""
+    from vistracker_amd import demo_inputs
+    net = demo_inputs.sifnet(synth["decoders"])
+    from vistracker_amd.generator import GeneratorTriplaneVis
+    T = 8
+    seq = demo_inputs.sequence(T, {"model": synth["model"], "regs": synth["regs"]})
+    images = torch.zeros(T, 8, 512, 512, device="cuda"); images[:, :5] = seq["images5"]
+    data = {"images": images, "crop_center": torch.as_tensor(seq["crop_center"], device="cuda"),
+            "body_center": torch.as_tensor(np.asarray(seq["trans_init"], np.float32), device="cuda")}
+    outs = []
+    for skip in (True, False):
+        gen = GeneratorTriplaneVis(net, "x", seed=5); gen.skip_done_frames = skip
+        gen.reseed(0)
+        pc = gen.generate_pclouds_batch(data, num_points=3000, num_steps=10, targets=("object",))["object"]
+        outs.append({k: (v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in pc.items()})
+    a, b = outs
+    assert a["points"].shape == b["points"].shape and a["points"].shape[1] >= 3000
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k        # (the human half of `centers` is NaN when only the object is sampled)

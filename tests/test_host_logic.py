@@ -170,6 +170,7 @@ def test_generator_round_logic_on_cpu():
             return samples.clone(), preds
 
     gen = Stub()
+    gen.skip_done_frames = False        # every frame in every round: the stub records what it was shown by batch position
     B = 4
     bc = torch.tensor([[0.0, 0.0, 2.2]] * B)
     init = gen.get_grid_samples(3000, B, bc)

@@ -21,6 +21,11 @@ from . import ops
 
 class Generator:
     use_projection = True
+    # frames that already hold 1.5 x the requested points sit the following rounds of gen_pc_batch out (their feature maps are not gathered, their
+    # samples not projected).  The reference counts progress by the MINIMUM over the frames of the points a round keeps: a frame that is far ahead is
+    # never that minimum, so the common sample count -- and with it every output -- is the same as with all frames in every round (tested); should the
+    # final count overtake a frame that sat out, that frame alone is sampled further.
+    skip_done_frames = True
 
     def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,
                  filter_val=0.03, seed=0, **kwargs):
@@ -116,11 +121,42 @@ class Generator:
         fill = torch.zeros(B, dtype=torch.long, device=dev)
         it, samples_count = 0, 0
         samples = samples_init.clone()
-        while samples_count < num_points:
-            samples_surface, preds = self.approx_surface(model, samples, num_steps, query_input, df_type=df_type)
+        active = np.ones(B, bool)                       # host copy: which frames still take part in the rounds
+        stop_at = num_points + num_points // 2
+        full_maps, sub_maps, sub_key = getattr(model, "maps", None), None, None
+        refill = False                                  # True: the common count is final, only frames it has overtaken are sampled further
+
+        def project(samples):
+            """approx_surface on the active frames only; results scattered back to batch-sized tensors (zeros for the frames that sit out)"""
+            nonlocal sub_maps, sub_key
+            if active.all():
+                return self.approx_surface(model, samples, num_steps, query_input, df_type=df_type)
+            idx = torch.as_tensor(np.nonzero(active)[0], device=dev)
+            key = active.tobytes()
+            if key != sub_key and full_maps is not None:
+                if self.use_projection and full_maps.proj is None:
+                    full_maps.build_projection(model.handle)
+                sub_maps, sub_key = full_maps.select(idx), key
+            qi = {k: (v.index_select(0, idx) if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in query_input.items()}
+            if full_maps is not None:
+                model.maps = sub_maps
+            try:
+                ss, pr = self.approx_surface(model, samples.index_select(0, idx), num_steps, qi, df_type=df_type)
+            finally:
+                if full_maps is not None:
+                    model.maps = full_maps
+            ss_full = torch.zeros_like(samples); ss_full.index_copy_(0, idx, ss)
+            pr_full = []
+            for t in pr:
+                f = torch.zeros((B,) + tuple(t.shape[1:]), device=dev, dtype=t.dtype); f.index_copy_(0, idx, t); pr_full.append(f)
+            return ss_full, pr_full
+
+        while samples_count < num_points or refill:
+            samples_surface, preds = project(samples)
             S = samples.shape[1]
+            act = torch.as_tensor(active, device=dev)
             df_target = torch.clamp(preds[0][:, df_idx, :], max=self.threshold)
-            mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0)
+            mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0) & act[:, None]
             cnt = mask.sum(1)                                                  # (B,) kept points per frame
             order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)  # kept sample indices first, in sample order
             ar = torch.arange(S, device=dev)[None]
@@ -136,9 +172,22 @@ class Generator:
                         buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
                     buf[name].scatter_(1, dest[..., None].expand(B, S, Cc), pr.gather(1, order[..., None].expand(B, S, Cc)))
                 fill = torch.minimum(fill + cnt, torch.full_like(fill, cap))
-                samples_count += int(cnt.min().item())                          # the one host sync of the round
+                # the one host sync of the round: the round's minimum over the active frames and every frame's fill level
+                big = torch.full_like(cnt, 1 << 40)
+                host = torch.cat([torch.where(act, cnt, big).min()[None], fill]).cpu().numpy()
+                if not refill:
+                    samples_count += int(host[0])
                 if not mute:
                     print(f"{samples_count} points")
+                fill_h = host[1:]
+                if samples_count >= num_points:
+                    # done -- unless the final common count has overtaken a frame that sat rounds out: then only those frames continue
+                    active = fill_h < min(samples_count, cap)
+                    refill = bool(active.any())
+                elif self.skip_done_frames:
+                    keep = active & (fill_h < stop_at)
+                    if keep.any():
+                        active = keep
             # samples of the next round
             u = torch.rand(B, sample_num, device=dev, generator=self.rng)
             pert = torch.randn(B, sample_num, 3, device=dev, generator=self.rng)

@@ -231,6 +231,15 @@ class FeatureMaps:
         """frames [start, end) as a FeatureMaps of views (no copy; the projection, if any, is not carried over)"""
         return FeatureMaps({k: t[start:end] for k, t in zip(MAP_ORDER, self.t)})
 
+    def select(self, idx):
+        """the frames ``idx`` (1-D index tensor) as a new FeatureMaps (copies: 71 MB per frame + the hoisted projection, 17 MB per frame, if there is
+        one) -- for passes that continue with a subset of a batch"""
+        fm = FeatureMaps({k: t.index_select(0, idx).contiguous() for k, t in zip(MAP_ORDER, self.t)})
+        if self.proj is not None:
+            fm.proj = self.proj.view(self.B, -1).index_select(0, idx).reshape(-1).contiguous()
+            fm.c.proj = fm.proj.data_ptr(); fm.c.proj_cols = self.c.proj_cols
+        return fm
+
     def build_projection(self, net):
         """Hoist the im_feat part of the decoders' first layer out of the optimisation loop (vt_query_build_projection): one fp32 GEMM over
         all im_feat texels of the batch -> (B, res, res, 256) array the fused objective kernels blend instead of gathering 256 channels and
