@@ -413,7 +413,10 @@ __device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int k = (nt * 4 + p) * 4 + r;
-                const unsigned keep = (unsigned)((int)(m << k) >> 31);          // all ones where the unit was active
+                // all ones where the unit was active: ONE signed bit-field extract (left to itself hipcc builds the mask from and + compare +
+                // select: 4 instructions per value with the multiply instead of 3)
+                unsigned keep;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(31 - k));
                 c.v[nt][p][r] = __uint_as_float(__float_as_uint(c.v[nt][p][r] * sc) & keep);
             }
 }
