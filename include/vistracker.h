@@ -159,7 +159,7 @@ int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *p
 
 /* ---------------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 bias-free convolution of the HGFilter encoders (model/HGFilters.py:56-203, model/net_util.py:346-396 ConvBlock) as a
- * split-f16 implicit GEMM (fp32 accumulate, same operand format as the point query).  weight (Cout, Cin, 3, 3) fp32 host, Cout in {64, 128},
+ * split-f16 implicit GEMM (fp32 accumulate, same operand format as the point query).  weight (Cout, Cin, 3, 3) fp32 host, Cout in {32, 64, 128} (32: the 64-channel kernel with zero rows, half its waves idle in the MFMA phase),
  * Cin a multiple of 32.  in (B,H,W,Cin) NHWC fp32 device, H % 8 == 0, W % 16 == 0; the result goes to channels [out_coff, out_coff + Cout) of an
  * NHWC tensor with out_cstride channels (a ConvBlock's concatenation can be written in place).  A value beyond the operand range yields NaN.
  * ------------------------------------------------------------------------------------------------- */

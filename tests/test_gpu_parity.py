@@ -663,7 +663,7 @@ def test_surface_sampling_is_area_weighted_and_seeded(hip):
     assert batch.shape == (2, 100, 3) and np.abs(npy(batch[1] - batch[0]) - 1).max() < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (256, 128), (32, 64)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (256, 128), (32, 64), (64, 32), (32, 32)])
 def test_conv3x3_split_f16_vs_float64(hip, cin, cout):
     """vt_conv3x3_forward (split-f16 implicit GEMM, csrc/conv.hip) against torch's float64 convolution on the host: fp32-level agreement (the 3 x 22-bit
     products drop ~3 * 2^-22 per term), zero padding at the image border, channel-offset output, loud NaN beyond the operand range."""

@@ -46,7 +46,7 @@ __device__ __forceinline__ void cv_split2(float x0, float x1, unsigned &hi, unsi
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
-                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale)
+                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout)
 {
     // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
     __shared__ __attribute__((aligned(16))) uint4 patch[2][2 * 4 * CV_PX];
@@ -115,12 +115,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
         }
     };
     const unsigned wvo = (unsigned)(wave * NT * 128 + lane);
+    // a 32-channel layer runs the 64-channel kernel with its upper rows packed as zeros: the waves that own none of its output channels take part in
+    // the staging only (no weight loads, no MFMAs, no stores)
+    const bool live = wave * NT * 16 < cout;
     uint4 wf[2][NT][2];
 #define CV_LOAD_W(slot_, step_)                                                                                      \
     _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                \
         _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
     issue(0);
-    CV_LOAD_W(0, 0)
+    if (live) { CV_LOAD_W(0, 0) }
     stage(0, 0);
     if (nchunk > 1) issue(1);
     for (int c = 0; c < nchunk; c++) {
@@ -129,11 +132,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             const int dy = t / 3, dx = t % 3, step = c * 9 + t;
-            if (step + 1 < nchunk * 9) { CV_LOAD_W((t + 1) & 1, step + 1) }          // 9 taps: slots alternate with t, chunk c + 1 starts on slot (9 & 1) = 1 ...
+            if (live && step + 1 < nchunk * 9) { CV_LOAD_W((t + 1) & 1, step + 1) }          // 9 taps: slots alternate with t, chunk c + 1 starts on slot (9 & 1) = 1 ...
             // ... so the slot of (c, t) is (c + t) & 1: handled by indexing with the running parity below
             const int sl = t & 1;
 #pragma unroll
-            for (int ph = 0; ph < 2; ph++) {                    // two halves of four image rows: 8 B fragments live at a time
+            for (int ph = 0; ph < (live ? 2 : 0); ph++) {       // two halves of four image rows: 8 B fragments live at a time
                 h8 xh[4], xl[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 #pragma unroll
         for (int p = 0; p < CV_TH; p++) {
             const int y = ty * CV_TH + p, x = tx * CV_TW + j, co = (wave * NT + nt) * 16 + 4 * q;
+            if (co >= cout) continue;
             float4 v = make_float4(acc[nt][p][0] * inv_scale, acc[nt][p][1] * inv_scale, acc[nt][p][2] * inv_scale, acc[nt][p][3] * inv_scale);
             if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 
 extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout, int cin, void *stream)
 {
-    VT_REQUIRE(out && weight && (cout == 64 || cout == 128) && cin >= 32 && cin % 32 == 0, "vt_conv3x3_create: needs Cout in {64, 128} and Cin a multiple of 32");
-    const int nt = cout / 64, nchunk = cin / 32;
+    VT_REQUIRE(out && weight && (cout == 32 || cout == 64 || cout == 128) && cin >= 32 && cin % 32 == 0, "vt_conv3x3_create: needs Cout in {32, 64, 128} and Cin a multiple of 32");
+    const int nt = cout == 128 ? 2 : 1, nchunk = cin / 32;
     float m = 0.f;
     for (size_t i = 0; i < (size_t)cout * cin * 9; i++) m = fmaxf(m, fabsf(weight[i]));
     float sw = 1.0f;
@@ -191,7 +195,7 @@ extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout
     // fragment (step = chunk * 9 + tap, wave, nt, hi|lo, lane) halves t: W[cout = (wave nt_count + nt) 16 + (lane & 15)][cin = 32 chunk + 8 (lane >> 4) + t][tap]
     for (int c = 0; c < nchunk; c++) for (int t = 0; t < 9; t++) for (int w = 0; w < 4; w++) for (int n = 0; n < nt; n++) for (int l = 0; l < 64; l++) for (int k = 0; k < 8; k++) {
         const int co = (w * nt + n) * 16 + (l & 15), ci = 32 * c + 8 * (l >> 4) + k;
-        const float x = weight[((size_t)co * cin + ci) * 9 + t] * sw;          // (Cout, Cin, 3, 3): tap = 3 ky + kx
+        const float x = co < cout ? weight[((size_t)co * cin + ci) * 9 + t] * sw : 0.f;          // (Cout, Cin, 3, 3): tap = 3 ky + kx; rows beyond Cout = 32 are zero
         const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
         const size_t base = ((((size_t)(c * 9 + t) * 4 + w) * nt + n) * 2) * 64;
         host[(base + l) * 8 + k] = hi; host[(base + 64 + l) * 8 + k] = lo;
@@ -216,8 +220,8 @@ extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int i
     VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv3x3_forward_gn: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
     const dim3 grid((H / CV_TH) * (W / CV_TW), B);
     const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
-    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale);
-    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale);
+    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout);
+    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

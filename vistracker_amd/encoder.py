@@ -94,7 +94,7 @@ class HGFilterEncoder:
 
     def _hip_conv_ok(self, name, H, W, cuda):
         cout, cin = self.sd[name].shape[:2]
-        return self.use_hip_conv and cuda and cout in (64, 128) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0
+        return self.use_hip_conv and cuda and cout in (32, 64, 128) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0
 
     # ---- blocks ------------------------------------------------------------------------------------------------
     def _conv_block(self, x, p):
