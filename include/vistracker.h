@@ -172,6 +172,15 @@ int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W
  * vt_groupnorm_stats) max((x - mean) rstd gamma + beta, 0) is applied while the operand planes are staged (zero padding pads the rectified value). */
 int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
                           const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
+/* The same with the GroupNorm partial sums of the OUTPUT as a by-product (per 8 x 16 pixel tile, vt_conv3x3_tiles(H, W) of them, at
+ * stats_ws + B * stats_groups doubles): vt_groupnorm_finalize(stats_ws, tiles, B, H * W, Cout, stats_groups, eps) turns them into the {mean, rstd}
+ * pairs at the start of stats_ws -- the statistics the next convolution of a ConvBlock needs, without a pass over the tensor.
+ * stats_ws >= B stats_groups + tiles B Cout 2 doubles (NULL: no statistics). */
+int vt_conv3x3_forward_gn_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, double *stats_ws,
+                                int stats_groups, void *stream);
+int vt_conv3x3_tiles(int H, int W);
+int vt_groupnorm_finalize(double *ws, int nblk, int B, int HW, int C, int groups, float eps, void *stream);
 /* GroupNorm statistics of a channel slice: ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles; the (B, groups) {mean, rstd} float pairs
  * are written at the START of ws (pass `(const float *)ws` as gn_stats) */
 int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream);

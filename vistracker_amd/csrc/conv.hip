@@ -43,10 +43,17 @@ __device__ __forceinline__ void cv_split2(float x0, float x1, unsigned &hi, unsi
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
 }
 
+// sum over the 16 lanes of a DPP row, every lane gets the result
+__device__ __forceinline__ float cv_row16_sum(float v)
+{
+#define CV_DPP(x_, c_) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x_)), (c_), 0xF, 0xF, true))
+    v += CV_DPP(v, 0xB1); v += CV_DPP(v, 0x4E); v += CV_DPP(v, 0x141); return v + CV_DPP(v, 0x140);
+#undef CV_DPP
+}
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
-                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout)
+                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part)
 {
     // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
     __shared__ __attribute__((aligned(16))) uint4 patch[2][2 * 4 * CV_PX];
@@ -180,6 +187,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
             if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
         }
+    // GroupNorm statistics of the OUTPUT for the convolution that follows in a ConvBlock (it normalises exactly these values): per output channel
+    // the sum and the sum of squares over this workgroup's 8 x 16 pixels -- 8 rows in the lane, 16 columns across a DPP row -- written as one
+    // block of partials [tile][frame][channel][2] (fp64) for vt_groupnorm_finalize.  Saves the statistics pass over the tensor.
+    if (stats_part) {
+        double *pp = stats_part + (((size_t)blockIdx.x * gridDim.y + b) * cout) * 2;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int co = (wave * NT + nt) * 16 + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int p = 0; p < CV_TH; p++) { const float v = acc[nt][p][r] * inv_scale; sm += v; sq = __builtin_fmaf(v, v, sq); }
+                sm = cv_row16_sum(sm); sq = cv_row16_sum(sq);
+                if (j == 0 && co + r < cout) { pp[(co + r) * 2] = (double)sm; pp[(co + r) * 2 + 1] = (double)sq; }
+            }
+        }
+    }
 }
 
 extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout, int cin, void *stream)
@@ -211,8 +236,12 @@ extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout
 }
 extern "C" void vt_conv3x3_destroy(vt_conv3x3 *h) { if (!h) return; (void)hipFree(h->w); delete h; }
 
-extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
-                                     const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
+// like vt_conv3x3_forward_gn; with stats_ws != NULL the kernel also leaves the GroupNorm partial sums of its OUTPUT (one block per 8 x 16 pixel tile,
+// layout of vt_groupnorm_stats' partials) at stats_ws + B * groups doubles: vt_groupnorm_finalize(stats_ws, tiles, ...) then yields the {mean, rstd}
+// pairs the next convolution of the ConvBlock consumes, without a statistics pass over the tensor.  stats_ws >= B groups + tiles B Cout 2 doubles.
+extern "C" int vt_conv3x3_forward_gn_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                           const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, double *stats_ws,
+                                           int stats_groups, void *stream)
 {
     VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0
                    && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
@@ -220,10 +249,18 @@ extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int i
     VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv3x3_forward_gn: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
     const dim3 grid((H / CV_TH) * (W / CV_TW), B);
     const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
-    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout);
-    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout);
+    VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv3x3_forward_gn_stats: stats_groups must be positive");
+    double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
+    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part);
+    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part);
     VT_LAUNCH_CHECK();
     return VT_OK;
+}
+extern "C" int vt_conv3x3_tiles(int H, int W) { return (H / CV_TH) * (W / CV_TW); }
+extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                     const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
+{
+    return vt_conv3x3_forward_gn_stats(h, in, in_cstride, in_coff, gn_stats, gamma, beta, groups, B, H, W, out, out_cstride, out_coff, nullptr, 0, stream);
 }
 extern "C" int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream)
 {

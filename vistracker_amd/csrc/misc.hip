@@ -552,6 +552,16 @@ extern "C" int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, 
     return gn_statistics(x + coff, cstride, B, HW, C, groups, eps, ws, vt_stream(stream));
 }
 
+// second half of vt_groupnorm_stats for partial sums that somebody else produced: `part` = ws + B * groups doubles holds nblk x (B, C) x {sum, sum of
+// squares} (vt_conv3x3_forward_gn_stats writes one block per output tile); the (B, groups) {mean, rstd} float pairs go to the start of ws
+extern "C" int vt_groupnorm_finalize(double *ws, int nblk, int B, int HW, int C, int groups, float eps, void *stream)
+{
+    VT_REQUIRE(ws && nblk > 0 && B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "vt_groupnorm_finalize: bad argument");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, vt_stream(stream), ws + (size_t)B * groups, nblk, B, HW, C, groups, eps, reinterpret_cast<float2 *>(ws));
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
 extern "C" int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream)
 {
     VT_REQUIRE(low && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "vt_upsample2x_bicubic_add: bad argument (C must be a multiple of 4)");

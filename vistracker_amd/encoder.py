@@ -116,16 +116,28 @@ class HGFilterEncoder:
             out = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)          # NHWC in memory
             src, cstride, coff, C = x, Cin, 0, Cin
             off = 0
+            lib = L.lib()
+            tiles = lib.vt_conv3x3_tiles(H, W)
+            ws_prev = None              # statistics of the current input slice left behind by the convolution that produced it
             for i, co in zip((1, 2, 3), couts):
                 wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
                 if self._hip_conv_ok(wn, H, W, True):
-                    ws = torch.empty(L.lib().vt_groupnorm_workspace_doubles(B, H * W, C, 32), dtype=torch.float64, device=x.device)
-                    L.check(L.lib().vt_groupnorm_stats(src.data_ptr(), cstride, coff, B, H * W, C, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
-                    L.check(L.lib().vt_conv3x3_forward_gn(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(),
-                                                          sd[gn + ".weight"].data_ptr(), sd[gn + ".bias"].data_ptr(), 32, B, H, W, out.data_ptr(), Ct, off, L.stream_ptr()))
+                    if ws_prev is None:         # input from outside the block (or from a library convolution): one statistics pass
+                        ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, C, 32), dtype=torch.float64, device=x.device)
+                        L.check(lib.vt_groupnorm_stats(src.data_ptr(), cstride, coff, B, H * W, C, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+                    else:                       # the producing convolution wrote per-tile partial sums: reduce them, no pass over the tensor
+                        ws = ws_prev
+                        L.check(lib.vt_groupnorm_finalize(ws.data_ptr(), tiles, B, H * W, C, 32, 1e-5, L.stream_ptr()))
+                    nxt = i < 3 and self._hip_conv_ok(p + f"conv{i + 1}.weight", H, W, True)
+                    ws_out = torch.empty(B * 32 + tiles * B * co * 2, dtype=torch.float64, device=x.device) if nxt else None
+                    L.check(lib.vt_conv3x3_forward_gn_stats(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(),
+                                                            sd[gn + ".weight"].data_ptr(), sd[gn + ".bias"].data_ptr(), 32, B, H, W, out.data_ptr(), Ct, off,
+                                                            ws_out.data_ptr() if nxt else None, 32, L.stream_ptr()))
+                    ws_prev = ws_out
                 else:
                     xin = src if (cstride == C and coff == 0) else src[:, coff:coff + C]
                     out[:, off:off + co] = F.conv2d(_gn(xin, sd, gn, relu=True), sd[wn], None, 1, 1)
+                    ws_prev = None
                 src, cstride, coff, C = out, Ct, off, co
                 off += co
         if p + "downsample.2.weight" in sd:
