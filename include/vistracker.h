@@ -179,6 +179,12 @@ int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, 
 int vt_conv3x3_forward_gn_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
                                 const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, double *stats_ws,
                                 int stats_groups, void *stream);
+/* The general form (one ConvBlock step): out (or NULL) <- convolution, fin (or NULL) <- convolution + res, the block's result for these channels
+ * (model/net_util.py:390-394: the residual add without a pass of its own). */
+int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                             const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff,
+                             const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
+                             double *stats_ws, int stats_groups, void *stream);
 int vt_conv3x3_tiles(int H, int W);
 int vt_groupnorm_finalize(double *ws, int nblk, int B, int HW, int C, int groups, float eps, void *stream);
 /* GroupNorm statistics of a channel slice: ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles; the (B, groups) {mean, rstd} float pairs

@@ -53,7 +53,8 @@ __device__ __forceinline__ float cv_row16_sum(float v)
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
-                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part)
+                                                         float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part,
+                                                         const float *__restrict__ res, int res_cstride, int res_coff, float *__restrict__ fin, int fin_cstride, int fin_coff)
 {
     // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
     __shared__ __attribute__((aligned(16))) uint4 patch[2][2 * 4 * CV_PX];
@@ -176,17 +177,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     if (rmax > CV_SPLIT_MAX) sOvf = 1;
     __syncthreads();
     const bool ovf = sOvf != 0;
-    float *__restrict__ ob = out + (size_t)b * H * W * out_cstride + out_coff;
+    // `out` (may be NULL) takes the convolution itself -- what the next convolution of a ConvBlock reads --, `fin` (may be NULL) the block's result
+    // for these channels: convolution + residual (model/net_util.py:390-394), so that the concatenation never needs a separate add pass.
+    // The D fragments hold 4 channels of 8 x 1 pixels per lane: written from there, the 16 lanes of a row hit 16 different pixels (16 bytes at a
+    // stride of the whole channel vector -- the lane pattern that halves the vector-memory rate).  The tile goes through LDS
+    // ([pixel][64 channels], one pass per NT) and leaves with 16 adjacent lanes per pixel = 256 contiguous bytes; the residual is read the same way.
+    float *__restrict__ ob = out ? out + (size_t)b * H * W * out_cstride + out_coff : nullptr;
+    float *__restrict__ fb = fin ? fin + (size_t)b * H * W * fin_cstride + fin_coff : nullptr;
+    const float *__restrict__ rb = fin ? res + (size_t)b * H * W * res_cstride + res_coff : nullptr;
+    constexpr int TS = 68;                                      // floats per staged pixel row: 64 channels + 4 (bank spread)
+    float *tile = reinterpret_cast<float *>(patch);            // 128 x 68 floats = 34 KB of the 46 KB patch buffers (all readers passed the barrier above)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
+    for (int nt = 0; nt < NT; nt++) {
+        if (nt) __syncthreads();                                // the readers of the previous pass are done
 #pragma unroll
         for (int p = 0; p < CV_TH; p++) {
-            const int y = ty * CV_TH + p, x = tx * CV_TW + j, co = (wave * NT + nt) * 16 + 4 * q;
-            if (co >= cout) continue;
             float4 v = make_float4(acc[nt][p][0] * inv_scale, acc[nt][p][1] * inv_scale, acc[nt][p][2] * inv_scale, acc[nt][p][3] * inv_scale);
             if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-            *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
+            *reinterpret_cast<float4 *>(tile + (p * CV_TW + j) * TS + wave * 16 + 4 * q) = v;
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int item = r * 256 + tid, piece = item & 15, px = item >> 4;                  // 128 pixels x 16 pieces of 4 channels
+            const int co = ((piece >> 2) * NT + nt) * 16 + (piece & 3) * 4;                     // staged column 4 piece = wave (piece >> 2), row 4 (piece & 3) of its tile
+            if (co >= cout) continue;
+            const int y = ty * CV_TH + px / CV_TW, x = tx * CV_TW + px % CV_TW;
+            const float4 v = *reinterpret_cast<const float4 *>(tile + px * TS + piece * 4);
+            if (ob) *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
+            if (fb) {
+                const float4 rr = *reinterpret_cast<const float4 *>(rb + ((size_t)y * W + x) * res_cstride + co);
+                *reinterpret_cast<float4 *>(fb + ((size_t)y * W + x) * fin_cstride + co) = make_float4(v.x + rr.x, v.y + rr.y, v.z + rr.z, v.w + rr.w);
+            }
+        }
+    }
     // GroupNorm statistics of the OUTPUT for the convolution that follows in a ConvBlock (it normalises exactly these values): per output channel
     // the sum and the sum of squares over this workgroup's 8 x 16 pixels -- 8 rows in the lane, 16 columns across a DPP row -- written as one
     // block of partials [tile][frame][channel][2] (fp64) for vt_groupnorm_finalize.  Saves the statistics pass over the tensor.
@@ -236,25 +260,37 @@ extern "C" int vt_conv3x3_create(vt_conv3x3 **out, const float *weight, int cout
 }
 extern "C" void vt_conv3x3_destroy(vt_conv3x3 *h) { if (!h) return; (void)hipFree(h->w); delete h; }
 
-// like vt_conv3x3_forward_gn; with stats_ws != NULL the kernel also leaves the GroupNorm partial sums of its OUTPUT (one block per 8 x 16 pixel tile,
-// layout of vt_groupnorm_stats' partials) at stats_ws + B * groups doubles: vt_groupnorm_finalize(stats_ws, tiles, ...) then yields the {mean, rstd}
-// pairs the next convolution of the ConvBlock consumes, without a statistics pass over the tensor.  stats_ws >= B groups + tiles B Cout 2 doubles.
+// The general form: GroupNorm + ReLU prologue (gn_stats), the convolution to `out` (or NULL), convolution + residual to `fin` (or NULL; res =
+// channels [res_coff, ..) of an NHWC tensor with res_cstride channels), and with stats_ws != NULL the GroupNorm partial sums of the convolution's
+// output (one block per 8 x 16 pixel tile, layout of vt_groupnorm_stats' partials) at stats_ws + B * stats_groups doubles: vt_groupnorm_finalize(
+// stats_ws, tiles, ...) then yields the {mean, rstd} pairs the next convolution of the ConvBlock consumes, without a statistics pass over the tensor.
+extern "C" int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                        const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff,
+                                        const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
+                                        double *stats_ws, int stats_groups, void *stream)
+{
+    VT_REQUIRE(h && in && (out || fin) && B > 0 && H % CV_TH == 0 && W % CV_TW == 0
+                   && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
+               "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and 16-byte aligned channel slices");
+    VT_REQUIRE(!out || (out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0), "vt_conv3x3_forward: bad output slice");
+    VT_REQUIRE(!fin || (res && fin_cstride >= fin_coff + h->cout && fin_cstride % 4 == 0 && fin_coff % 4 == 0 && res_cstride >= res_coff + h->cout && res_cstride % 4 == 0 && res_coff % 4 == 0),
+               "vt_conv3x3_forward_block: bad residual / result slice");
+    VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv3x3_forward_gn: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
+    const dim3 grid((H / CV_TH) * (W / CV_TW), B);
+    const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
+    VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv3x3_forward_block: stats_groups must be positive");
+    double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
+    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff);
+    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
 extern "C" int vt_conv3x3_forward_gn_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
                                            const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff, double *stats_ws,
                                            int stats_groups, void *stream)
 {
-    VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0
-                   && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
-               "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and 16-byte aligned channel slices");
-    VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv3x3_forward_gn: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
-    const dim3 grid((H / CV_TH) * (W / CV_TW), B);
-    const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
-    VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv3x3_forward_gn_stats: stats_groups must be positive");
-    double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
-    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part);
-    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part);
-    VT_LAUNCH_CHECK();
-    return VT_OK;
+    return vt_conv3x3_forward_block(h, in, in_cstride, in_coff, gn_stats, gamma, beta, groups, B, H, W, out, out_cstride, out_coff, nullptr, 0, 0, nullptr, 0, 0,
+                                    stats_ws, stats_groups, stream);
 }
 extern "C" int vt_conv3x3_tiles(int H, int W) { return (H / CV_TH) * (W / CV_TW); }
 extern "C" int vt_conv3x3_forward_gn(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,

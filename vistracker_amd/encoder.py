@@ -105,6 +105,8 @@ class HGFilterEncoder:
         sd = self.sd
         B, Cin, H, W = x.shape
         couts = [sd[p + f"conv{i}.weight"].shape[0] for i in (1, 2, 3)]
+        if x.is_cuda and all(self._hip_conv_ok(p + f"conv{i}.weight", H, W, True) for i in (1, 2, 3)):
+            return self._conv_block_fused(x, p, couts)
         if not (x.is_cuda and any(self._hip_conv_ok(p + f"conv{i}.weight", H, W, True) for i in (1, 2, 3))):
             o1 = F.conv2d(_gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
             o2 = F.conv2d(_gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
@@ -145,6 +147,37 @@ class HGFilterEncoder:
             # real checkpoint); "downsample.0" is the name that is loaded last, i.e. the one the reference ends up using
             x = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"])
         return out + x
+
+    def _conv_block_fused(self, x, p, couts):
+        """all three convolutions on the split-f16 kernel: GroupNorm + ReLU in the operand staging, the statistics of the inner convolutions from the
+        per-tile partial sums of their producer, and the block's result (concatenation + residual, model/net_util.py:390-394) written by the
+        convolutions themselves: ``raw`` holds o1 | o2 for the next convolution to read, ``fin`` = cat(o1, o2, o3) + residual"""
+        sd, lib = self.sd, L.lib()
+        B, Cin, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        res = x
+        if p + "downsample.2.weight" in sd:         # see _conv_block: Sequential(bn4, ReLU, conv1x1)
+            res = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"]).contiguous(memory_format=torch.channels_last)
+        Ct, Cr = sum(couts), couts[0] + couts[1]
+        assert res.shape[1] == Ct
+        raw = torch.empty(B, Cr, H, W, device=x.device, memory_format=torch.channels_last)
+        fin = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)
+        tiles = lib.vt_conv3x3_tiles(H, W)
+        ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, Cin, 32), dtype=torch.float64, device=x.device)
+        L.check(lib.vt_groupnorm_stats(x.data_ptr(), Cin, 0, B, H * W, Cin, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+        src, cstride, coff, C, off = x, Cin, 0, Cin, 0
+        for i, co in zip((1, 2, 3), couts):
+            wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
+            ws_out = torch.empty(B * 32 + tiles * B * co * 2, dtype=torch.float64, device=x.device) if i < 3 else None
+            L.check(lib.vt_conv3x3_forward_block(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(), sd[gn + ".weight"].data_ptr(),
+                                                 sd[gn + ".bias"].data_ptr(), 32, B, H, W, raw.data_ptr() if i < 3 else None, Cr, off if i < 3 else 0,
+                                                 res.data_ptr(), Ct, off, fin.data_ptr(), Ct, off, ws_out.data_ptr() if i < 3 else None, 32, L.stream_ptr()))
+            if i < 3:
+                L.check(lib.vt_groupnorm_finalize(ws_out.data_ptr(), tiles, B, H * W, co, 32, 1e-5, L.stream_ptr()))
+                ws = ws_out
+            src, cstride, coff, C = raw, Cr, off, co
+            off += co
+        return fin
 
     def _hourglass(self, level, x, p):
         up1 = self._conv_block(x, f"{p}b1_{level}.")
