@@ -689,3 +689,46 @@ def test_conv3x3_split_f16_vs_float64(hip, cin, cout):
     L.check(L.lib().vt_conv3x3_forward(h, L.dptr(xn), B, H, W, L.dptr(out), ctot, coff, L.stream_ptr()))
     assert torch.isnan(out[0, 0:8, 0:16, coff:coff + cout]).all() and torch.isfinite(out[1]).all()       # the tiles that saw it are poisoned, others fine
     L.lib().vt_conv3x3_destroy(h)
+
+
+def test_conv3x3_block_step_vs_float64(hip):
+    """vt_conv3x3_forward_block, one step of a ConvBlock (model/net_util.py:374-394): GroupNorm + ReLU prologue from vt_groupnorm_stats, the plain
+    convolution to `out`, convolution + residual to `fin`, and the GroupNorm partial sums of the convolution's output -> vt_groupnorm_finalize gives
+    the same {mean, rstd} as a statistics pass over the stored output."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vistracker_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(11)
+    B, H, W, cin, cout, groups = 3, 16, 32, 64, 64, 32
+    x = torch.randn(B, cin, H, W, generator=g) * 1.5 + 0.3
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    gamma = torch.rand(cin, generator=g) + 0.5; beta = torch.randn(cin, generator=g) * 0.2
+    res = torch.randn(B, cout + 8, H, W, generator=g)
+    act = F.relu(F.group_norm(x.double(), groups, gamma.double(), beta.double(), 1e-5))
+    ref = F.conv2d(act, w.double(), None, 1, 1)
+    h = C.c_void_p()
+    wh = np.ascontiguousarray(w.numpy().reshape(cout, cin, 9))
+    L.check(lib.vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda(); rn = res.permute(0, 2, 3, 1).contiguous().cuda()
+    ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, cin, groups), dtype=torch.float64, device="cuda")
+    L.check(lib.vt_groupnorm_stats(L.dptr(xn), cin, 0, B, H * W, cin, groups, 1e-5, L.dptr(ws), L.stream_ptr()))
+    tiles = lib.vt_conv3x3_tiles(H, W)
+    ws2 = torch.empty(B * groups + tiles * B * cout * 2, dtype=torch.float64, device="cuda")
+    out = torch.full((B, H, W, cout), 7.0, device="cuda"); fin = torch.full((B, H, W, cout + 16), 7.0, device="cuda")
+    ga, be = gamma.cuda(), beta.cuda()
+    L.check(lib.vt_conv3x3_forward_block(h, L.dptr(xn), cin, 0, L.dptr(ws), L.dptr(ga), L.dptr(be), groups, B, H, W, L.dptr(out), cout, 0,
+                                         L.dptr(rn), cout + 8, 4, L.dptr(fin), cout + 16, 8, L.dptr(ws2), groups, L.stream_ptr()))
+    L.check(lib.vt_groupnorm_finalize(L.dptr(ws2), tiles, B, H * W, cout, groups, 1e-5, L.stream_ptr()))
+    refn = ref.permute(0, 2, 3, 1).numpy(); sc = np.abs(refn).max()
+    assert np.abs(npy(out) - refn).max() < 3e-6 * sc
+    want = refn + res.permute(0, 2, 3, 1).numpy()[..., 4:4 + cout]
+    got = npy(fin)
+    assert np.abs(got[..., 8:8 + cout] - want).max() < 3e-6 * np.abs(want).max()
+    assert (got[..., :8] == 7.0).all() and (got[..., 8 + cout:] == 7.0).all()
+    # statistics of the stored output: mean and rstd per (frame, group)
+    st = ws2[:B * groups].view(torch.float32).view(B, groups, 2).cpu().numpy().astype(np.float64)
+    o = npy(out).astype(np.float64).reshape(B, H * W, groups, cout // groups)
+    mean = o.mean((1, 3)); var = o.var((1, 3))
+    assert np.abs(st[..., 0] - mean).max() < 1e-5 * sc and np.abs(st[..., 1] - 1 / np.sqrt(var + 1e-5)).max() < 1e-4 * (1 / np.sqrt(var + 1e-5)).max()
+    lib.vt_conv3x3_destroy(h)
