@@ -2,12 +2,16 @@
 """bench.py -- frames/s of the VisTracker SMPL-H + object fit (recon_fit_trivis_full: optimize_smpl + optimize_smpl_object)
 on MI355X.
 
-A "step" is one pass of the hot path over one batch of B=96 consecutive frames of a synthetic 1500-frame sequence
-(reference batch size, recon/recon_fit_triplane.py:257): the full SMPL stage and the full object stage with the
-reference's schedules, loss weights and early-stop rules.  Feature maps (71.3 MB/frame fp32) are
-resident in HBM when the timed region starts.  With N GPUs every rank fits its own K batches (batch-aligned frame
-sharding, no collective inside the fit; one all_gather of the fitted parameters at the end) -> weak scaling; `value` is
-the whole-job frames/s.
+The workload is BASELINE.json's: a synthetic 1500-frame sequence cut into the reference's batches of 96 consecutive frames
+(recon/recon_fit_triplane.py:257; 1500 = 15 x 96 + 60, the tail batch is part of it).  A "step" is one pass of the hot path
+over ONE batch: the full SMPL stage and the full object stage with the reference's schedules, loss weights and early-stop
+rules.  `--steps K` times exactly K batches taken in order from the sequence's batch list (cyclically:
+K = 16 is one pass over the sequence, the default; K = 20 is one pass plus the first four batches again with fresh noise).
+Feature maps (71.3 MB/frame fp32) are resident in HBM when the timed region starts.  With N GPUs the K batches are sharded
+over the ranks in contiguous runs of whole batches (the reference's --start/--end contract, recon/recon_fit_base.py:411-419;
+no collective inside the fit; one all_gather of the fitted parameters at the end) -> STRONG scaling of one job; `value` is the
+whole-job frames/s = frames of the K batches / max-over-ranks wall clock.  `--mode weak` is the former per-rank form (every
+rank fits its own K full batches).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -51,15 +55,17 @@ def pmc_traffic_bytes():
         return None
 
 
-def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0):
-    """Synthetic inputs of one 96-frame batch, all on the device."""
+def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0, seq=None):
+    """Synthetic inputs of one batch, all on the device.  ``seq``: the batch's frames of the synthetic sequence
+    (a slice of syn.sequence_params); None = an independent 96-frame trajectory drawn from ``seed``."""
     import torch.nn.functional as F
     from vistracker_amd import ops
     from vistracker_amd.fitting import SilSetup
     g = torch.Generator(device=dev); g.manual_seed(seed)
     rng = np.random.default_rng(seed)
-    B = BATCH
-    seq = syn.sequence_params(B, seed=seed, grab_hand_mean=np.concatenate([ctx.pri_np["lhand_mean"], ctx.pri_np["rhand_mean"]]))
+    if seq is None:
+        seq = syn.sequence_params(BATCH, seed=seed, grab_hand_mean=np.concatenate([ctx.pri_np["lhand_mean"], ctx.pri_np["rhand_mean"]]))
+    B = len(seq["pose"])
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
     gt_pose, gt_betas, gt_trans = t(seq["pose"]), t(seq["betas"]), t(seq["trans"])
     cc = t(np.tile([[1018.952, 779.486]], (B, 1)) + rng.normal(0, 20, (B, 2)))
@@ -218,7 +224,11 @@ def cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps, budg
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=None, help="batches in the timed region (default: one pass over the sequence = 16 for 1500 frames; "
+                                                             "--mode weak: per rank, default 4)")
+    ap.add_argument("--sequence", type=int, default=1500, help="frames of the synthetic sequence the batches are cut from")
+    ap.add_argument("--mode", choices=("strong", "weak"), default="strong",
+                    help="strong (default): the K batches of ONE sequence sharded over the ranks; weak: every rank fits its own K full batches")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
@@ -255,14 +265,35 @@ def main():
     ctx = FitContext(model, regs, pri, dec, labels, ov, of, opts, device=dev)
     ctx.pri_np = pri
 
+    from vistracker_amd import sharding
+    strong = args.mode == "strong"
+    seq_batches = sharding.batches_of(args.sequence, BATCH)            # [(0, 96), ..., (1440, 1500)]: the reference's batch list
+    if args.steps is None:
+        args.steps = len(seq_batches) if strong else 4
+    hands = np.concatenate([pri["lhand_mean"], pri["rhand_mean"]])
+    seq_all = syn.sequence_params(args.sequence, seed=7, grab_hand_mean=hands) if strong else None
+
     def run(idx, prof=None):
-        d = make_batch(ctx, syn, torch, seed=1000 * rank + idx, dev=dev, res_scale=args.res_scale)
+        if strong:       # job idx = batch (idx mod 16) of the sequence, the noise of the synthetic observations keyed by idx
+            s_, e_ = seq_batches[idx % len(seq_batches)]
+            d = make_batch(ctx, syn, torch, seed=1000 + idx, dev=dev, res_scale=args.res_scale, seq={k: v[s_:e_] for k, v in seq_all.items()})
+        else:
+            d = make_batch(ctx, syn, torch, seed=1000 * rank + idx, dev=dev, res_scale=args.res_scale)
         torch.cuda.synchronize()
         return d
 
+    # this rank's jobs: a contiguous run of the K batches (first K % world ranks take one more), or K of its own in weak mode
+    if strong:
+        base_, extra_ = divmod(args.steps, world)
+        lo_ = rank * base_ + min(rank, extra_)
+        my_jobs = list(range(lo_, lo_ + base_ + (1 if rank < extra_ else 0)))
+        total_frames = sum(e_ - s_ for s_, e_ in (seq_batches[j % len(seq_batches)] for j in range(args.steps)))
+    else:
+        my_jobs = list(range(args.steps)); total_frames = world * args.steps * BATCH
     for wi in range(args.warmup):
-        d = run(100 + wi); fit_batch(ctx, torch, d); del d
-    batches = [run(i) for i in range(args.steps)]          # inputs resident in HBM before the timed region
+        d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
+        fit_batch(ctx, torch, d); del d
+    batches = [run(i) for i in my_jobs]                    # inputs resident in HBM before the timed region
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events
     torch.cuda.synchronize()
@@ -291,8 +322,13 @@ def main():
         for t_ in th_: t_.join()
         for s_ in streams:
             torch.cuda.current_stream().wait_stream(s_)
-    if world > 1:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch)
-        packed = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(BATCH, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches]).to(cdev)
+    if world > 1:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch), padded to the largest shard
+        rows_max = (args.steps + world - 1) // world * BATCH if strong else args.steps * BATCH
+        packed = torch.zeros(rows_max, 182, device=dev)
+        if batches:
+            mine = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(-1, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches])
+            packed[: mine.shape[0]] = mine
+        packed = packed.to(cdev)
         out = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(out, packed)
     torch.cuda.synchronize()
@@ -310,30 +346,36 @@ def main():
                 extras[name] = fn()
             except Exception as e:          # noqa: BLE001
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
-        leg("solo_launch_s", lambda: solo_kernel_leg(ctx, torch, batches[0]))
+        full96 = next((d_ for d_ in batches if d_["pose"].shape[0] == BATCH), None) or make_batch(ctx, syn, torch, seed=555, dev=dev, res_scale=args.res_scale)
+        leg("solo_launch_s", lambda: solo_kernel_leg(ctx, torch, full96))
 
         def full_schedule():
-            d = run(900); torch.cuda.synchronize(); t1 = time.perf_counter()
+            d = make_batch(ctx, syn, torch, seed=900, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize(); t1 = time.perf_counter()
             r1, r2 = fit_batch(ctx, torch, d, early_stop=False); torch.cuda.synchronize(); dt = time.perf_counter() - t1
             return {"workload": "one 96-frame batch, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
                                 "steps, of which 1100 in phase 'joint' with the contact Chamfer term), one batch in flight",
                     "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds": dt, "frames_per_s": BATCH / dt,
                     "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
         leg("full_schedule", full_schedule)
-        del batches[1:]
+        del full96; batches.clear()
         torch.cuda.empty_cache()
         leg("sifnet_inference", lambda: sifnet_inference_leg(torch, syn))
         torch.cuda.empty_cache()
         leg("demo_pipeline", lambda: pipeline_leg(torch, args.pipeline_frames))
     if rank == 0:
-        frames = world * args.steps * BATCH
+        frames = total_frames
         smpl_steps = float(np.mean([r[0].steps for r in results])); obj_steps = float(np.mean([r[1].steps for r in results]))
-        th = np.array([a.elapsed_time(b) for a, b in prof["human"]]) * 1e-3 if prof["human"] else np.zeros(1)
-        to = np.array([a.elapsed_time(b) for a, b in prof["object"]]) * 1e-3 if prof["object"] else np.zeros(1)
-        flops_h = FLOP_PER_POINT_HUMAN * BATCH * 6890
+        # frames x executed Adam steps of THIS rank's batches (the tail batch has fewer frames), scaled to the job
+        my_frames = sum(d_["pose"].shape[0] for d_ in batches)
+        frame_steps = sum(d_["pose"].shape[0] * (r[0].steps + r[1].steps) for d_, r in zip(batches, results)) * (frames / max(my_frames, 1))
+        th = np.array([a.elapsed_time(b) for a, b, _ in prof["human"]]) * 1e-3 if prof["human"] else np.zeros(1)
+        to = np.array([a.elapsed_time(b) for a, b, _ in prof["object"]]) * 1e-3 if prof["object"] else np.zeros(1)
+        fo = np.array([n for _, _, n in prof["object"]], np.float64) if prof["object"] else np.ones(1)
+        flops_h = FLOP_PER_POINT_HUMAN * BATCH * 6890          # per launch of a full 96-frame batch
+        flops_all = FLOP_PER_POINT_HUMAN * 6890 * float(sum(n for _, _, n in prof["human"]))
         # time during which at least one launch of the kernel was executing (union of the [start, end] intervals): equal to the
         # sum of the durations with one stream; with several streams two launches share the chip and each one's own duration grows
-        iv = sorted((base_ev.elapsed_time(a) * 1e-3, base_ev.elapsed_time(b) * 1e-3) for a, b in prof["human"])
+        iv = sorted((base_ev.elapsed_time(a) * 1e-3, base_ev.elapsed_time(b) * 1e-3) for a, b, _ in prof["human"])
         busy, cur_s, cur_e = 0.0, None, None
         for s_, e_ in iv:
             if cur_e is None or s_ > cur_e:
@@ -343,20 +385,25 @@ def main():
                 cur_e = max(cur_e, e_)
         busy += (cur_e - cur_s) if cur_e is not None else 0.0
         eff = busy / max(len(iv), 1)                       # effective time per launch
-        ach = flops_h / eff / 1e12 if eff > 0 else 0.0
+        ach = flops_all / busy / 1e12 if busy > 0 else 0.0
         solo = extras.get("solo_launch_s") if isinstance(extras.get("solo_launch_s"), float) else None
         line = {
             "metric": "frames/sec joint SMPL+object fit", "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32 (decoder GEMMs: 22-bit split-f16 operands x3 MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "recon_fit_trivis_full joint opt (optimize_smpl + optimize_smpl_object), batches of 96 frames of a synthetic "
-                                   "1500-frame sequence, SMPL-H V=6890 + 1 rigid object (2500 faces, 3000 surface points), feature maps resident "
-                                   f"(res_scale={args.res_scale})",
+            "config": {"workload": ("recon_fit_trivis_full joint opt (optimize_smpl + optimize_smpl_object) over " +
+                                    (f"{args.steps} batches taken in order (cyclically) from the batch list of ONE synthetic {args.sequence}-frame sequence "
+                                     f"({len(seq_batches)} batches of <= 96 consecutive frames: {args.sequence} = {args.sequence // BATCH} x 96 + {args.sequence % BATCH}), "
+                                     f"{frames} frames in the timed region" if strong else
+                                     f"{args.steps} independent 96-frame batches per rank") +
+                                    f", SMPL-H V=6890 + 1 rigid object (2500 faces, 3000 surface points), feature maps resident (res_scale={args.res_scale})"),
+                       "sequence_frames": args.sequence if strong else None, "frames_timed": frames,
                        "batch_frames": BATCH, "adam_steps_smpl_stage": smpl_steps, "adam_steps_object_stage": obj_steps,
                        "early_stop": "reference rule, evaluated on device",
                        # the stop rules make the step count data dependent: the steps-normalised rate lets runs with different counts be compared
-                       "frame_steps_per_s": frames * (smpl_steps + obj_steps) / elapsed,
-                       "sharding": f"{world} ranks x {args.steps} batches, no collective in the fit; {args.streams} batch(es) in flight per GPU"},
+                       "frame_steps_per_s": frame_steps / elapsed,
+                       "sharding": (f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)" if strong
+                                    else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
                          "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_query_human.json)",
@@ -368,7 +415,7 @@ def main():
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
                          "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "
                                           "per-launch HIP events); equals flop_per_launch / avg_launch_ms when --streams 1",
-                         "launches": int(len(th)), "flop_per_launch": flops_h,
+                         "launches": int(len(th)), "flop_per_launch": flops_h, "flop_all_launches": flops_all,
                          "mfma_flop_per_launch": FLOP_PER_POINT_HUMAN_MFMA * BATCH * 6890,
                          "frac_mfma_executed": ach * FLOP_PER_POINT_HUMAN_MFMA / FLOP_PER_POINT_HUMAN / PEAK_SPLIT_TFLOPS,
                          "hoisting_note": "the im_feat part of layer 1 (42 % of its FLOPs, 30 % of the kernel's) is hoisted out of the Adam loop: applied to "
@@ -377,10 +424,10 @@ def main():
                          # the other roof of this kernel, for information: SURVEY.md 8(d) counts 608 ch x 4 taps x 4 B = 9728 B/pt "touched" in each
                          # direction (an upper bound: neighbouring points share texels, the caches serve them; "traffic" above is what reaches HBM)
                          "gather": {"algorithmic_bytes_per_launch": 2 * 9728 * BATCH * 6890, "unit": "TB/s", "peak": 8.0,
-                                    "achieved": 2 * 9728 * BATCH * 6890 / max(eff, 1e-12) / 1e12, "frac": 2 * 9728 * BATCH * 6890 / max(eff, 1e-12) / 8e12,
+                                    "achieved": ach / FLOP_PER_POINT_HUMAN * 2 * 9728, "frac": ach / FLOP_PER_POINT_HUMAN * 2 * 9728 / 8.0,
                                     "note": "bytes the gathers request (touched, not unique) / launch time vs the HBM peak; the L2 / MALL serve ~70 % of them"},
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
-                         "object_kernel_tflops": FLOP_PER_POINT_OBJECT * BATCH * N_OBJ / max(to.mean(), 1e-12) / 1e12},
+                         "object_kernel_tflops": FLOP_PER_POINT_OBJECT * N_OBJ * float(fo.sum()) / max(to.sum(), 1e-12) / 1e12},
         }
         for k in ("full_schedule", "sifnet_inference", "demo_pipeline"):
             if k in extras:

@@ -124,6 +124,17 @@ typedef struct {
      * this array instead of gathering the 256 im_feat channels and multiplying them by W1.  Results agree to fp32 round-off. */
     const float *proj;
     int proj_cols;
+    /* operand-range level of the split-f16 decoders for the calls that pass THESE maps: level k runs the last hidden layer at the operand scale
+     * 2^(6 - 4 k) (representable |activation| < 1023, 16 368, 262 016 for k = 0, 1, 2; the earlier layers have at least that range -- the decoders
+     * of model/chore.py:113-126 have no such bound); beyond it a call yields NaN, loudly.  Same weights, exact power-of-two rescaling of biases /
+     * features / outputs, so a checkpoint with large activations costs one repeated launch at the next level, not the 5x slower fp32 route.
+     * proj_level = the level `proj` was built for (vt_query_build_projection uses act_level; a projection of another level is ignored).
+     * Zero-initialised = level 0. */
+    int act_level;
+    int proj_level;
+    /* non-zero: these calls run on the strict-fp32 kernels whatever the handle's precision (per batch, so concurrent fits through one handle do
+     * not see each other's switch) */
+    int force_fp32;
 } vt_maps;
 
 /* pts (B,N,3), crop_center (B,2), body_center (B,3).  Outputs may be NULL (head skipped); layout as the
@@ -193,7 +204,7 @@ int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int
 
 /* Arithmetic of the decoder GEMMs behind every vt_query_* call of a handle:
  *   VT_PRECISION_SPLIT_F16 (default): 22-bit split-f16 operands on the f16 MFMA, fp32 accumulate (5.3x the f32-input MFMA rate; forward within
- *       ~1e-6 of the fp32 reference); activations must satisfy |x| < 1023, beyond that the result is inf/NaN;
+ *       ~1e-6 of the fp32 reference); activations must satisfy |x| < 1023 * 16^(vt_maps::act_level), beyond that the result is NaN;
  *   VT_PRECISION_FP32: exact fp32 products on the f32-input MFMA (the reference's nn.Conv1d arithmetic, model/chore.py:113-126), any magnitude,
  *       ~1/5 of the speed; the hoisted projection of the maps is ignored.
  * The fused fit loops of the host layer switch a handle to VT_PRECISION_FP32 and re-run the batch when the split route produced a non-finite

@@ -29,6 +29,11 @@ cfg = PipelineConfig(smplt_bs=40, neural_bs=32, fit_bs=48, smplt_max_iter=4, ref
 pipe, assets = demo_inputs.pipeline(cfg, n_obj_points=600)
 seq = demo_inputs.sequence(T, assets)
 out = pipe.run(seq)
+# every rank: the maps of ITS frames stayed resident between the SIF-Net pass and the joint fit, two batches were in flight, and the encoder ran
+# exactly once per frame of the rank's range (stage 6 did not encode again)
+lo, hi = pipe.log["frame_range"]
+assert pipe.log["resident_maps"] and pipe.log["frames_encoded"] == hi - lo, (pipe.log["resident_maps"], pipe.log["frames_encoded"], lo, hi)
+print("RANK_OK", int(os.environ.get("RANK", "0")), lo, hi, pipe.log["frames_encoded"], flush=True)
 if not dist.is_initialized() or dist.get_rank() == 0:
     rc, st, nn_ = out["recon"], out["smplt_smoothed_fit"], out["neural"]
     np.savez(sys.argv[1], poses=rc["poses"], betas=rc["betas"], trans=rc["trans"], obj_angles=rc["obj_angles"], obj_trans=rc["obj_trans"],

@@ -212,39 +212,115 @@ def test_empty_object_mask_in_a_batch(synth):
     assert res.steps == 30 and np.isfinite(res.losses).all() and torch.isfinite(R).all() and torch.isfinite(t).all()
 
 
-def test_activation_range_fallback_to_fp32(synth):
-    """Adversarial magnitudes (features x 100, decoder weights x 10): hidden activations leave the range of the split-f16 operands (|x| >= 1023), the
-    split route yields a non-finite loss -- the fit restores its parameters, switches the handle to the strict-fp32 kernels and returns the fp32
-    result (the reference's Conv1d decoders have no such limit, model/chore.py:113-126)."""
-    from oracle import oracle as O
+def _range_case(synth, feat_gain, w_gain):
     from vistracker_amd import ops, synthetic as syn
     from vistracker_amd.fitting import FitContext
     from conftest import golden
     g = golden("smplfit")
-    dec = syn.sifnet_decoders(3, gain=10.0)
-    mp = {k: (100.0 * v).astype(np.float32) for k, v in syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])).items()}
+    dec = syn.sifnet_decoders(3, gain=w_gain)
+    mp = {k: (feat_gain * v).astype(np.float32) for k, v in syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])).items()}
     ctx = FitContext(synth["model"], synth["regs"], synth["priors"], dec, synth["labels"], np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32), np.zeros((8, 3), np.float32))
-    maps = ops.FeatureMaps.from_nchw(mp)
+    return g, dec, mp, ctx, ops.FeatureMaps.from_nchw(mp)
+
+
+def test_activation_range_levels_and_fp32_fallback(synth):
+    """Adversarial magnitudes (features x 30, decoder weights x 6): hidden activations leave the range of the split-f16 operands at level 0
+    (|x| >= 1023) and the call returns NaN, loudly.  The same kernels at a wider operand-range level (vt_maps::act_level: operand scale / 16 per
+    level, exact power-of-two rescaling) serve the network within 5e-6 of the strict-fp32 kernels; the fit climbs the levels by itself -- one
+    repeated fit per level, per batch, nothing stored in the shared network handle -- and takes the fp32 route only when the last level
+    overflows too (the reference's Conv1d decoders have no such limit, model/chore.py:113-126)."""
+    from oracle import oracle as O
+    from vistracker_amd import ops
+    g, dec, mp, ctx, maps = _range_case(synth, 30.0, 6.0)
     pts = cu(g["trans"])[:, None, :] + torch.randn(4, 70, 3, device="cuda") * 0.2
-    df = ops.sifnet_query(ctx.net, maps, pts, cu(g["crop_center"]), cu(g["body_center"]), head_mask=1)[0]
-    assert not torch.isfinite(df).all()                                  # the split route overflows on this network ...
-    ctx.net.set_precision("fp32")
-    df32 = ops.sifnet_query(ctx.net, maps, pts, cu(g["crop_center"]), cu(g["body_center"]), head_mask=1)[0]
+    q = lambda: ops.sifnet_query(ctx.net, maps, pts, cu(g["crop_center"]), cu(g["body_center"]), head_mask=0b00101)
+    df0, _, parts0, _, _ = q()
+    assert not torch.isfinite(df0).all()                                 # level 0 overflows on this network ...
+    maps.set_force_fp32(True); df32, _, parts32, _, _ = q(); maps.set_force_fp32(False)
     df_o = O.SifNet(dec, mp).query(pts.cpu().numpy(), g["crop_center"], g["body_center"], head_mask=1)[0]
-    assert torch.isfinite(df32).all() and np.abs(df32.cpu().numpy() - df_o).max() < 2e-5 * np.abs(df_o).max()      # ... the fp32 route does not
-    ctx.net.set_precision("split-f16")
+    assert torch.isfinite(df32).all() and np.abs(df32.cpu().numpy() - df_o).max() < 2e-5 * np.abs(df_o).max()      # ... the fp32 route does not ...
+    ok_level = None
+    for lv in range(1, maps.ACT_LEVELS):
+        maps.set_act_level(lv); df, _, parts, _, _ = q()
+        if torch.isfinite(df).all() and torch.isfinite(parts).all():
+            ok_level = lv; break
+    assert ok_level is not None, "no operand-range level serves the x30 / x6 network"
+    for a_, b_ in ((df, df32), (parts, parts32)):                        # ... and neither does the split route at the level that fits: 5e-6 of range
+        assert (a_ - b_).abs().max().item() < 5e-6 * b_.abs().max().item(), ((a_ - b_).abs().max().item(), b_.abs().max().item())
+    # coordinate gradients at that level against the fp32 kernels
+    def grads():
+        p = pts.clone().requires_grad_(True)
+        d, _, pa, _, _ = ops.sifnet_query(ctx.net, maps, p, cu(g["crop_center"]), cu(g["body_center"]), head_mask=0b00101)
+        (d.sum() + pa.sum()).backward()
+        return p.grad
+    gl = grads(); maps.set_force_fp32(True); g32 = grads(); maps.set_force_fp32(False)
+    err = ((gl - g32).abs().amax(-1) / g32.abs().max()).flatten()
+    assert torch.quantile(err, 0.97).item() < 1e-5, torch.quantile(err, 0.97).item()
+    # the fit finds the level by itself
+    maps.set_act_level(0)
     pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
-    with pytest.warns(RuntimeWarning, match="strict-fp32"):
+    with pytest.warns(RuntimeWarning, match="operand-range level"):
         res = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
-    assert ctx.fp32_fallbacks == 1 and ctx.net.precision == "fp32" and res.steps == 10 and np.isfinite(res.losses).all()
-    assert torch.isfinite(pose).all() and not torch.equal(trans, cu(g["trans"]))
+    assert ctx.range_retries == ok_level and ctx.fp32_fallbacks == 0 and maps.act_level == ok_level and not maps.force_fp32
+    assert ctx.net.precision == "split-f16"                              # nothing was switched in the shared handle
+    assert res.steps == 10 and np.isfinite(res.losses).all() and torch.isfinite(pose).all() and not torch.equal(trans, cu(g["trans"]))
     m = O.SmplModel(synth["model"]); b25 = O.Landmarks(synth["regs"]["body25"])
     total, _, _, _, _ = O.smplfit_loss_and_grad(m, b25, synth["priors"], O.SifNet(dec, mp), synth["labels"], g["pose"], g["betas"], g["trans"], crop_center=g["crop_center"],
                                                 body_center=g["body_center"], body_kpts=g["body_kpts"], pose_init=g["pose"][:, 3:72].copy(), phase="global", decay=1)
     assert abs(res.losses[0] - total) < 1e-4 * abs(total), (res.losses[0], total)
-    # a second fit on the same context goes straight to fp32: no warning, no repeat
+    # a second fit with the same maps starts at the level that worked: no warning, no repeat
     res2 = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
-    assert ctx.fp32_fallbacks == 1 and np.isfinite(res2.losses).all()
+    assert ctx.range_retries == ok_level and np.isfinite(res2.losses).all()
+
+
+def test_activation_range_beyond_every_level_falls_back_to_fp32(synth):
+    """features x 1e4, weights x 30: beyond the widest operand range too -- the fit ends on the strict-fp32 kernels, for this batch only"""
+    g, dec, mp, ctx, maps = _range_case(synth, 1.0e4, 30.0)
+    pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+    with pytest.warns(RuntimeWarning, match="strict-fp32"):
+        res = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 1))
+    assert ctx.fp32_fallbacks == 1 and maps.force_fp32 and ctx.net.precision == "split-f16" and np.isfinite(res.losses).all()
+    other = maps.slice(0, 4).set_force_fp32(False).set_act_level(0)       # another batch through the same handle is not affected
+    assert not other.force_fp32 and other.act_level == 0
+
+
+def test_concurrent_fits_through_one_handle_with_an_overflowing_batch(synth):
+    """Two batches in flight through ONE FitContext / network handle (pipeline.fit_streams = 2): one of them leaves the operand range of level 0 and
+    climbs the levels, the other never does.  Range level and route live in each batch's own maps, so neither fit can see the other's switch:
+    both results are bit-identical to the same fits run one after the other."""
+    import threading
+    from vistracker_amd import ops, synthetic as syn
+    g, dec, mp_big, ctx, _ = _range_case(synth, 30.0, 4.0)
+    mp_small = {k: (v / 30.0).astype(np.float32) for k, v in mp_big.items()}
+
+    def fit(mp, stream=None):
+        maps = ops.FeatureMaps.from_nchw(mp)
+        pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            res = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 2))
+        return maps.act_level, maps.force_fp32, pose, trans, res.losses.copy()
+    seq_big, seq_small = fit(mp_big), fit(mp_small)
+    assert seq_big[0] >= 1 and not seq_big[1] and seq_small[0] == 0 and not seq_small[1]          # the big batch needed a wider level, the small one did not
+    out = [None, None]; errs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def worker(k, mp):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(streams[k]):
+                out[k] = fit(mp)
+            streams[k].synchronize()
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(0, mp_big)), threading.Thread(target=worker, args=(1, mp_small))]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    assert not errs, errs
+    for seq, par in ((seq_big, out[0]), (seq_small, out[1])):
+        assert seq[0] == par[0] and seq[1] == par[1] and torch.equal(seq[2], par[2]) and torch.equal(seq[3], par[3]) and np.array_equal(seq[4], par[4])
+    assert ctx.net.precision == "split-f16"
 
 
 def _collision_case(synth, B=3, seed=4):

@@ -14,17 +14,21 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_bench_two_ranks_on_one_gpu(mode):
     env = dict(os.environ, VT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    # strong (the default): 3 batches of a 250-frame sequence (96 + 96 + 58 frames) over two ranks -> rank 0 two batches, rank 1 the tail
+    extra = ["--steps", "3", "--sequence", "250"] if mode == "strong" else ["--steps", "1", "--mode", "weak"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak" and line["unit"] == "frames/s"
-    # both ranks' batches are counted: 2 x 96 frames / the slower rank's time
-    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 96) < 1e-6 * 192
+    steps, frames = (3, 250) if mode == "strong" else (1, 2 * 96)
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == mode and line["unit"] == "frames/s"
+    # every rank's batches are counted: all frames of the job / the slowest rank's time
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 * steps - frames) < 1e-6 * frames and line["config"]["frames_timed"] == frames
     assert line["config"]["adam_steps_smpl_stage"] >= 280 and line["roofline"]["launches"] >= 280
 
 
@@ -43,7 +47,7 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                script, str(f), "100"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
-        assert out.returncode == 0 and "PIPELINE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        assert out.returncode == 0 and "PIPELINE_OK" in out.stdout and out.stdout.count("RANK_OK") == n, out.stdout[-2000:] + out.stderr[-4000:]
         outs.append(dict(np.load(f)))
     a, b = outs
     # the step logs are per rank: rank 0 of the 2-rank run holds the first half of the batches of every stage

@@ -232,10 +232,14 @@ def test_query_fused_objectives_vs_oracle(hip, synth, proj, precision):
         assert maps.c.proj_cols == 256 and maps.proj.numel() == B * mp["im_feat"].shape[2] * mp["im_feat"].shape[3] * 256
         P = npy(maps.proj).reshape(B, mp["im_feat"].shape[2], mp["im_feat"].shape[3], 256)
         tex = np.transpose(np.asarray(mp["im_feat"], np.float64), (0, 2, 3, 1))
+        # the kernel's power-of-two scales (query.hip: weight_scale_exp / vt_sifnet_create): s_l lifts max |W_l| into [1, 2) (hidden layers: never
+        # below 1), the feature scale U_1 is common to the heads and keeps every head's U_4 = s_1 s_2 s_3 U_1 <= 2^6
+        sexp = lambda w: 1 - int(np.frexp(np.abs(np.asarray(w)).max())[1])
+        u1 = 2.0 ** min(6 - sum(max(sexp(synth["decoders"][hd][l][0]), 0) for l in range(3)) for hd in ("df", "pca", "parts", "centers", "vis"))
         for col, head in ((0, "df"), (128, "parts")):
             W1 = np.asarray(synth["decoders"][head][0][0], np.float64)           # (128, 611), im_feat = reference channels 0..255
-            s1 = 2.0 ** (14 - np.frexp(np.abs(W1).max())[1])                     # the kernel's power-of-two weight scale
-            ref = tex @ (64.0 * s1 * W1[:, :256]).T
+            s1 = 2.0 ** max(sexp(W1), 0)
+            ref = tex @ (u1 * s1 * W1[:, :256]).T
             assert np.abs(P[..., col:col + 128] - ref).max() < 2e-6 * np.abs(ref).max(), head
     terms = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, N, 3, device="cuda")
     pts_t, cc_t, bc_t, lab_t, occ_t = cu(pts), cu(cc), cu(bc), cu(labels), cu(occ)

@@ -21,7 +21,8 @@ cd = C.c_double
 
 
 class VtMaps(C.Structure):
-    _fields_ = [("maps", C.c_void_p * 8), ("res", C.c_int * 8), ("proj", C.c_void_p), ("proj_cols", C.c_int)]
+    _fields_ = [("maps", C.c_void_p * 8), ("res", C.c_int * 8), ("proj", C.c_void_p), ("proj_cols", C.c_int),
+                ("act_level", C.c_int), ("proj_level", C.c_int), ("force_fp32", C.c_int)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check the export list against the header

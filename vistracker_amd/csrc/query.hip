@@ -41,8 +41,10 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define NSTEP1 20           /* K32 steps of layer 1: 19 map chunks + the xyz step */
 #define TS 36               /* LDS stride (floats) of a tap-difference row [pt][32 + 4] */
 #define OUT_DIST 5.0f       /* chore.py:93 */
-#define ACT_SCALE 64.0f     /* forward activations enter the MFMAs as 2^6 x */
-#define GO_EXP 5            /* upstream gradients are normalised per point to [2^5, 2^6) */
+#define ACT_EXP0 6           /* operand scale U of the forward activations at range level 0: 2^6 (|x| < 1023 representable) */
+#define ACT_LEVEL_SHIFT 4    /* every range level divides U by 2^4: level 1 = 2^2 (|x| < 16 368), level 2 = 2^-2 (|x| < 262 016) */
+#define ACT_LEVELS 3
+#define GO_EXP 5            /* upstream gradients are normalised per point so that the operands of the backward chain stay near [2^5, 2^6) x growth: HeadW::goexp */
 #define PROJ_COLS 256       /* columns of the hoisted im_feat projection: hidden-1 pre-activations of head df (0..127) | parts (128..255) */
 #define PROJ_C0 8           /* first chunk the layer-1 loops still process when the projection is used (chunks 0..7 = im_feat) */
 
@@ -52,11 +54,17 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_HUMAN = 2, MODE_OBJECT = 3, MODE_PROJECT
 //   T-pack : [K/32 steps][4 waves][2 nt][hi|lo][64 lanes]   halves t = M[32 wave + 16 nt + (lane & 15)][32 s + 8 (lane >> 4) + t]
 //   w4p    : [4 steps][hi|lo][64 lanes]                     halves t = W4[o = lane & 15][32 s + 8 (lane >> 4) + t]   (B operand of layer 4)
 //   w1c    : [20 chunks][4 steps][2 ct][hi|lo][64 lanes]    halves t = W1[u = 32 s + 8 (lane >> 4) + t][c = 32 chunk + 16 ct + (lane & 15)]
+// Scales (all exact powers of two).  The operand of layer l is U_l x_l, its weights are stored as s_l W_l, so the accumulators of layer l ARE
+// the operands of layer l + 1 with U_(l+1) = s_l U_l: no multiply in the hidden epilogues.  The biases of layers 2, 3 are preloaded into the
+// accumulators (U_(l+1) b_l, fp32), the bias of layer 1 rides on the constant-one input channel (internal channel 611) as the weight s_1 b_1.
+// s_l lifts max |W_l| into [1, 2) (weight_scale_exp); U_1 is common to all heads and such that U_4 <= 2^ACT_EXP0 at range level 0; a range level
+// divides every U_l by 2^ACT_LEVEL_SHIFT.
 struct HeadW {
     const uint4 *w1p, *w1c, *w2p, *w2tp, *w3p, *w3tp, *w4p, *w4tp;
-    const float *b1, *b2, *b3, *b4;
-    float cf[4];            // forward epilogue scale: layers 1..3 1 / s_W (output stays in ACT_SCALE units), layer 4 1 / (ACT_SCALE s_W)
-    float cb[4];            // backward epilogue scale: 1 / s_W
+    const float *b2, *b3, *b4;      // U_3 b_2 | U_4 b_3 (operand units of the CURRENT range level) | b_4 (plain)
+    float cout;             // layer-4 output scale 1 / (U_4 s_4) at the current range level
+    float kback;            // backward chain: 1 / (s_1 s_2 s_3 s_4)
+    int goexp;              // exponent of the per-point normalisation of the upstream gradient: GO_EXP - log2(s_4 s_3 s_2), so that d(hidden-1)' has the magnitude it had with unit weight scales
     int kout, id;
     int pcol;               // first column of this head in the hoisted im_feat projection (vt_maps.proj), -1: the head is not in it
 };
@@ -65,7 +73,10 @@ struct vt_sifnet {
     void *blob;             // all weights of the 5 heads
     HeadW head[5];
     float cam[5];
-    float *projw;           // [256 im_feat channels][PROJ_COLS] fp32: ACT_SCALE s_W1 W1[u][c] of the heads df | parts (vt_query_build_projection)
+    float *projw;           // [256 im_feat channels][PROJ_COLS] fp32: s_1 W1[u][c] of the heads df | parts (vt_query_build_projection multiplies by U_1)
+    const float *bias_dev[5];   // per head: [ACT_LEVELS][512] floats: U_3 b_2 (128) | U_4 b_3 (128) | b_4 (16) | pad
+    float cout0[5];         // per head: 1 / (U_4 s_4) at level 0
+    int u1_exp;             // U_1 = 2^u1_exp at range level 0 (common to all heads)
     f32q::Net *f32;         // the same decoders packed for the strict-fp32 kernels (query_f32.hip)
     std::atomic<int> precision;     // VT_PRECISION_SPLIT_F16 (default) | VT_PRECISION_FP32: which kernels serve the vt_query_* calls of this handle
 };
@@ -76,6 +87,7 @@ struct QArgs {
     const float *pts, *crop_center, *body_center;
     int B, N;
     float fx, fy, cx, cy, crop;
+    float u1, u1inv;        // operand scale of the layer-1 input (features, xyz, the constant one) at the range level of the launch, and its inverse
     HeadW hw[2];
     const float *proj; int pw;      // hoisted layer-1 projection of im_feat (B, res0, res0, pw) or NULL
     float *out[2];          // MODE_FWD
@@ -139,7 +151,7 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 // Bilinear sampling, split in two so that nothing is recomputed per chunk:
 //   TapGeom -- per MAP (8 of them over the 19 chunks): the four texel byte offsets (32-bit, inside the frame's map) and the four tap
 //              coefficients of two points per thread (thread = point pp / pp+32, 16-B piece `sub` of a tap row).  Forward (NC = 1):
-//              the bilinear weights x ACT_SCALE; backward (NC = 2): the coefficients of d feat / d u and d feat / d v,
+//              the bilinear weights x U_1 (QArgs::u1); backward (NC = 2): the coefficients of d feat / d u and d feat / d v,
 //              d/du = sc ((ne - nw) wy0 + (se - sw) wy1),  d/dv = sc ((sw - nw) wx0 + (se - ne) wx1), sc = (res - 1) / 2.
 //              Out-of-bounds taps (zeros padding) get coefficient 0 and are loaded from a clamped, valid texel: plain global_load,
 //              no divergent branch, no select between a global and a private address.
@@ -194,7 +206,7 @@ __device__ __forceinline__ void taps_geom(const QArgs &a, int mi, const float *s
         g.o[pass][0] = (r0 + (unsigned)(xc0 * C)) * 4u; g.o[pass][1] = (r0 + (unsigned)(xc1 * C)) * 4u;
         g.o[pass][2] = (r1 + (unsigned)(xc0 * C)) * 4u; g.o[pass][3] = (r1 + (unsigned)(xc1 * C)) * 4u;
         if (NC == 1) {
-            const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
+            const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * a.u1, wy1s = wy1 * a.u1;
             g.c[0][pass][0] = i0 ? wx0 * wy0s : 0.f; g.c[0][pass][1] = i1 ? wx1 * wy0s : 0.f;
             g.c[0][pass][2] = i2 ? wx0 * wy1s : 0.f; g.c[0][pass][3] = i3 ? wx1 * wy1s : 0.f;
         } else {
@@ -229,7 +241,7 @@ __device__ __forceinline__ void geom_compute(const QArgs &a, int mi, const float
     uint4 o = make_uint4((r0 + (unsigned)(xc0 * C)) * 4u, (r0 + (unsigned)(xc1 * C)) * 4u, (r1 + (unsigned)(xc0 * C)) * 4u, (r1 + (unsigned)(xc1 * C)) * 4u);
     float4 c0, c1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (NC == 1) {
-        const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
+        const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * a.u1, wy1s = wy1 * a.u1;
         c0 = make_float4(i0 ? wx0 * wy0s : 0.f, i1 ? wx1 * wy0s : 0.f, i2 ? wx0 * wy1s : 0.f, i3 ? wx1 * wy1s : 0.f);
     } else {
         const float sx1 = wx1 * sc, sy1 = wy1 * sc, sx0 = sc - sx1, sy0 = sc - sy1;
@@ -282,21 +294,8 @@ __device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> 
         hi8[idx] = hi; lo8[idx] = lo;
     }
 }
-// ... or the tap differences d feat / d u, d feat / d v, fp32 rows [pt][TS] (backward): 4 + 4 multiply-adds per channel
-__device__ __forceinline__ void taps_store_grad(const Taps &r, const TapGeom<2> &g, float *bufU, float *bufV, int tid)
-{
-    const int sub = tid & 7, pp = tid >> 3;
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-        const float4 nw = r.t[pass][0], ne = r.t[pass][1], sw = r.t[pass][2], se = r.t[pass][3];
-        const float *cu = g.c[0][pass], *cv = g.c[1][pass];
-        *reinterpret_cast<float4 *>(bufU + (pp + 32 * pass) * TS + sub * 4) = make_float4(TAPSUM_(x, cu), TAPSUM_(y, cu), TAPSUM_(z, cu), TAPSUM_(w, cu));
-        *reinterpret_cast<float4 *>(bufV + (pp + 32 * pass) * TS + sub * 4) = make_float4(TAPSUM_(x, cv), TAPSUM_(y, cv), TAPSUM_(z, cv), TAPSUM_(w, cv));
-    }
-}
-
 // ---- hoisted im_feat projection (USEP): layer 1 is linear in the features and the features are bilinear blends of texels, so
-//      W1 . (sum_t w_t texel_t) = sum_t w_t (W1 . texel_t): the product P = ACT_SCALE s_W1 W1[:, im_feat] . texel of every im_feat texel is
+//      W1 . (sum_t w_t texel_t) = sum_t w_t (W1 . texel_t): the product P = U_1 s_1 W1[:, im_feat] . texel of every im_feat texel is
 //      computed ONCE per batch (vt_query_build_projection; maps and weights do not change over the ~730 Adam steps of a batch) and the
 //      256 im_feat channels -- 8 of the 19 chunks of both layer-1 loops -- become a 4-tap blend of P rows (forward, straight into the
 //      accumulator fragments) and 4 dot products of P rows with d(hidden-1) (backward).  Same bytes gathered as the im_feat taps.
@@ -340,9 +339,6 @@ __device__ __forceinline__ void acc_zero(Acc8 &c)
 #ifndef Q_PRIO
 #define Q_PRIO 0
 #endif
-#ifndef HID_FUSE
-#define HID_FUSE 0     /* interleave head 1 layer-1 epilogue with head 0 layer-2 GEMM inside a wave (gemm128_epi): MEASURED 0.8 % slower, off */
-#endif
 #if Q_PRIO == 1
 #define Q_PRIO_MFMA_BEGIN __builtin_amdgcn_s_setprio(2);
 #define Q_PRIO_MFMA_END __builtin_amdgcn_s_setprio(1);
@@ -375,63 +371,97 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
         for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
     Q_PRIO_MFMA_END
 }
-// scale + bias + ReLU on the D fragments, result left in the ACT_SCALE-d units the next layer's operands use (bias = ACT_SCALE * b,
-// sc = ACT_SCALE * cf); returns the mask of positive pre-activations, bit 31 - ((nt*4 + p)*4 + r)  (shift-in order)
-__device__ __forceinline__ unsigned bias_relu(Acc8 &c, const float *__restrict__ bias, float sc, int wave, int lane)
+// HAZARD RULE of this file: an MFMA accumulator is never read FIRST by inline assembly.  hipcc's hazard recogniser inserts the wait states
+// between a matrix instruction and the VALU read of its result only for instructions it knows; an asm statement that consumed c.v[..] directly
+// read stale registers (measured: garbage outputs).  The first consumers below are builtins (v_cvt_pk_f16_f32 via the vector conversion,
+// v_med3_f32); asm only ever sees their results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, h2)); }      // v_cvt_pk_f16_f32 (RTN)
+// ReLU + split of two pre-activations whose RAW fp16 conversion `hr` is already known: hi = max(hr, 0) (packed, = fp16(max(x, 0)): the conversion is
+// monotone), lo = fp16(y - hi) with y = max(x, 0).  8 VALU instructions per pair with the range tracker (y >= 0: no |.|).
+__device__ __forceinline__ void relu_split2(float x0, float x1, unsigned hr, unsigned &hi, unsigned &lo, float &rmax)
+{
+    // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf is canonicalised first: two per value)
+    const float y0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff()), y1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+    float r0, r1;
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(rmax) : "v"(y0), "v"(y1));
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(hi) : "v"(hr));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(y0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(y1));
+    lo = cvt_pk(r0, r1);
+}
+// sign bytes of the four values of a D fragment (raw conversions hr01, hr23) -> bits 8 r + 7 - f of the mask, f = fragment index 0..7: one byte
+// permute, one rotate, one bit-field insert per FOUR values (the compare + add-with-carry chain this replaces cost two per value)
+template <int F> __device__ __forceinline__ void sign_bits(unsigned &m, unsigned hr01, unsigned hr23)
+{
+    unsigned t;
+    constexpr unsigned K = 0x80808080u >> F;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(t) : "v"(hr23), "v"(hr01), "s"(0x07050301u));     // bytes {x0.hi, x1.hi, x2.hi, x3.hi}: sign in bit 7 of each
+    if (F) asm("v_alignbit_b32 %0, %1, %1, %2" : "=v"(t) : "v"(t), "n"(F));                  // rotate right by F
+    asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(m) : "s"(K), "v"(t));                              // m = (K & t) | (~K & m)
+}
+#define MASK_BIT(f_, r_) (8 * (r_) + 7 - (f_))
+// hidden-layer epilogue, forward: D fragments (bias preloaded, already in the next layer's operand units) -> ReLU -> packed split halves (the plane
+// stores follow after the barrier that retires the planes' readers: planes_store); returns the ACTIVITY mask, bit MASK_BIT(f, r) set <=> the
+// pre-activation's sign bit is clear
+struct Packed8 { uint2 hi[8], lo[8]; };
+__device__ __forceinline__ unsigned relu_pack(const Acc8 &c, Packed8 &pk, float &rmax)
 {
     unsigned m = 0;
-#ifdef HID_ABL      /* TIMING ABLATION (wrong results): no bias / ReLU / mask in the hidden-layer epilogues */
-    return m;
-#endif
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        const float4 bb = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4));
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float x = __builtin_fmaf(c.v[nt][p][r], sc, bv[r]);
-                // m = 2 m + (x > 0): compare into VCC, add-with-carry.  Opaque on purpose: left to itself hipcc keeps the 32 compares
-                // as lane masks, runs out of SGPRs and spills the pre-activations to scratch to redo the compares in the backward.
-                asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
-                c.v[nt][p][r] = fmaxf(x, 0.f);
-            }
+#define RELU_PACK_F(nt_, p_)                                                                                    \
+    {                                                                                                           \
+        const f32x4 x = c.v[nt_][p_];                                                                           \
+        const unsigned h01 = cvt_pk(x[0], x[1]), h23 = cvt_pk(x[2], x[3]);                                      \
+        sign_bits<(nt_) * 4 + (p_)>(m, h01, h23);                                                               \
+        relu_split2(x[0], x[1], h01, pk.hi[(nt_) * 4 + (p_)].x, pk.lo[(nt_) * 4 + (p_)].x, rmax);               \
+        relu_split2(x[2], x[3], h23, pk.hi[(nt_) * 4 + (p_)].y, pk.lo[(nt_) * 4 + (p_)].y, rmax);               \
     }
-    return m;
+    RELU_PACK_F(0, 0) RELU_PACK_F(0, 1) RELU_PACK_F(0, 2) RELU_PACK_F(0, 3)
+    RELU_PACK_F(1, 0) RELU_PACK_F(1, 1) RELU_PACK_F(1, 2) RELU_PACK_F(1, 3)
+#undef RELU_PACK_F
+    return ~m;
 }
-// backward: scale and apply the ReLU mask (bit 31 - k of m belongs to element k)
-__device__ __forceinline__ void scale_mask(Acc8 &c, float sc, unsigned m)
-{
-#ifdef HID_ABL
-    return;
-#endif
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = (nt * 4 + p) * 4 + r;
-                // all ones where the unit was active: ONE signed bit-field extract (left to itself hipcc builds the mask from and + compare +
-                // select: 4 instructions per value with the multiply instead of 3)
-                unsigned keep;
-                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(31 - k));
-                c.v[nt][p][r] = __uint_as_float(__float_as_uint(c.v[nt][p][r] * sc) & keep);
-            }
-}
-// D fragments (already in operand units) -> split planes [16 kb][64 pt][8 halves] (8-B units)
-__device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *lo8, int wave, int lane, float &rmax)
+// packed halves of a wave's 32 hidden units x 64 points -> split planes [16 kb][64 pt][8 halves] (8-B units)
+__device__ __forceinline__ void planes_store(const Packed8 &pk, uint2 *hi8, uint2 *lo8, int wave, int lane)
 {
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            uint2 hi, lo;
-            split4(c.v[nt][p][0], c.v[nt][p][1], c.v[nt][p][2], c.v[nt][p][3], hi, lo, rmax);
             const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
-            hi8[idx] = hi; lo8[idx] = lo;
+            hi8[idx] = pk.hi[nt * 4 + p]; lo8[idx] = pk.lo[nt * 4 + p];
+        }
+}
+// split without the range tracker (backward chain: a non-finite gradient is loud by itself, nothing downstream rectifies it away)
+__device__ __forceinline__ void split2_nr(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    float r0, r1;
+    hi = cvt_pk(x0, x1);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    lo = cvt_pk(r0, r1);
+}
+// hidden-layer epilogue, backward: ReLU mask (one signed bit-field extract + and per value; the accumulators already carry the scale of the
+// chain, HeadW::kback undoes it at the very end) and split; the stores follow with planes_store
+__device__ __forceinline__ void mask_pack(const Acc8 &c, unsigned m, Packed8 &pk)
+{
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#ifdef HID_ABL      /* TIMING ABLATION (wrong results): no mask in the backward hidden-layer epilogues */
+                y[r] = c.v[nt][p][r];
+#else
+                unsigned keep;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(MASK_BIT(nt * 4 + p, r)));
+                y[r] = __uint_as_float(__float_as_uint(c.v[nt][p][r]) & keep);
+#endif
+            }
+            split2_nr(y[0], y[1], pk.hi[nt * 4 + p].x, pk.lo[nt * 4 + p].x); split2_nr(y[2], y[3], pk.hi[nt * 4 + p].y, pk.lo[nt * 4 + p].y);
         }
 }
 // out[32 rows of this wave][64 pts] = M[128 x 128] (A, T-pack fragments from L2) x X[128 x 64 pts] (B, LDS planes), K = 128.
@@ -439,9 +469,13 @@ __device__ __forceinline__ void store_planes(const Acc8 &c, uint2 *hi8, uint2 *l
 #ifndef WPF_BUF
 #define WPF_BUF 0     /* hidden-layer weight fragments as buffer loads: measured 0.5 % SLOWER than the saddr global form the compiler already finds there */
 #endif
-struct WPre { uint4 v[4][2][2]; };
-__device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp, int wave, int lane)
+struct WPre { uint4 v[4][2][2]; float4 bias[2]; };
+__device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp, int wave, int lane, const float *__restrict__ bias = nullptr)
 {
+    // bias (operand units of the layer's OUTPUT, or NULL for the bias-free backward GEMMs): the accumulators start from it
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+        p.bias[nt] = bias ? *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
     const rsrc_t wr = make_rsrc(Wp, 4u * 1024u * 16u);          // [4 K32 steps][4 waves][2 nt][hi|lo][64 lanes] uint4
 #pragma unroll
     for (int s = 0; s < 4; s++)
@@ -456,79 +490,12 @@ __device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp,
 }
 __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
 {
-    acc_zero(c);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) c.v[nt][pp] = (f32x4){p.bias[nt].x, p.bias[nt].y, p.bias[nt].z, p.bias[nt].w};
 #pragma unroll
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
-}
-
-// ---- a hidden-layer GEMM of one head with the epilogue of ANOTHER fragment set in its shadow -------------------------------------------------
-// The 96 MFMAs of gemm128 keep the matrix pipe busy 16 cycles each but need only 4 issue cycles; the epilogue of a layer (bias, ReLU, mask bit,
-// split, plane store: 6.5 VALU instructions per value) has nothing to do with them when it belongs to the OTHER head.  Source order = schedule:
-// after every 6 MFMAs one pair-step of the epilogue (2 values = ~13 VALU instructions), fenced with sched_barrier(0) so that hipcc neither clusters
-// the MFMAs nor sinks the VALU work behind them.  EPI_FWD: x = fma(e, sc, bias) -> mask bit -> ReLU; EPI_BWD: x = e * sc masked with bit k of `m`.
-struct EpiArgs { const float *bias; float sc; unsigned m; uint2 *hi8, *lo8; };
-template <bool FWD>
-__device__ __forceinline__ void epi_pair(Acc8 &e, int k, EpiArgs &ea, float (&bv)[2][4], uint2 &hi, uint2 &lo, int wave, int lane, float &rmax)
-{
-    // pair k = fragment (nt, p) = k >> 1, values r = 2 (k & 1), 2 (k & 1) + 1
-    const int f = k >> 1, nt = f >> 2, p = f & 3, r0 = 2 * (k & 1);
-    float y[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int r = r0 + t;
-        if (FWD) {
-            const float x = __builtin_fmaf(e.v[nt][p][r], ea.sc, bv[nt][r]);
-            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ea.m) : "v"(x) : "vcc");      // m = 2 m + (x > 0), see bias_relu
-            y[t] = fmaxf(x, 0.f);
-        } else {
-            const int kk = f * 4 + r;
-            const unsigned keep = (unsigned)((int)(ea.m << kk) >> 31);
-            y[t] = __uint_as_float(__float_as_uint(e.v[nt][p][r] * ea.sc) & keep);
-        }
-    }
-    if ((k & 1) == 0) split2(y[0], y[1], hi.x, lo.x, rmax);
-    else {
-        split2(y[0], y[1], hi.y, lo.y, rmax);
-        const int q = lane >> 4, j = lane & 15;
-        const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
-        ea.hi8[idx] = hi; ea.lo8[idx] = lo;
-    }
-}
-template <bool FWD>
-__device__ __forceinline__ void gemm128_epi(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &w, Acc8 &e, EpiArgs &ea, int wave, int lane, float &rmax)
-{
-    const int q = lane >> 4, j = lane & 15;
-    float bv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (FWD) {
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const float4 bb = *reinterpret_cast<const float4 *>(ea.bias + 32 * wave + 16 * nt + 4 * q);
-            bv[nt][0] = bb.x; bv[nt][1] = bb.y; bv[nt][2] = bb.z; bv[nt][3] = bb.w;
-        }
-    }
-    acc_zero(c);
-    uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        h8 xh[4], xl[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[(4 * s + q) * 64 + 16 * p + j]); xl[p] = as_h8(Xlo[(4 * s + q) * 64 + 16 * p + j]); }
-#pragma unroll
-        for (int ph = 0; ph < 3; ph++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-                    c.v[nt][p] = MFMAH(as_h8(w.v[s][nt][ph == 2 ? 1 : 0]), ph == 1 ? xl[p] : xh[p], c.v[nt][p]);
-                // 4 MFMAs issued; after every 6th (= every 1.5 of these groups) one pair-step: pairs 4 s .. 4 s + 3 over the 24 MFMAs of step s
-                if ((ph * 2 + nt) == 1 || (ph * 2 + nt) == 2 || (ph * 2 + nt) == 4 || (ph * 2 + nt) == 5) {
-                    const int kq = (ph * 2 + nt) == 1 ? 0 : ((ph * 2 + nt) == 2 ? 1 : ((ph * 2 + nt) == 4 ? 2 : 3));
-                    __builtin_amdgcn_sched_barrier(0);
-                    epi_pair<FWD>(e, 4 * s + kq, ea, bv, hi, lo, wave, lane, rmax);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-    }
 }
 
 // Compile-time interleave of the MFMAs of one chunk with the independent VALU work of the next (blend / split of the taps): left to itself
@@ -725,7 +692,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
             if (q == 0) {
                 const float *pp = sPt + (16 * p + j) * 3;
-                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo, rmax);
+                split4(pp[0] * a.u1, pp[1] * a.u1, (pp[2] - 2.2f) * a.u1, a.u1, hi, lo, rmax);       // 4th channel = the constant one (weight s_1 b_1)
             }
             xh[p] = make_uint4(hi.x, hi.y, 0u, 0u); xl[p] = make_uint4(lo.x, lo.y, 0u, 0u);
         }
@@ -745,12 +712,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     PCLK(1);
     __syncthreads();        // region 0 changes role: chunk buffers -> hidden-activation planes
     // hidden-1 activations of ALL heads go to their planes right away: no head's layer-1 accumulators stay live in registers
-    // while another head runs its layers 2..4 and backward
+    // while another head runs its layers 2..4 and backward.  The layer-1 bias came in through the constant-one channel of the xyz step.
     unsigned m1s[G];
 #pragma unroll
-    for (int g = 0; g < (HID_FUSE && G == 2 ? 1 : G); g++) {
-        m1s[g] = bias_relu(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave, lane);
-        store_planes(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane, rmax); OVF_PUBLISH();
+    for (int g = 0; g < G; g++) {
+        Packed8 pk;
+        m1s[g] = relu_pack(acc1[g], pk, rmax);
+        planes_store(pk, reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane); OVF_PUBLISH();
     }
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
@@ -762,27 +730,20 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         uint2 *Hhi8 = reinterpret_cast<uint2 *>(Hhi), *Hlo8 = reinterpret_cast<uint2 *>(Hlo);
         Acc8 c;
         WPre wp;
-        wprefetch(wp, hw.w2p, wave, lane);
+        Packed8 pk;
+        wprefetch(wp, hw.w2p, wave, lane, hw.b2);
         const unsigned m1 = m1s[g];
         if (g == 0) __syncthreads();           // hidden-1 planes of all heads visible
-        if (HID_FUSE && G == 2 && g == 0) {
-            // layer 2 of head 0 on the matrix pipe WHILE the VALU does the layer-1 epilogue of head 1 (bias, ReLU, mask, split, plane stores): two
-            // independent instruction streams of ONE wave, interleaved 1 MFMA : 3 VALU (an MFMA occupies its pipe 16 cycles, issues in 4)
-            EpiArgs ea = {a.hw[G - 1].b1, a.hw[G - 1].cf[0], 0u, reinterpret_cast<uint2 *>(Hp + (G - 1) * 2048), reinterpret_cast<uint2 *>(Hp + (G - 1) * 2048 + 1024)};
-            gemm128_epi<true>(c, Hhi, Hlo, wp, acc1[G - 1], ea, wave, lane, rmax);
-            m1s[G - 1] = ea.m;
-            OVF_PUBLISH();
-        } else
-            gemm128(c, Hhi, Hlo, wp, lane);
-        wprefetch(wp, hw.w3p, wave, lane);
-        const unsigned m2 = bias_relu(c, hw.b2, hw.cf[1], wave, lane);
+        gemm128(c, Hhi, Hlo, wp, lane);
+        wprefetch(wp, hw.w3p, wave, lane, hw.b3);
+        const unsigned m2 = relu_pack(c, pk, rmax);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
+        planes_store(pk, Hhi8, Hlo8, wave, lane); OVF_PUBLISH();
         __syncthreads();
         gemm128(c, Hhi, Hlo, wp, lane);
-        const unsigned m3 = bias_relu(c, hw.b3, hw.cf[2], wave, lane);
+        const unsigned m3 = relu_pack(c, pk, rmax);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
+        planes_store(pk, Hhi8, Hlo8, wave, lane); OVF_PUBLISH();
         __syncthreads();
         // layer 4 (points as rows): wave w owns the 16 points of tile w, columns = up to 16 outputs (zero padded)
         f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -800,7 +761,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             const bool valid = n < a.N, live = j < hw.kout;
             const bool inimg = (sIn[pt] & 1) != 0;
             const int pn = sIn[pt] >> 1;
-            float val = o4[r] * hw.cf[3] + bias4;
+            float val = o4[r] * hw.cout + bias4;
             if (*sOvf) val = __builtin_nanf("");        // an operand left the split range: no silent finite garbage
             go[r] = 0.f;
             if (MODE == MODE_FWD) {
@@ -854,9 +815,10 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         for (int r = 0; r < 4; r++) {
             const float m = row16_max(fabsf(go[r]));
             const int eb = (int)((__float_as_uint(m) >> 23) & 255u);
-            const bool ok = eb >= GO_EXP + 2 && eb < 255;       // zero / denormal-sized / non-finite gradients pass unscaled
-            const float s = ok ? __uint_as_float((unsigned)(254 + GO_EXP - eb) << 23) : 1.0f;
-            const float inv = ok ? __uint_as_float((unsigned)(eb - GO_EXP) << 23) : 1.0f;
+            const int ge = hw.goexp;                            // go' in [2^ge, 2^(ge+1)): the weight scales s_4 s_3 s_2 of the chain are taken out in advance
+            const bool ok = eb >= ge + 2 && eb >= 2 && eb < 255 && eb - ge < 254;      // zero / denormal-sized / non-finite gradients pass unscaled
+            const float s = ok ? __uint_as_float((unsigned)(254 + ge - eb) << 23) : 1.0f;
+            const float inv = ok ? __uint_as_float((unsigned)(eb - ge) << 23) : 1.0f;
             const int pt = wave * 16 + q * 4 + r;
             if (j == 0) sInv[g * 64 + pt] = inv;
             const float x = go[r] * s;
@@ -890,19 +852,19 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
                 }
         }
-        scale_mask(c, hw.cb[3], m3);
-        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
+        mask_pack(c, m3, pk);
+        planes_store(pk, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g2 = W3^T . g3
         wprefetch(wq, hw.w2tp, wave, lane);
-        scale_mask(c, hw.cb[2], m2);
+        mask_pack(c, m2, pk);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();
+        planes_store(pk, Hhi8, Hlo8, wave, lane);
         __syncthreads();
         gemm128(c, Hhi, Hlo, wq, lane);            // g1 = W2^T . g2
-        scale_mask(c, hw.cb[1], m1);
+        mask_pack(c, m1, pk);
         __syncthreads();
-        store_planes(c, Hhi8, Hlo8, wave, lane, rmax); OVF_PUBLISH();   // the planes now hold d loss' / d (pre-activation 1) of this head
+        planes_store(pk, Hhi8, Hlo8, wave, lane);   // the planes now hold d loss' / d (pre-activation 1) of this head (times the chain's scale)
         __syncthreads();
     }
 
@@ -937,7 +899,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             dh[g][s][0] = Hp[g * 2048 + (4 * s + q) * 64 + 16 * wave + j];
             dh[g][s][1] = Hp[g * 2048 + 1024 + (4 * s + q) * 64 + 16 * wave + j];
         }
-        kscale[g] = sInv[g * 64 + 16 * wave + j] * a.hw[g].cb[0];
+        kscale[g] = sInv[g * 64 + 16 * wave + j] * a.hw[g].kback;
     }
     const int mypt = 16 * wave + j;
     const float px_ = sPt[mypt * 3], py_ = sPt[mypt * 3 + 1], iz_ = 1.0f / sPt[mypt * 3 + 2];
@@ -981,7 +943,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     const h8 hh = as_h8(xh[ii]), hl = as_h8(xl[ii]);
                     float x[8];
 #pragma unroll
-                    for (int t = 0; t < 8; t++) x[t] = (float)hh[t] + (float)hl[t];
+                    for (int t = 0; t < 8; t++) x[t] = __builtin_fmaf((float)hh[t], 1.0f, (float)hl[t]);     // hi + lo: one v_fma_mix_f32 per value (both halves extended inside the fma)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float4 p0 = pr[ii][k][0], p1 = pr[ii][k][1];
@@ -990,7 +952,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     }
                 }
             }
-            const float ks = sInv[g * 64 + spt] * a.hw[g].cb[0] * (1.0f / ACT_SCALE);
+            const float ks = sInv[g * 64 + spt] * a.hw[g].kback * a.u1inv;
 #pragma unroll
             for (int k = 0; k < 4; k++) dot[k] = __builtin_fmaf(ks, dg[k], dot[k]);
         }
@@ -1007,10 +969,16 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         if (SHGEO && wave == 0) geom_compute<2>(a, mi, sUV, lane, sGeo);
         if (SHGEO && wave == 1 && mi + 1 < 8) geom_compute<2>(a, mi + 1, sUV, lane, sGeo);
     }
-    __syncthreads();        // region 0 changes role again: activation planes -> tap-difference buffers + weight slab
+    __syncthreads();        // region 0 changes role again: activation planes -> d(feature) rows + weight slab
     // Every wave needs the whole weight slab of a chunk (the waves split the POINTS here): the workgroup stages it once
     // in LDS with the asynchronous global->LDS DMA (16 B per lane, lane-linear destination = the fragment order), no VGPRs.
-    float *bu = reinterpret_cast<float *>(lds), *bv = bu + 64 * TS;      // tap differences of the current chunk
+    //
+    // The chunk's contribution to the coordinate gradient is  sum_c d feat[c] (d f_c / d u) = sum_t cu_t <d feat, texel_t>  (and cv for v): FOUR dot
+    // products of d feat with the raw tap rows per (point, chunk) -- 4 multiply-adds per channel -- instead of blending the taps to d f / d u and
+    // d f / d v first (8 per channel) and contracting afterwards (2 more).  The dot products run in the gather layout (thread = 16-byte piece `sub`
+    // of the taps of points pp, pp + 32), so d feat goes through LDS once ([point][32 channels] fp32, half the bytes the two tap-difference
+    // buffers took) and the partial sums of a map's chunks stay in registers until the map ends (one 8-lane DPP reduction per map).
+    float *sD = reinterpret_cast<float *>(lds);                          // [64 points][TS] d feat of the current chunk
     uint4 *Sl = lds + 1152;                                              // [G][4 s][2 ct][hi|lo][64 lanes]
 #define SLAB_DMA(ci_)                                                                                                        \
     _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                                                         \
@@ -1022,6 +990,14 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     { int mi, co; chunk_info(C0, mi, co); if (SHGEO) geom_fetch<2>(mi, sGeo, tid, tgb); else taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
     __syncthreads();
     PCLK(3);
+    const int gsub = tid & 7, gpp = tid >> 3;                            // gather role: piece gsub of the taps of points gpp, gpp + 32
+    float Dt[2][4];                                                      // <d feat, texel_t> of the current MAP, this thread's channels
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) Dt[pass][k] = 0.f;
+    float hx[2] = {0.f, 0.f}, hy[2] = {0.f, 0.f}, hz[2] = {0.f, 0.f};    // coordinate gradient of points gpp, gpp + 32 from the orthographic maps, this thread's channels
+    float hp[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                           // (su, sv) of the perspective maps
     for (int ci = C0; ci < NCHUNK; ci++) {
         int mi, co; chunk_info(ci, mi, co);
         f32x4 dd[G][2];
@@ -1045,23 +1021,52 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #pragma unroll
             for (int g = 0; g < G; g++) { dd[g][0] = MFMAH(wl[g][0], xh[g], dd[g][0]); dd[g][1] = MFMAH(wl[g][1], xh[g], dd[g][1]); }
         }
-        taps_store_grad(tp, tgb, bu, bv, tid);
-        SCHED_MFMA_VALU(24 * G, 2)
-        __syncthreads();                                   // slab(ci) fully consumed, tap differences of chunk ci visible
-        // read this point's tap differences FIRST, then start the DMA of the next slab: hipcc orders an LDS read after an LDS-DMA
-        // with a full vmcnt(0) wait (they may alias), which put the whole DMA latency in front of the epilogue
-        float4 u4[2], v4[2];
+        // d feat of point mypt, channels 16 ct + 4 q .. +3 (true scale: the per-point normalisation and the chain's weight scales undone)
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
-            u4[ct] = *reinterpret_cast<const float4 *>(bu + mypt * TS + 16 * ct + 4 * q);
-            v4[ct] = *reinterpret_cast<const float4 *>(bv + mypt * TS + 16 * ct + 4 * q);
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] = __builtin_fmaf(dd[G - 1][ct][r], kscale[G - 1], d[r]); }
+            *reinterpret_cast<float4 *>(sD + mypt * TS + 16 * ct + 4 * q) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+        __syncthreads();                                   // slab(ci) fully consumed, d feat of chunk ci visible
+        // read this thread's d feat FIRST, then start the DMA of the next slab: hipcc orders an LDS read after an LDS-DMA
+        // with a full vmcnt(0) wait (they may alias), which put the whole DMA latency in front of the dot products
+        float4 d4[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) d4[pass] = *reinterpret_cast<const float4 *>(sD + (gpp + 32 * pass) * TS + 4 * gsub);
+        if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) asm volatile("" ::: "memory"); }
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 t = tp.t[pass][k];
+                Dt[pass][k] = __builtin_fmaf(d4[pass].w, t.w, __builtin_fmaf(d4[pass].z, t.z, __builtin_fmaf(d4[pass].y, t.y, __builtin_fmaf(d4[pass].x, t.x, Dt[pass][k]))));
+            }
+        int m2i = -1, c2o = 0;
+        if (ci + 1 < NCHUNK) chunk_info(ci + 1, m2i, c2o);
+        if (c2o == 0) {
+            // the map ends with this chunk (uniform branch): apply the tap coefficients to this thread's PARTIAL dot products (everything is linear,
+            // the sum over the 8 pieces of a tap row waits until after the loop) and the projection Jacobians (camera.py:52-90;
+            // chore_triplane.py:220-251):  right (u, v) = (c2, c1): gz += su, gy += sv;  back (-c0, c1): gx -= su, gy += sv;  top (c0, -c2): gx += su,
+            // gz -= sv;  perspective maps collect (su, sv) and take their per-point Jacobian at the end
+            const int pr = map_proj(mi);
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                float su = tgb.c[0][pass][0] * Dt[pass][0], sv = tgb.c[1][pass][0] * Dt[pass][0];
+#pragma unroll
+                for (int k = 1; k < 4; k++) { su = __builtin_fmaf(tgb.c[0][pass][k], Dt[pass][k], su); sv = __builtin_fmaf(tgb.c[1][pass][k], Dt[pass][k], sv); }
+#pragma unroll
+                for (int k = 0; k < 4; k++) Dt[pass][k] = 0.f;
+                if (pr == 0) { hp[pass][0] += su; hp[pass][1] += sv; }
+                else if (pr == 1) { hz[pass] += su; hy[pass] += sv; }
+                else if (pr == 2) { hx[pass] -= su; hy[pass] += sv; }
+                else { hx[pass] += su; hz[pass] -= sv; }
+            }
         }
         if (ci + 1 < NCHUNK) {
-            SLAB_DMA(ci + 1)
             // taps of chunk ci+1 AFTER the DMA (vmcnt retires in order): the barrier below then waits for the slab only, the gather
             // stays in flight across it
-            asm volatile("" ::: "memory");
-            int m2i, c2o; chunk_info(ci + 1, m2i, c2o);
             if (c2o == 0) {         // see the forward loop: fetch this map's slot, one wave refills the other with the next map
                 if (SHGEO) {
                     geom_fetch<2>(m2i, sGeo, tid, tgb);
@@ -1070,27 +1075,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                     taps_geom(a, m2i, sUV, tid, tgb);
             }
             taps_issue(a, b, m2i, c2o, tgb, tp);
-        }
-        float su = 0.f, sv = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) {
-            float d[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) { d[r] = dd[0][ct][r] * kscale[0]; if (G == 2) d[r] = __builtin_fmaf(dd[G - 1][ct][r], kscale[G - 1], d[r]); }
-            su = __builtin_fmaf(d[3], u4[ct].w, __builtin_fmaf(d[2], u4[ct].z, __builtin_fmaf(d[1], u4[ct].y, __builtin_fmaf(d[0], u4[ct].x, su))));
-            sv = __builtin_fmaf(d[3], v4[ct].w, __builtin_fmaf(d[2], v4[ct].z, __builtin_fmaf(d[1], v4[ct].y, __builtin_fmaf(d[0], v4[ct].x, sv))));
-        }
-        // projection Jacobians (camera.py:52-90; chore_triplane.py:220-251), branch-free: the chunk's projection picks the
-        // coefficients of  gx += su cxu,  gy += sv cyv,  gz += su czu + sv czv
-        //   perspective: (kx/z, ky/z, -kx x/z^2, -ky y/z^2)   right (c2, c1): (0, 1, 1, 0)   back (-c0, c1): (-1, 1, 0, 0)   top (c0, -c2): (1, 0, 0, -1)
-        const int pr = map_proj(mi);
-        const float cxu = pr == 0 ? j0x : (pr == 2 ? -1.f : (pr == 3 ? 1.f : 0.f));
-        const float cyv = pr == 0 ? j0y : (pr == 3 ? 0.f : 1.f);
-        const float czu = pr == 0 ? j0zu : (pr == 1 ? 1.f : 0.f);
-        const float czv = pr == 0 ? j0zv : (pr == 3 ? -1.f : 0.f);
-        gx = __builtin_fmaf(su, cxu, gx); gy = __builtin_fmaf(sv, cyv, gy); gz = __builtin_fmaf(sv, czv, __builtin_fmaf(su, czu, gz));
-        if (ci + 1 < NCHUNK) {
-            // slab(ci+1) landed, tap buffers free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
+            // slab(ci+1) landed, the d feat rows free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
             // 8 tap loads just issued; the DMA pieces are older than those, so "at most 8 outstanding" means the slab is in LDS.
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1099,6 +1084,22 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     }
 #undef SLAB_DMA
     PCLK(4);
+    // the gathered-map part: perspective Jacobian (kx/z, ky/z, -kx x/z^2, -ky y/z^2), sum over the 8 pieces of a tap row (xor 1, xor 2 inside the quad,
+    // then the half-row mirror), hand-over from the gather layout (piece 0 of points gpp, gpp + 32) to the owner lanes (q == 0: point mypt)
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const float *pp3 = sPt + (gpp + 32 * pass) * 3;
+        const float iz = 1.0f / pp3[2];
+        float vx = __builtin_fmaf(hp[pass][0], kx * iz, hx[pass]), vy = __builtin_fmaf(hp[pass][1], ky * iz, hy[pass]);
+        float vz = __builtin_fmaf(hp[pass][1], -ky * pp3[1] * iz * iz, __builtin_fmaf(hp[pass][0], -kx * pp3[0] * iz * iz, hz[pass]));
+        vx += dpp_mov<0xB1>(vx); vy += dpp_mov<0xB1>(vy); vz += dpp_mov<0xB1>(vz);
+        vx += dpp_mov<0x4E>(vx); vy += dpp_mov<0x4E>(vy); vz += dpp_mov<0x4E>(vz);
+        vx += dpp_mov<0x141>(vx); vy += dpp_mov<0x141>(vy); vz += dpp_mov<0x141>(vz);
+        if (gsub == 0) { float *o = sD + (gpp + 32 * pass) * 4; o[0] = vx; o[1] = vy; o[2] = vz; }
+    }
+    __syncthreads();
+    if (q == 0) { gx += sD[mypt * 4]; gy += sD[mypt * 4 + 1]; gz += sD[mypt * 4 + 2]; }
     {   // direct xyz features: d feat[608..610]: "chunk" 19 of the slab array, rows 0..2 of its first 16-row tile, straight from L2
         f32x4 dz[G];
 #pragma unroll
@@ -1117,9 +1118,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             for (int g = 0; g < G; g++) { gx += dz[g][0] * kscale[g]; gy += dz[g][1] * kscale[g]; gz += dz[g][2] * kscale[g]; }
         }
     }
-    // reduce the channel partials over the 4 lane groups q that share a point
-    gx += __shfl_xor(gx, 16, 64); gy += __shfl_xor(gy, 16, 64); gz += __shfl_xor(gz, 16, 64);
-    gx += __shfl_xor(gx, 32, 64); gy += __shfl_xor(gy, 32, 64); gz += __shfl_xor(gz, 32, 64);
+    // (all three parts -- hoisted projection, gathered maps, xyz -- were accumulated by the owner lane q == 0 of the point)
     if (*sOvf) gx = gy = gz = __builtin_nanf("");
     if (q == 0) {
         const int n = n0 + mypt;
@@ -1172,9 +1171,9 @@ __device__ __forceinline__ constexpr int w8_chan(int mi) { return mi == 0 ? 256 
 __device__ __forceinline__ constexpr int w8_proj(int mi) { return mi < 2 ? 0 : (mi < 5 ? mi - 1 : mi - 4); }
 
 // texel byte offsets (o) and tap coefficients (c) of one point in a map of resolution R with C channels, for the 16-byte piece `sub`
-// (same arithmetic as taps_geom; NC = 1: bilinear weights x ACT_SCALE, NC = 2: d/du and d/dv coefficients)
+// (same arithmetic as taps_geom; NC = 1: bilinear weights x U_1, NC = 2: d/du and d/dv coefficients)
 template <int NC, bool WANT_O, bool WANT_C>
-__device__ __forceinline__ void tap1_geom(int R, int C, float u, float v, int sub, unsigned (&o)[4], float (&c)[NC][4])
+__device__ __forceinline__ void tap1_geom(int R, int C, float u, float v, int sub, unsigned (&o)[4], float (&c)[NC][4], float u1 = 0.f)
 {
     const float sc = 0.5f * (float)(R - 1);
     float ix = (u + 1.0f) * 0.5f * (float)(R - 1), iy = (v + 1.0f) * 0.5f * (float)(R - 1);
@@ -1192,7 +1191,7 @@ __device__ __forceinline__ void tap1_geom(int R, int C, float u, float v, int su
         const bool bx0 = x0 >= 0 && x0 < R, bx1 = x1 >= 0 && x1 < R, by0 = y0 >= 0 && y0 < R, by1 = y1 >= 0 && y1 < R;
         const bool i0 = bx0 && by0, i1 = bx1 && by0, i2 = bx0 && by1, i3 = bx1 && by1;
         if (NC == 1) {
-            const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * ACT_SCALE, wy1s = wy1 * ACT_SCALE;
+            const float wx0 = 1.0f - wx1, wy0s = (1.0f - wy1) * u1, wy1s = wy1 * u1;
             c[0][0] = i0 ? wx0 * wy0s : 0.f; c[0][1] = i1 ? wx1 * wy0s : 0.f; c[0][2] = i2 ? wx0 * wy1s : 0.f; c[0][3] = i3 ? wx1 * wy1s : 0.f;
         } else {
             const float sx1 = wx1 * sc, sy1 = wy1 * sc, sx0 = sc - sx1, sy0 = sc - sy1;
@@ -1239,49 +1238,51 @@ __device__ __forceinline__ void k32_step8(Acc4 (&c)[G], const uint4 (&w)[G][2], 
 #pragma unroll
         for (int p = 0; p < 4; p++) c[g].v[p] = MFMAH(as_h8(w[g][1]), xh[p], c[g].v[p]);
 }
-// bias + ReLU of a thin wave's fragments (hidden units 16 wave8 + 4 q + r); mask bit 15 - (4 p + r)
-__device__ __forceinline__ unsigned bias_relu8(Acc4 &c, const float *__restrict__ bias, float sc, int wave8, int lane)
+// thin-wave forms of relu_pack / mask_pack / planes_store (hidden units 16 wave8 + 4 q + r; mask bit MASK_BIT(p, r))
+struct Packed4 { uint2 hi[4], lo[4]; };
+__device__ __forceinline__ unsigned relu_pack4(const Acc4 &c, Packed4 &pk, float &rmax)
 {
     unsigned m = 0;
-    const float4 bb = *reinterpret_cast<const float4 *>(bias + 16 * wave8 + 4 * (lane >> 4));
-    const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float x = __builtin_fmaf(c.v[p][r], sc, bv[r]);
-            asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
-            c.v[p][r] = fmaxf(x, 0.f);
-        }
-    return m;
+#define RELU_PACK4_F(p_)                                                                                        \
+    {                                                                                                           \
+        const f32x4 x = c.v[p_];                                                                                \
+        const unsigned h01 = cvt_pk(x[0], x[1]), h23 = cvt_pk(x[2], x[3]);                                      \
+        sign_bits<(p_)>(m, h01, h23);                                                                           \
+        relu_split2(x[0], x[1], h01, pk.hi[p_].x, pk.lo[p_].x, rmax); relu_split2(x[2], x[3], h23, pk.hi[p_].y, pk.lo[p_].y, rmax); \
+    }
+    RELU_PACK4_F(0) RELU_PACK4_F(1) RELU_PACK4_F(2) RELU_PACK4_F(3)
+#undef RELU_PACK4_F
+    return ~m;
 }
-__device__ __forceinline__ void scale_mask8(Acc4 &c, float sc, unsigned m)
+__device__ __forceinline__ void mask_pack4(const Acc4 &c, unsigned m, Packed4 &pk)
 {
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int p = 0; p < 4; p++) {
+        float y[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int k = 16 + p * 4 + r;
-            const unsigned keep = (unsigned)((int)(m << k) >> 31);
-            c.v[p][r] = __uint_as_float(__float_as_uint(c.v[p][r] * sc) & keep);
+            unsigned keep;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(MASK_BIT(p, r)));
+            y[r] = __uint_as_float(__float_as_uint(c.v[p][r]) & keep);
         }
+        split2_nr(y[0], y[1], pk.hi[p].x, pk.lo[p].x); split2_nr(y[2], y[3], pk.hi[p].y, pk.lo[p].y);
+    }
 }
-// thin-wave D fragments -> split planes [16 kb][64 pt][8 halves]: hidden unit 16 wave8 + 4 q + r -> kb = 2 wave8 + (q >> 1), half (q & 1)
-__device__ __forceinline__ void store_planes8(const Acc4 &c, uint2 *hi8, uint2 *lo8, int wave8, int lane, float &rmax)
+// thin-wave halves -> split planes [16 kb][64 pt][8 halves]: hidden unit 16 wave8 + 4 q + r -> kb = 2 wave8 + (q >> 1), half (q & 1)
+__device__ __forceinline__ void planes_store8(const Packed4 &pk, uint2 *hi8, uint2 *lo8, int wave8, int lane)
 {
     const int q = lane >> 4, j = lane & 15;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        uint2 hi, lo;
-        split4(c.v[p][0], c.v[p][1], c.v[p][2], c.v[p][3], hi, lo, rmax);
         const int idx = (((2 * wave8 + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
-        hi8[idx] = hi; lo8[idx] = lo;
+        hi8[idx] = pk.hi[p]; lo8[idx] = pk.lo[p];
     }
 }
 // T-pack fragments of a thin wave: [K/32 steps][8 waves][hi|lo][64 lanes] (the 256-thread layout [4 waves][2 nt] read as wave8 = 2 wave + nt)
-struct WPre8 { uint4 v[4][2]; };
-__device__ __forceinline__ void wprefetch8(WPre8 &p, const uint4 *__restrict__ Wp, int wave8, int lane)
+struct WPre8 { uint4 v[4][2]; float4 bias; };
+__device__ __forceinline__ void wprefetch8(WPre8 &p, const uint4 *__restrict__ Wp, int wave8, int lane, const float *__restrict__ bias = nullptr)
 {
+    p.bias = bias ? *reinterpret_cast<const float4 *>(bias + 16 * wave8 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -1291,7 +1292,9 @@ template <int G>
 __device__ __forceinline__ void gemm128x(Acc4 (&c)[G], const uint4 *Hp, const WPre8 (&p)[G], int lane)
 {
 #pragma unroll
-    for (int g = 0; g < G; g++) acc4_zero(c[g]);
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) c[g].v[pp] = (f32x4){p[g].bias.x, p[g].bias.y, p[g].bias.z, p[g].bias.w};
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         // the heads have separate activation planes: one B-fragment read per head
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     {                                                                                                                \
         const int mi_ = w8_map(ci_);                                                                                 \
         unsigned o_[4]; float c_[1][4];                                                                              \
-        tap1_geom<1, false, true>(a.res[mi_], w8_chan(mi_), uv[w8_proj(mi_)][0], uv[w8_proj(mi_)][1], sub, o_, c_);  \
+        tap1_geom<1, false, true>(a.res[mi_], w8_chan(mi_), uv[w8_proj(mi_)][0], uv[w8_proj(mi_)][1], sub, o_, c_, a.u1); \
         const Taps1 &r = tp[((ci_) - C0) % W8_PD];                                                                   \
         uint2 hi_, lo_;                                                                                              \
         split4(TAP1SUM_(x, c_[0]), TAP1SUM_(y, c_[0]), TAP1SUM_(z, c_[0]), TAP1SUM_(w, c_[0]), hi_, lo_, rmax);            \
@@ -1430,7 +1433,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             uint2 hi = make_uint2(0u, 0u), lo = make_uint2(0u, 0u);
             if (q == 0) {
                 const float *pp = sPt + (16 * p + j) * 3;
-                split4(pp[0] * ACT_SCALE, pp[1] * ACT_SCALE, (pp[2] - 2.2f) * ACT_SCALE, 0.f, hi, lo, rmax);
+                split4(pp[0] * a.u1, pp[1] * a.u1, (pp[2] - 2.2f) * a.u1, a.u1, hi, lo, rmax);       // 4th channel = the constant one (weight s_1 b_1)
             }
             const h8 xh = as_h8(make_uint4(hi.x, hi.y, 0u, 0u)), xl = as_h8(make_uint4(lo.x, lo.y, 0u, 0u));
 #pragma unroll
@@ -1446,13 +1449,15 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     PCLK(2);
     WPre8 wp[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) wprefetch8(wp[g], a.hw[g].w2p, wave8, lane);
+    for (int g = 0; g < G; g++) wprefetch8(wp[g], a.hw[g].w2p, wave8, lane, a.hw[g].b2);
     __syncthreads();        // region 0 changes role: chunk slots -> hidden-activation planes
     unsigned m1[G], m2[G], m3[G];
+    Packed4 pk[G];
+#define W8_PLANES(g_) reinterpret_cast<uint2 *>(Hp + (g_) * 2048), reinterpret_cast<uint2 *>(Hp + (g_) * 2048 + 1024)
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        m1[g] = bias_relu8(acc1[g], a.hw[g].b1, a.hw[g].cf[0], wave8, lane);
-        store_planes8(acc1[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+        m1[g] = relu_pack4(acc1[g], pk[g], rmax);
+        planes_store8(pk[g], W8_PLANES(g), wave8, lane); OVF_PUBLISH();
     }
     __syncthreads();
 
@@ -1461,17 +1466,17 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
     Acc4 c[G];
     gemm128x<G>(c, Hp, wp, lane);
 #pragma unroll
-    for (int g = 0; g < G; g++) { wprefetch8(wp[g], a.hw[g].w3p, wave8, lane); m2[g] = bias_relu8(c[g], a.hw[g].b2, a.hw[g].cf[1], wave8, lane); }
+    for (int g = 0; g < G; g++) { wprefetch8(wp[g], a.hw[g].w3p, wave8, lane, a.hw[g].b3); m2[g] = relu_pack4(c[g], pk[g], rmax); }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+    for (int g = 0; g < G; g++) planes_store8(pk[g], W8_PLANES(g), wave8, lane); OVF_PUBLISH();
     __syncthreads();
     gemm128x<G>(c, Hp, wp, lane);
 #pragma unroll
-    for (int g = 0; g < G; g++) m3[g] = bias_relu8(c[g], a.hw[g].b3, a.hw[g].cf[2], wave8, lane);
+    for (int g = 0; g < G; g++) m3[g] = relu_pack4(c[g], pk[g], rmax);
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+    for (int g = 0; g < G; g++) planes_store8(pk[g], W8_PLANES(g), wave8, lane); OVF_PUBLISH();
     __syncthreads();
 
     PCLK(4);
@@ -1496,7 +1501,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             const bool valid = n < a.N, live = j < hw.kout;
             const bool inimg = (sIn[pt] & 1) != 0;
             const int pn = sIn[pt] >> 1;
-            float val = o4[r] * hw.cf[3] + bias4;
+            float val = o4[r] * hw.cout + bias4;
             if (*sOvf) val = __builtin_nanf("");
             go[r] = 0.f;
             if (g4 == 0) {
@@ -1530,9 +1535,10 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             const int eb = (int)((__float_as_uint(m) >> 23) & 255u);
-            const bool ok = eb >= GO_EXP + 2 && eb < 255;
-            const float s = ok ? __uint_as_float((unsigned)(254 + GO_EXP - eb) << 23) : 1.0f;
-            const float inv = ok ? __uint_as_float((unsigned)(eb - GO_EXP) << 23) : 1.0f;
+            const int ge = hw.goexp;
+            const bool ok = eb >= ge + 2 && eb >= 2 && eb < 255 && eb - ge < 254;
+            const float s = ok ? __uint_as_float((unsigned)(254 + ge - eb) << 23) : 1.0f;
+            const float inv = ok ? __uint_as_float((unsigned)(eb - ge) << 23) : 1.0f;
             const int pt = w4 * 16 + q * 4 + r;
             if (j == 0) sInv[g4 * 64 + pt] = inv;
             const float x = go[r] * s;
@@ -1562,23 +1568,24 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             c[g].v[p] = MFMAH(as_h8(w4t[g][0]), xl, c[g].v[p]);
             c[g].v[p] = MFMAH(as_h8(w4t[g][1]), xh, c[g].v[p]);
         }
-        scale_mask8(c[g], a.hw[g].cb[3], m3[g]);
-        store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+        mask_pack4(c[g], m3[g], pk[g]);
+        planes_store8(pk[g], W8_PLANES(g), wave8, lane);
     }
     __syncthreads();
     gemm128x<G>(c, Hp, wq, lane);                       // g2 = W3^T . g3
 #pragma unroll
-    for (int g = 0; g < G; g++) { wprefetch8(wq[g], a.hw[g].w2tp, wave8, lane); scale_mask8(c[g], a.hw[g].cb[2], m2[g]); }
+    for (int g = 0; g < G; g++) { wprefetch8(wq[g], a.hw[g].w2tp, wave8, lane); mask_pack4(c[g], m2[g], pk[g]); }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+    for (int g = 0; g < G; g++) planes_store8(pk[g], W8_PLANES(g), wave8, lane);
     __syncthreads();
     gemm128x<G>(c, Hp, wq, lane);                       // g1 = W2^T . g2
 #pragma unroll
-    for (int g = 0; g < G; g++) scale_mask8(c[g], a.hw[g].cb[1], m1[g]);
+    for (int g = 0; g < G; g++) mask_pack4(c[g], m1[g], pk[g]);
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; g++) store_planes8(c[g], reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave8, lane, rmax); OVF_PUBLISH();
+    for (int g = 0; g < G; g++) planes_store8(pk[g], W8_PLANES(g), wave8, lane);
+#undef W8_PLANES
     PCLK(6);
     {   // block-reduce the loss partials (waves 0-3 hold the df term, waves 4-7 the part term)
         double s = loss_acc;
@@ -1605,7 +1612,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
             dh[t][s][0] = Hp[gb * 2048 + (4 * s + q) * 64 + 16 * (2 * ph + t) + j];
             dh[t][s][1] = Hp[gb * 2048 + 1024 + (4 * s + q) * 64 + 16 * (2 * ph + t) + j];
         }
-        kscale[t] = sInv[gb * 64 + 16 * (2 * ph + t) + j] * a.hw[gb].cb[0];
+        kscale[t] = sInv[gb * 64 + 16 * (2 * ph + t) + j] * a.hw[gb].kback;
     }
     float ptx[2], pty[2], piz[2];
 #pragma unroll
@@ -1657,7 +1664,7 @@ __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
                 }
             }
         }
-        const float ks = (ct ? kscale[1] : kscale[0]) * (1.0f / ACT_SCALE);
+        const float ks = (ct ? kscale[1] : kscale[0]) * a.u1inv;
         const float su = ks * (cu[0] * dg[0] + cu[1] * dg[1] + cu[2] * dg[2] + cu[3] * dg[3]);
         const float sv = ks * (cv[0] * dg[0] + cv[1] * dg[1] + cv[2] * dg[2] + cv[3] * dg[3]);
         const float px = ct ? ptx[1] : ptx[0], py = ct ? pty[1] : pty[0], iz = ct ? piz[1] : piz[0];
@@ -1792,14 +1799,17 @@ extern "C" int vt_selftest_mfma(const float *A, const float *Bm, float *out, voi
 static const int kHeadDims[5] = {2, 9, 14, 3, 1};
 static inline int orig_channel(int k) { return k < 256 ? k : (k < 608 ? k + 3 : (k < 611 ? k - 608 + 256 : -1)); }
 
-// power-of-two scale that maps max |w| into [2^13, 2^14)
-static float weight_scale(const float *w, size_t n)
+// Power-of-two weight scale s_l of a layer: max |s_l W_l| in [1, 2).  A split weight hi + lo carries an absolute error <= max(2^-22 |s w|, 2^-25)
+// (fp16 subnormals are honoured by the f16 MFMA: the lo halves of small weights live there), i.e. <= 2^-25 of the matrix maximum for every
+// weight below 2^-3 of it and 2^-22 relative above.  The accumulators of layer l are the operands of layer l + 1 (U_(l+1) = s_l U_l, HeadW), so the
+// scales of the three hidden matrices decide how far below U_4 = 2^ACT_EXP0 the feature scale U_1 sits.
+static int weight_scale_exp(const float *w, size_t n)
 {
     float m = 0.f;
     for (size_t i = 0; i < n; i++) m = fmaxf(m, fabsf(w[i]));
-    if (!(m > 0.f) || !std::isfinite(m)) return 1.0f;
+    if (!(m > 0.f) || !std::isfinite(m)) return 0;
     int e; frexpf(m, &e);          // m = f * 2^e, f in [0.5, 1)
-    return ldexpf(1.0f, 14 - e);
+    return 1 - e;                  // s m in [1, 2)
 }
 static inline void put_split(_Float16 *hi, _Float16 *lo, float x)
 {
@@ -1820,16 +1830,27 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
 {
     VT_REQUIRE(out && w && bvec && cam, "vt_sifnet_create: null argument");
     hipStream_t st = vt_stream(stream);
-    // per head (halves): w1p 20*4*2*2*64*8 | w1c 20*1024*8 | (w2p, w2tp, w3p, w3tp) 4 x 4*4*2*2*64*8 | w4p 4*2*64*8 | w4tp 4*2*2*64*8 ; then floats b1 b2 b3 (128) b4 (16)
+    // per head (halves): w1p 20*4*2*2*64*8 | w1c 20*1024*8 | (w2p, w2tp, w3p, w3tp) 4 x 4*4*2*2*64*8 | w4p 4*2*64*8 | w4tp 4*2*2*64*8 ; then ACT_LEVELS x 512 floats: U_3 b2 | U_4 b3 (128 each) | b4 (16) | pad
     const size_t n_w1p = (size_t)NSTEP1 * 4 * 2 * 2 * 64 * 8, n_w1c = (size_t)(NCHUNK + 1) * 1024 * 8, n_mid = (size_t)4 * 4 * 2 * 2 * 64 * 8,
                  n_w4p = (size_t)4 * 2 * 64 * 8, n_w4t = (size_t)4 * 2 * 2 * 64 * 8;
-    const size_t halves = n_w1p + n_w1c + 4 * n_mid + n_w4p + n_w4t, nbias = 128 * 3 + 16;
+    const size_t halves = n_w1p + n_w1c + 4 * n_mid + n_w4p + n_w4t, nbias = 512 * ACT_LEVELS;
     const size_t per_head = halves * sizeof(_Float16) + nbias * sizeof(float);     // multiple of 16 bytes
     unsigned char *host = new unsigned char[per_head * 5]();
     vt_sifnet *h = new vt_sifnet();
     VT_HIP(hipMalloc(&h->blob, per_head * 5));
     VT_HIP(hipMalloc(&h->projw, sizeof(float) * 256 * PROJ_COLS));
     float *projw_host = new float[256 * PROJ_COLS]();
+    // scales: per head s_1..s_4 from the weights; the feature scale U_1 is shared by the heads of a launch (one set of feature operand planes),
+    // chosen so that no head's last hidden operand scale U_4 = s_1 s_2 s_3 U_1 exceeds 2^ACT_EXP0 (|h_3| < 1023 at range level 0, as before)
+    int se[5][4], e1 = 64;
+    for (int hd = 0; hd < 5; hd++) {
+        se[hd][0] = weight_scale_exp(w[hd * 4], (size_t)128 * VT_FEAT); se[hd][1] = weight_scale_exp(w[hd * 4 + 1], 128 * 128);
+        se[hd][2] = weight_scale_exp(w[hd * 4 + 2], 128 * 128); se[hd][3] = weight_scale_exp(w[hd * 4 + 3], (size_t)kHeadDims[hd] * 128);
+        for (int l = 0; l < 3; l++) se[hd][l] = std::max(se[hd][l], 0);        // hidden layers: never scale DOWN (keeps U_(l+1) >= U_l: headroom only shrinks where weights are small)
+        e1 = std::min(e1, ACT_EXP0 - (se[hd][0] + se[hd][1] + se[hd][2]));
+    }
+    e1 = std::max(e1, -8);
+    h->u1_exp = e1;
     for (int hd = 0; hd < 5; hd++) {
         _Float16 *p = reinterpret_cast<_Float16 *>(host + per_head * hd);
         const unsigned char *d = reinterpret_cast<const unsigned char *>(h->blob) + per_head * hd;
@@ -1838,11 +1859,13 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
         HeadW &H = h->head[hd];
         H.kout = ko; H.id = hd; H.pcol = hd == 0 ? 0 : (hd == 2 ? 128 : -1);
         const float *W1 = w[hd * 4], *W2 = w[hd * 4 + 1], *W3 = w[hd * 4 + 2], *W4 = w[hd * 4 + 3];   // (out, in), W1 in reference channel order
-        const float s1 = weight_scale(W1, (size_t)128 * VT_FEAT), s2 = weight_scale(W2, 128 * 128), s3 = weight_scale(W3, 128 * 128),
-                    s4 = weight_scale(W4, (size_t)ko * 128);
-        const float sc[4] = {s1, s2, s3, s4};
-        for (int l = 0; l < 4; l++) { H.cf[l] = l < 3 ? 1.0f / sc[l] : 1.0f / (ACT_SCALE * sc[l]); H.cb[l] = 1.0f / sc[l]; }
-        auto w1 = [&](int u, int k) { const int c = k < KTOT ? orig_channel(k) : -1; return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c] * s1; };   // internal order
+        const float s1 = ldexpf(1.0f, se[hd][0]), s2 = ldexpf(1.0f, se[hd][1]), s3 = ldexpf(1.0f, se[hd][2]), s4 = ldexpf(1.0f, se[hd][3]);
+        const float U1 = ldexpf(1.0f, e1), U2 = s1 * U1, U3 = s2 * U2, U4 = s3 * U3;      // operand scales at range level 0
+        H.cout = 1.0f / (U4 * s4); H.kback = 1.0f / (s1 * s2 * s3 * s4);
+        H.goexp = std::max(GO_EXP - (se[hd][1] + se[hd][2] + se[hd][3]), -12);
+        h->cout0[hd] = H.cout;
+        // internal channel 611 is the constant one: its weight is the layer-1 bias (22 significand bits like every other weight)
+        auto w1 = [&](int u, int k) { if (k == 611) return bvec[hd * 4][u] * s1; const int c = k < KTOT ? orig_channel(k) : -1; return c < 0 ? 0.f : W1[(size_t)u * VT_FEAT + c] * s1; };   // internal order
         size_t o = 0;
         H.w1p = dev(o); pack_T(p + o, 32 * NSTEP1, [&](int n, int k) { return w1(n, k); }); o += n_w1p;
         H.w1c = dev(o);
@@ -1863,12 +1886,17 @@ extern "C" int vt_sifnet_create(vt_sifnet **out, const float *const *w, const fl
         o += n_w4p;
         H.w4tp = dev(o); pack_T(p + o, 32, [&](int n, int k) { return k < ko ? W4[k * 128 + n] * s4 : 0.f; }); o += n_w4t;
         if (H.pcol >= 0)       // im_feat occupies reference channels 0..255 (chore_triplane.py:97-164 feature order)
-            for (int c = 0; c < 256; c++) for (int u = 0; u < 128; u++) projw_host[(size_t)c * PROJ_COLS + H.pcol + u] = ACT_SCALE * s1 * W1[(size_t)u * VT_FEAT + c];
+            for (int c = 0; c < 256; c++) for (int u = 0; u < 128; u++) projw_host[(size_t)c * PROJ_COLS + H.pcol + u] = s1 * W1[(size_t)u * VT_FEAT + c];
         float *bp = reinterpret_cast<float *>(p + o);
         const float *bd = reinterpret_cast<const float *>(d + o * sizeof(_Float16));
-        H.b1 = bd; H.b2 = bd + 128; H.b3 = bd + 256; H.b4 = bd + 384;
-        for (int l = 0; l < 3; l++) for (int i = 0; i < 128; i++) bp[l * 128 + i] = bvec[hd * 4 + l][i] * ACT_SCALE + 0.0f;   // hidden biases in operand units (exact); -0 -> +0 (bias_relu's mask bit)
-        memcpy(bp + 384, bvec[hd * 4 + 3], ko * sizeof(float));
+        h->bias_dev[hd] = bd;
+        for (int lv = 0; lv < ACT_LEVELS; lv++) {
+            // hidden biases of layers 2, 3 in the operand units of the layer's output at range level lv (exact: powers of two)
+            const float dn = ldexpf(1.0f, -ACT_LEVEL_SHIFT * lv);
+            for (int i = 0; i < 128; i++) { bp[lv * 512 + i] = bvec[hd * 4 + 1][i] * (U3 * dn); bp[lv * 512 + 128 + i] = bvec[hd * 4 + 2][i] * (U4 * dn); }
+            memcpy(bp + lv * 512 + 256, bvec[hd * 4 + 3], ko * sizeof(float));
+        }
+        H.b2 = bd; H.b3 = bd + 128; H.b4 = bd + 256;
     }
     VT_HIP(hipMemcpyAsync(h->blob, host, per_head * 5, hipMemcpyHostToDevice, st));
     VT_HIP(hipMemcpyAsync(h->projw, projw_host, sizeof(float) * 256 * PROJ_COLS, hipMemcpyHostToDevice, st));
@@ -1889,14 +1917,25 @@ extern "C" int vt_sifnet_set_precision(vt_sifnet *h, int mode)
     return VT_OK;
 }
 extern "C" int vt_sifnet_get_precision(const vt_sifnet *h) { return h ? h->precision.load(std::memory_order_relaxed) : VT_ERR_ARG; }
-#define VT_IS_F32(h_) ((h_) && (h_)->precision.load(std::memory_order_relaxed) == VT_PRECISION_FP32)
+// which arithmetic serves a call: the handle's default, overridden per call by the maps (vt_maps::force_fp32 -- per batch, so concurrent fits
+// through one handle never see each other's switch)
+#define VT_IS_F32(h_, m_) ((h_) && ((h_)->precision.load(std::memory_order_relaxed) == VT_PRECISION_FP32 || ((m_) && (m_)->force_fp32)))
+// decoder head `id` at operand-range level `lvl` (vt_maps::act_level): same weights, biases and output scale of that level
+static HeadW head_at(const vt_sifnet *h, int id, int lvl)
+{
+    HeadW H = h->head[id];
+    const float *bd = h->bias_dev[id] + 512 * lvl;
+    H.b2 = bd; H.b3 = bd + 128; H.b4 = bd + 256;
+    H.cout = h->cout0[id] * ldexpf(1.0f, ACT_LEVEL_SHIFT * lvl);
+    return H;
+}
 
 // ---- hoisted projection: P[m][n] = sum_c im_feat[m][c] Wp[c][n], m over all texels of the batch, c < 256, n < PROJ_COLS; fp32 MFMA
 // (16x16x4), one workgroup per 64 texels: the A tile (64 x 256) sits in LDS, wave w owns columns 64 w .. +63 (4 x 4 tiles) and streams
 // its slice of Wp (256 KB, L2 resident) from global.  0.2 TFLOP per 96-frame batch, once per batch.
 #define PJ_AS 260
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Wp, float *__restrict__ P, long M)
+__global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Wp, float *__restrict__ P, long M, float u1)
 {
     extern __shared__ __attribute__((aligned(16))) float sA[];      // [64][PJ_AS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, i = lane & 15;
@@ -1932,7 +1971,7 @@ __global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict_
             const long m = m0 + 16 * rt + 4 * kq + r;
             if (m < M) {
 #pragma unroll
-                for (int ct = 0; ct < 4; ct++) P[m * PROJ_COLS + 64 * wave + 16 * ct + i] = acc[rt][ct][r];
+                for (int ct = 0; ct < 4; ct++) P[m * PROJ_COLS + 64 * wave + 16 * ct + i] = acc[rt][ct][r] * u1;      // exact: a power of two
             }
         }
 }
@@ -1953,11 +1992,13 @@ extern "C" long vt_query_projection_floats(const vt_maps *maps, int B)
 
 extern "C" int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps, int B, float *proj, void *stream)
 {
-    VT_REQUIRE(h && maps && proj && B > 0 && maps->maps[0] && maps->res[0] >= 2, "vt_query_build_projection: bad argument");
+    VT_REQUIRE(h && maps && proj && B > 0 && maps->maps[0] && maps->res[0] >= 2 && maps->act_level >= 0 && maps->act_level < ACT_LEVELS,
+               "vt_query_build_projection: bad argument");
     const long M = (long)B * maps->res[0] * maps->res[0];
     const size_t lds = sizeof(float) * 64 * PJ_AS;
     VT_LDS_LIMIT(proj_gemm_kernel, lds);
-    hipLaunchKernelGGL(proj_gemm_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, vt_stream(stream), maps->maps[0], h->projw, proj, M);
+    hipLaunchKernelGGL(proj_gemm_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), lds, vt_stream(stream), maps->maps[0], h->projw, proj, M,
+                       ldexpf(1.0f, h->u1_exp - ACT_LEVEL_SHIFT * maps->act_level));
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -1993,7 +2034,11 @@ static int fill_common(QArgs &a, const vt_sifnet *h, const vt_maps *maps, const 
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < 8; i++) { VT_REQUIRE(maps->maps[i] && maps->res[i] >= 2, "vt_query: map %d missing", i); a.maps[i] = maps->maps[i]; a.res[i] = maps->res[i]; }
     a.pts = pts; a.crop_center = cc; a.body_center = bc; a.B = B; a.N = N;
-    a.proj = maps->proj; a.pw = maps->proj ? maps->proj_cols : 0;
+    VT_REQUIRE(maps->act_level >= 0 && maps->act_level < ACT_LEVELS, "vt_query: vt_maps::act_level must be in [0, %d)", ACT_LEVELS);
+    // the hoisted projection carries the operand scale of the level it was built for
+    const bool proj_ok = maps->proj && maps->proj_level == maps->act_level;
+    a.proj = proj_ok ? maps->proj : nullptr; a.pw = proj_ok ? maps->proj_cols : 0;
+    a.u1 = ldexpf(1.0f, h->u1_exp - ACT_LEVEL_SHIFT * maps->act_level); a.u1inv = 1.0f / a.u1;
     a.fx = h->cam[0]; a.fy = h->cam[1]; a.cx = h->cam[2]; a.cy = h->cam[3]; a.crop = h->cam[4];
     return VT_OK;
 }
@@ -2001,7 +2046,7 @@ static int fill_common(QArgs &a, const vt_sifnet *h, const vt_maps *maps, const 
 extern "C" int vt_query_forward(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                 int B, int N, float *df, float *pca, float *parts, float *centers, float *vis, void *stream)
 {
-    if (VT_IS_F32(h)) return f32q::forward(h->f32, maps, pts, crop_center, body_center, B, N, df, pca, parts, centers, vis, stream);
+    if (VT_IS_F32(h, maps)) return f32q::forward(h->f32, maps, pts, crop_center, body_center, B, N, df, pca, parts, centers, vis, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     float *outs[5] = {df, pca, parts, centers, vis};
     int ids[5], n = 0;
@@ -2009,7 +2054,7 @@ extern "C" int vt_query_forward(const vt_sifnet *h, const vt_maps *maps, const f
     VT_REQUIRE(n > 0, "vt_query_forward: no output requested");
     for (int i = 0; i < n; i += 2) {
         const int g = (i + 1 < n) ? 2 : 1;
-        for (int k = 0; k < g; k++) { a.hw[k] = h->head[ids[i + k]]; a.out[k] = outs[ids[i + k]]; }
+        for (int k = 0; k < g; k++) { a.hw[k] = head_at(h, ids[i + k], maps->act_level); a.out[k] = outs[ids[i + k]]; }
         rc = (g == 2) ? launch<2, MODE_FWD>(a, vt_stream(stream)) : launch<1, MODE_FWD>(a, vt_stream(stream));
         if (rc) return rc;
     }
@@ -2020,7 +2065,7 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
                                  int B, int N, const float *d_df, const float *d_pca, const float *d_parts, const float *d_centers,
                                  const float *d_vis, float *dpts, void *stream)
 {
-    if (VT_IS_F32(h)) return f32q::backward(h->f32, maps, pts, crop_center, body_center, B, N, d_df, d_pca, d_parts, d_centers, d_vis, dpts, stream);
+    if (VT_IS_F32(h, maps)) return f32q::backward(h->f32, maps, pts, crop_center, body_center, B, N, d_df, d_pca, d_parts, d_centers, d_vis, dpts, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(dpts, "vt_query_backward: dpts is null");
     const float *gs[5] = {d_df, d_pca, d_parts, d_centers, d_vis};
@@ -2029,7 +2074,7 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
     if (n == 0) { VT_HIP(hipMemsetAsync(dpts, 0, sizeof(float) * (size_t)B * N * 3, vt_stream(stream))); return VT_OK; }
     VT_REQUIRE(n <= 2, "vt_query_backward: at most two heads with gradients per call (call again and add for more)");
     a.dpts = dpts;
-    for (int k = 0; k < n; k++) { a.hw[k] = h->head[ids[k]]; a.gout[k] = gs[ids[k]]; }
+    for (int k = 0; k < n; k++) { a.hw[k] = head_at(h, ids[k], maps->act_level); a.gout[k] = gs[ids[k]]; }
     return n == 2 ? launch<2, MODE_BWD>(a, vt_stream(stream)) : launch<1, MODE_BWD>(a, vt_stream(stream));
 }
 
@@ -2045,10 +2090,10 @@ extern "C" int vt_query_set_human_kernel(int threads)
 extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                    int B, int N, const int *labels, const int *order, float w_dfh, float w_part, float *dpts, double *terms, void *stream)
 {
-    if (VT_IS_F32(h)) return f32q::human_loss(h->f32, maps, pts, crop_center, body_center, B, N, labels, order, w_dfh, w_part, dpts, terms, stream);
+    if (VT_IS_F32(h, maps)) return f32q::human_loss(h->f32, maps, pts, crop_center, body_center, B, N, labels, order, w_dfh, w_part, dpts, terms, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(labels && dpts && terms, "vt_query_human_loss: null argument");
-    a.hw[0] = h->head[0]; a.hw[1] = h->head[2]; a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
+    a.hw[0] = head_at(h, 0, maps->act_level); a.hw[1] = head_at(h, 2, maps->act_level); a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
     // vt_query_set_human_kernel(512) / VT_QUERY_HUMAN_KERNEL=512 select the 512-thread kernel (one workgroup per CU, deep tap prefetch): an
     // experiment kept for A/B measurements and as an independent cross-check of the 256-thread kernel (measured slower)
     const bool use8 = g_human_kernel_threads.load(std::memory_order_relaxed) == 512;
@@ -2060,19 +2105,19 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
 extern "C" int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                      int B, int N, int df_idx, float threshold, float *pts_out, float *df_target, void *stream)
 {
-    if (VT_IS_F32(h)) return f32q::project_step(h->f32, maps, pts, crop_center, body_center, B, N, df_idx, threshold, pts_out, df_target, stream);
+    if (VT_IS_F32(h, maps)) return f32q::project_step(h->f32, maps, pts, crop_center, body_center, B, N, df_idx, threshold, pts_out, df_target, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(pts_out && (df_idx == 0 || df_idx == 1), "vt_query_project_step: pts_out is null or df_idx not in {0 (human), 1 (object)}");
-    a.hw[0] = h->head[0]; a.df_idx = df_idx; a.w0 = threshold; a.pts_out = pts_out; a.dft_out = df_target;
+    a.hw[0] = head_at(h, 0, maps->act_level); a.df_idx = df_idx; a.w0 = threshold; a.pts_out = pts_out; a.dft_out = df_target;
     return launch<1, MODE_PROJECT>(a, vt_stream(stream));
 }
 
 extern "C" int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
                                     int B, int N, const float *occ, float w_obj, float *dpts, double *terms, void *stream)
 {
-    if (VT_IS_F32(h)) return f32q::object_loss(h->f32, maps, pts, crop_center, body_center, B, N, occ, w_obj, dpts, terms, stream);
+    if (VT_IS_F32(h, maps)) return f32q::object_loss(h->f32, maps, pts, crop_center, body_center, B, N, occ, w_obj, dpts, terms, stream);
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(occ && dpts && terms, "vt_query_object_loss: null argument");
-    a.hw[0] = h->head[0]; a.occ = occ; a.w0 = w_obj; a.dpts = dpts; a.terms = terms;
+    a.hw[0] = head_at(h, 0, maps->act_level); a.occ = occ; a.w0 = w_obj; a.dpts = dpts; a.terms = terms;
     return launch<1, MODE_OBJECT>(a, vt_stream(stream));
 }

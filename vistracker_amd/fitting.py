@@ -13,6 +13,7 @@ prior gradient.  Loss VALUES keep every term the reference sums (the early-stop 
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -48,11 +49,11 @@ def _ev_begin(prof):
     return e
 
 
-def _ev_end(prof, key, e0):
+def _ev_end(prof, key, e0, frames):
     if prof is None:
         return
     e1 = torch.cuda.Event(enable_timing=True); e1.record()
-    prof[key].append((e0, e1))
+    prof[key].append((e0, e1, frames))      # frames of the launch: the tail batch of a sequence is smaller
 
 
 class Terms:
@@ -192,26 +193,40 @@ class FitContext:
         self.jw66 = t(JOINT_WEIGHTS_66)
 
     # ---- shared pieces ----------------------------------------------------------------------------------
-    fp32_fallbacks = 0      # how many fits of this context had to be repeated on the strict-fp32 kernels
+    range_retries = 0       # fits of this context repeated at a wider operand-range level of the split-f16 decoders
+    fp32_fallbacks = 0      # fits of this context that had to be repeated on the strict-fp32 kernels
+    _counter_lock = threading.Lock()
 
-    def _with_fp32_fallback(self, params, run):
-        """Run a fit; if the split-f16 decoders produced a non-finite loss (an activation beyond the range of the split operands, |x| >= 1023:
-        DESIGN.md 4.1 -- possible with a real checkpoint, the reference's fp32 Conv1d has no such limit) restore the parameters, switch the
-        network handle to the strict-fp32 kernels (query_f32.hip) and run the fit again.  The handle stays on fp32 afterwards (the same network
-        will overflow again); a loss that is non-finite on the fp32 route too (NaN inputs) still raises."""
-        if self.net is None or self.net.precision == "fp32":
+    def _with_range_fallback(self, maps, params, run):
+        """Run a fit; if the split-f16 decoders produced a non-finite loss (an activation beyond the range of the split operands at the maps'
+        level -- |x| >= 1023 at level 0; possible with a real checkpoint, the reference's fp32 Conv1d has no such limit) restore
+        the parameters and repeat the fit at the next operand-range level (same kernels, operand scale / 16: one repeated fit, not a slower
+        route), and only after the last level on the strict-fp32 kernels (query_f32.hip).  Level and route are properties of THIS batch's
+        maps (vt_maps::act_level / force_fp32): nothing another fit running concurrently through the same network handle can observe.  The
+        maps keep the level that worked (the same batch would overflow again); a loss that is non-finite on the fp32 route too still raises."""
+        if self.net is None or maps is None or maps.force_fp32 or self.net.precision == "fp32":
             return run()
         saved = [p.clone() for p in params]
-        try:
-            return run()
-        except FloatingPointError as e:
-            import warnings
-            warnings.warn(f"{e}; repeating the fit on the strict-fp32 decoder kernels (5x slower)", RuntimeWarning)
-            for p, s0 in zip(params, saved):
-                p.copy_(s0)
-            self.net.set_precision("fp32")
-            self.fp32_fallbacks += 1
-            return run()
+        while True:
+            try:
+                return run()
+            except FloatingPointError as e:
+                import warnings
+                for p, s0 in zip(params, saved):
+                    p.copy_(s0)
+                if maps.act_level + 1 < maps.ACT_LEVELS:
+                    maps.set_act_level(maps.act_level + 1)
+                    warnings.warn(f"{e}; repeating the fit at operand-range level {maps.act_level} of the split-f16 decoders", RuntimeWarning)
+                    with self._counter_lock:
+                        self.range_retries += 1
+                    continue
+                if maps.force_fp32:
+                    raise
+                warnings.warn(f"{e}; repeating the fit on the strict-fp32 decoder kernels (5x slower)", RuntimeWarning)
+                maps.set_force_fp32(True)
+                with self._counter_lock:
+                    self.fp32_fallbacks += 1
+                return run()
 
     def smpl_forward(self, pose, betas, trans, verts, jtr, vposed, ws):
         _chk(_lib().vt_smplh_forward(self.smpl.h, pose.data_ptr(), betas.data_ptr(), trans.data_ptr(), pose.shape[0], verts.data_ptr(),
@@ -310,7 +325,7 @@ class FitContext:
         body_kpts) are converted to contiguous float32 on the parameters' device if they are not already (a reference-style driver hands
         over float64 from the dataloader's default collate)."""
         with torch.cuda.device(pose.device):
-            return self._with_fp32_fallback((pose, betas, trans), lambda: self._optimize_smpl(
+            return self._with_range_fallback(maps, (pose, betas, trans), lambda: self._optimize_smpl(
                 maps, pose, betas, trans, crop_center, body_center, body_kpts, max_iter, iter_for_betas, iter_for_pose, iter_for_kpts, it_range, net_size,
                 check_every, prof, early_stop))
 
@@ -319,8 +334,8 @@ class FitContext:
         dev = pose.device; B = pose.shape[0]; V = 6890
         _require_params(pose, betas, trans)
         crop_center, body_center, body_kpts = _as_input(crop_center, dev), _as_input(body_center, dev), _as_input(body_kpts, dev)
-        if self.use_projection and self.net.precision != "fp32":
-            maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale
+        if self.use_projection and self.net.precision != "fp32" and not maps.force_fp32:
+            maps.build_projection(self.net)     # rebuilt at every call: 2.5 ms per 96-frame batch, never stale (and at the maps' range level)
         names = ["df_h", "part", "pose", "pinit", "j2d", "stemp", "hand"]
         vert_order = self.vert_order
         terms = Terms(names, dev)
@@ -364,7 +379,7 @@ class FitContext:
                 _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
                                                 self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
                                                 dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
-                _ev_end(prof, "human", ev)
+                _ev_end(prof, "human", ev, B)
                 if phase == "kpts":
                     _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
@@ -398,7 +413,7 @@ class FitContext:
         ``sil``: SilSetup (phase 'sil'); ``noise``: (steps,B,3,3) U[0,1) samples of decopose_axis or None (drawn from ``seed``).
         Constant inputs are converted to contiguous float32 on the parameters' device if needed."""
         with torch.cuda.device(obj_R.device):
-            return self._with_fp32_fallback((obj_R, obj_t), lambda: self._optimize_smpl_object(
+            return self._with_range_fallback(maps, (obj_R, obj_t), lambda: self._optimize_smpl_object(
                 maps, smpl_verts, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, noise, iter_for_obj, iter_for_sil, joint_iter, max_iter, it_range,
                 seed, check_every, prof, early_stop))
 
@@ -410,7 +425,7 @@ class FitContext:
         obj_s = obj_s.reshape(-1)
         if noise is not None:
             noise = _as_input(noise, dev)
-        if self.use_projection and self.net.precision != "fp32":
+        if self.use_projection and self.net.precision != "fp32" and not maps.force_fp32:
             maps.build_projection(self.net)
         names = ["object", "otemp", "ovtemp", "mask", "trans", "contact", "collide", "scale"]
         terms = Terms(names, dev)
@@ -467,7 +482,7 @@ class FitContext:
                     ev = _ev_begin(prof)
                     _chk(_lib().vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
                                                      occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), L.stream_ptr()))
-                    _ev_end(prof, "object", ev)
+                    _ev_end(prof, "object", ev, B)
                 if B >= 4:
                     _chk(_lib().vt_accel_loss(X.data_ptr(), B, N * 3, None, float(w[1]), terms.ptr("otemp"), dX.data_ptr(), L.stream_ptr()))
                     _chk(_lib().vt_velocity_loss(X.data_ptr(), B, N * 3, float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), L.stream_ptr()))

@@ -174,54 +174,66 @@ class MotionInfillAutoreg:
 
     def model_forward(self, data_, mask):
         """data_ (T,D) combined SMPL + object features, mask (T,) True = occluded: the object part of occluded frames is zeroed IN PLACE
-        (test_cinfill_autoreg.py:41-52)"""
+        (test_cinfill_autoreg.py:41-52).  numpy arrays (the reference's types) or device tensors."""
         od = self.obj_dim
-        data_[:, -od:] = data_[:, -od:] * (1 - np.expand_dims(mask.astype(float), -1))
-        x = torch.from_numpy(np.stack([data_], 0)).float().to(self.device)
-        m = torch.from_numpy(np.stack([mask], 0)).to(self.device)
+        if torch.is_tensor(data_):
+            data_[:, -od:] = data_[:, -od:] * (~mask).to(data_.dtype).unsqueeze(-1)
+            x, m = data_[None].float(), mask[None]
+        else:
+            data_[:, -od:] = data_[:, -od:] * (1 - np.expand_dims(mask.astype(float), -1))
+            x = torch.from_numpy(np.stack([data_], 0)).float().to(self.device)
+            m = torch.from_numpy(np.stack([mask], 0)).to(self.device)
         if self.conditional:
             return self.model(x[:, :, :-od], torch.zeros_like(m, dtype=torch.bool), x[:, :, -od:], m)
         return self.model(x, mask=None, src_key_padding_mask=m)
 
     def infill(self, dat: dict, obj_angles, occ_ratios):
         """``dat``: packed SMPL recon (poses, trans, obj_trans, frames, ...); ``obj_angles``: (L,3,3) object rotations of the packed object
-        recon; ``occ_ratios`` (L,) predicted visibility.  Returns (dat_out, infilled: bool)."""
+        recon; ``occ_ratios`` (L,) predicted visibility.  Returns (dat_out, infilled: bool).
+        The ~50 autoregressive clips of a 1500-frame sequence run on DEVICE-RESIDENT tensors: the sequence features go up once, every clip is
+        cut, masked and written back there (each clip's context is the previous clip's output: a serial chain of small launches with no host
+        round trip in it), and the result comes down once -- the per-clip numpy assembly + ``.cpu()`` of the reference's driver
+        (interp/test_infill_autoreg.py:112-175) was a host-bound 2-6 s on the shared host of a GPU box.  The arithmetic is float64 like numpy's
+        until the network input is cast to float32, as in the reference."""
         clip_len, window, od = self.clip_len, self.window, self.obj_dim
         dat = dict(dat)
         L = len(dat["frames"])
-        rot6d_smpl, rot6d_obj = prep_smpl_rot6d(dat["poses"]), prep_obj_rot6d(obj_angles)
-        trans_smpl, trans_obj = np.asarray(dat["trans"]), np.asarray(dat["obj_trans"])
-        occ_ratios = np.asarray(occ_ratios)
-        assert np.all(~np.isnan(occ_ratios)), "found invalid visibility value nan!"
-        rot6d_out, trans_out = np.zeros_like(rot6d_obj), np.zeros_like(trans_obj)
+        dev = self.device
+        up = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64).to(dev)
+        rot6d_smpl, rot6d_obj = up(prep_smpl_rot6d(dat["poses"])), up(prep_obj_rot6d(obj_angles))
+        trans_smpl, trans_obj = up(dat["trans"]), up(dat["obj_trans"])
+        occ_np = np.asarray(occ_ratios)
+        assert np.all(~np.isnan(occ_np)), "found invalid visibility value nan!"
+        occ = up(occ_np)
+        rot6d_out, trans_out = torch.zeros_like(rot6d_obj), torch.zeros_like(trans_obj)
 
         def clip(s, e, ctx=None):
-            parts = [rot6d_smpl[s:e].copy(), trans_smpl[s:e].copy(), (rot6d_obj if ctx is None else rot6d_out)[s:e].copy()]
+            parts = [rot6d_smpl[s:e], trans_smpl[s:e], (rot6d_obj if ctx is None else rot6d_out)[s:e]]
             if od == 9:
-                parts.append((trans_obj if ctx is None else trans_out)[s:e].copy())
-            return np.concatenate(parts, 1)
+                parts.append((trans_obj if ctx is None else trans_out)[s:e])
+            return torch.cat(parts, 1)          # a new tensor: model_forward may zero its object part in place
 
         start, end = 0, clip_len
-        data_ = clip(start, end)
-        mask = occ_ratios[start:end].copy() < self.init_thres            # a less strict requirement for the first clip: better seeds
-        if np.sum(~mask) < window:
+        if int(np.sum(~(occ_np[start:end] < self.init_thres))) < window:
             dat["obj_scales"] = np.ones(L); dat["exp_name"] = self.exp_name           # save_output(save_orig=True)
             return dat, False
+        data_ = clip(start, end)
+        mask = occ[start:end] < self.init_thres                           # a less strict requirement for the first clip: better seeds
         pred = self.model_forward(data_, mask)
-        rot6d_out[start:end] = pred[0, :, :6].cpu().numpy()
-        trans_out[start:end] = pred[0, :, 6:].cpu().numpy() if od == 9 else trans_obj[start:end].copy()
+        rot6d_out[start:end] = pred[0, :, :6].double()
+        trans_out[start:end] = pred[0, :, 6:].double() if od == 9 else trans_obj[start:end]
         for idx in range(0, L - clip_len + 1 + window, window):
             start, end = idx, idx + clip_len
             data_ = clip(start, end)
-            pre_ctx = clip(start, start + window, ctx=True)
-            mask = occ_ratios[start:end].copy() < self.occ_thres
-            data_[:window] = pre_ctx; mask[:window] = False
+            mask = occ[start:end] < self.occ_thres
+            data_[:window] = clip(start, start + window, ctx=True); mask[:window] = False
             pred = self.model_forward(data_, mask)
-            rot6d_out[start + window:end] = pred[0, window:, :6].cpu().numpy()
-            trans_out[start + window:end] = pred[0, window:, 6:].cpu().numpy() if od == 9 else trans_obj[start + window:end].copy()
-        rot_pred = rot6d_to_rotmat(torch.from_numpy(rot6d_out))
+            n = data_.shape[0]                                            # the last clips are shorter than clip_len
+            rot6d_out[start + window:start + n] = pred[0, window:, :6].double()
+            trans_out[start + window:start + n] = pred[0, window:, 6:].double() if od == 9 else trans_obj[start + window:start + n]
+        rot_pred = rot6d_to_rotmat(rot6d_out)
         assert torch.sum(torch.isnan(rot_pred)) == 0, "found nan values!"
         dat["obj_angles"] = rot_pred.transpose(1, 2).cpu().numpy().copy()
-        dat["obj_trans"] = trans_out
+        dat["obj_trans"] = trans_out.cpu().numpy()
         dat["obj_scales"] = np.ones(L); dat["exp_name"] = self.exp_name
         return dat, True

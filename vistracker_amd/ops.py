@@ -227,17 +227,42 @@ class FeatureMaps:
         for i, t in enumerate(self.t):
             self.c.maps[i] = t.data_ptr(); self.c.res[i] = t.shape[1]
 
+    ACT_LEVELS = 3      # operand-range levels of the split-f16 decoders (vt_maps::act_level): |activation| < 1023 * 16^level
+
+    @property
+    def act_level(self) -> int:
+        return int(self.c.act_level)
+
+    def set_act_level(self, level: int):
+        """operand-range level of the split-f16 decoders for every query call with THESE maps (per batch: concurrent fits through one network
+        handle do not share it).  A hoisted projection built for another level is ignored by the kernels until it is rebuilt."""
+        assert 0 <= level < self.ACT_LEVELS
+        self.c.act_level = level
+        return self
+
+    @property
+    def force_fp32(self) -> bool:
+        return bool(self.c.force_fp32)
+
+    def set_force_fp32(self, on: bool = True):
+        """route the query calls with THESE maps to the strict-fp32 kernels (any activation magnitude, ~1/5 of the speed)"""
+        self.c.force_fp32 = 1 if on else 0
+        return self
+
     def slice(self, start, end):
         """frames [start, end) as a FeatureMaps of views (no copy; the projection, if any, is not carried over)"""
-        return FeatureMaps({k: t[start:end] for k, t in zip(MAP_ORDER, self.t)})
+        fm = FeatureMaps({k: t[start:end] for k, t in zip(MAP_ORDER, self.t)})
+        fm.c.act_level = self.c.act_level; fm.c.force_fp32 = self.c.force_fp32
+        return fm
 
     def select(self, idx):
         """the frames ``idx`` (1-D index tensor) as a new FeatureMaps (copies: 71 MB per frame + the hoisted projection, 17 MB per frame, if there is
         one) -- for passes that continue with a subset of a batch"""
         fm = FeatureMaps({k: t.index_select(0, idx).contiguous() for k, t in zip(MAP_ORDER, self.t)})
+        fm.c.act_level = self.c.act_level; fm.c.force_fp32 = self.c.force_fp32
         if self.proj is not None:
             fm.proj = self.proj.view(self.B, -1).index_select(0, idx).reshape(-1).contiguous()
-            fm.c.proj = fm.proj.data_ptr(); fm.c.proj_cols = self.c.proj_cols
+            fm.c.proj = fm.proj.data_ptr(); fm.c.proj_cols = self.c.proj_cols; fm.c.proj_level = self.c.proj_level
         return fm
 
     def build_projection(self, net):
@@ -250,6 +275,7 @@ class FeatureMaps:
         self.c.proj = None; self.c.proj_cols = 0
         L.check(L.lib().vt_query_build_projection(h, C.byref(self.c), self.B, self.proj.data_ptr(), L.stream_ptr()))
         self.c.proj = self.proj.data_ptr(); self.c.proj_cols = n // (self.B * self.t[0].shape[1] * self.t[0].shape[2])
+        self.c.proj_level = self.c.act_level
         return self
 
     def drop_projection(self):

@@ -8,8 +8,9 @@ stages, so that a sequence goes from 2-D keypoints + image crops to packed SMPL-
     5  SmoothNet on object rotation, HVOP-Net smoothnet/smooth_objrot.py -neural_pca, interp/test_cinfill_autoreg.py
     6  joint optimisation, pack               recon/recon_fit_trivis_full.py, pack_recon.py
 
-Frames are sharded over ranks in whole batches (``sharding.shard_batches``) in the per-batch stages 1, 2b, 3, 4, 6; the whole-sequence
-stages 2a and 5 run on the gathered rows (one RCCL all-gather per barrier, ``sharding.gather_params``).  Dataset IO (image crops, openpose
+Frames are sharded over ranks in whole batches in the per-batch stages: 1 and 2b by ``smplt_bs`` batches (``sharding.shard_batches``), 4 and 6
+over the SAME frames of a rank (``sharding.shard_units``: units of lcm(neural_bs, fit_bs) frames), so the feature maps stage 4 encodes stay
+resident for stage 6 on every rank; the whole-sequence stages 2a and 5 run on the gathered rows (one RCCL all-gather per barrier, ``sharding.gather_params``).  Dataset IO (image crops, openpose
 json, mocap initialisation) is the caller's: ``seq`` holds the tensors the reference's readers would produce.
 """
 from __future__ import annotations
@@ -144,17 +145,23 @@ class SequencePipeline:
         rows = []
         MAPSPEC = (("im_feat", 128, 256), ("tmpx", 256, 64), ("tri_tmpx0", 256, 32), ("tri_tmpx1", 256, 32), ("tri_tmpx2", 256, 32),
                    ("tri_feat0", 128, 64), ("tri_feat1", 128, 64), ("tri_feat2", 128, 64))
-        mine = self._shard(T, cfg.fit_bs)
-        lo, hi = sharding.frame_range(mine)
-        world, _ = self._world()
-        resident = world == 1 and (hi - lo) * sum(r * r * c * 4 for _, r, c in MAPSPEC) <= cfg.resident_maps_bytes
-        big = {k: torch.empty(T, r, r, c, device=self.device) for k, r, c in MAPSPEC} if resident else None
-        for s, e in self._shard(T, cfg.neural_bs):
+        # stages 4 and 6 run over the SAME frames of a rank: shards are contiguous runs of lcm(neural_bs, fit_bs)-frame units, so both stages cut
+        # the batches the single-process run cuts and the maps stage 4 leaves in HBM are the ones stage 6 needs -- on every rank (8 ranks x 192
+        # frames x 71 MB = 14 GB of the 288 GB each)
+        import math
+        world, rank = self._world()
+        unit = math.lcm(cfg.neural_bs, cfg.fit_bs)
+        lo, hi = sharding.frame_range(sharding.shard_units(T, cfg.neural_bs, cfg.fit_bs, world, rank))
+        resident = (hi - lo) * sum(r * r * c * 4 for _, r, c in MAPSPEC) <= cfg.resident_maps_bytes
+        big = {k: torch.empty(hi - lo, r, r, c, device=self.device) for k, r, c in MAPSPEC} if resident else None
+        self.log["resident_maps"] = bool(resident); self.log["frame_range"] = (lo, hi)
+        enc0 = getattr(self.net, "frames_encoded", 0)
+        for s, e in sharding.batches_of(T, cfg.neural_bs, lo, hi):
             batch = {k: v[s:e] for k, v in data.items()}
             self.generator.reseed(s)            # random stream keyed by the batch's first frame: the same samples on any rank
             bm = None
             if resident:
-                self.net.filter(batch["images"], out={k: t[s:e] for k, t in big.items()})
+                self.net.filter(batch["images"], out={k: t[s - lo:e - lo] for k, t in big.items()})
                 bm = self.net.maps
             # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
             # neural-only pass is written to disk and never read again by steps 5-6 (work whose result is unused)
@@ -162,7 +169,7 @@ class SequencePipeline:
             o = pc["object"]
             rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
         local = torch.cat(rows, 0) if rows else torch.zeros(0, 16, device=self.device)
-        neural = self._gather(local, T, cfg.neural_bs).cpu().numpy()
+        neural = self._gather(local, T, unit).cpu().numpy()
         neural_dict = {"pca_axis": neural[:, :9].reshape(T, 3, 3), "centers": neural[:, 9:15], "visibility": neural[:, 15:16]}
         out["neural"] = packing.pack_neural(neural_dict, frames, gender, cfg.neural_name)
         lap("4_sifnet_neural")
@@ -174,7 +181,7 @@ class SequencePipeline:
         obj_rots = out["hvop"]["obj_angles"] if out["hvop_applied"] else out["obj_smooth"]["obj_angles"]
         lap("5_objrot_smooth_infill")
         # 6  joint optimisation of this rank's batches, gather, pack
-        shards = list(self._shard(T, cfg.fit_bs))
+        shards = sharding.batches_of(T, cfg.fit_bs, lo, hi)
         rows = [None] * len(shards); steps = [None] * len(shards)
 
         def fit_one(idx, fitter, generator):
@@ -182,7 +189,7 @@ class SequencePipeline:
             smpl = SMPLHGenerator.get_smplh(poses[s:e], betas[s:e], trans[s:e], gender, self.device, model_root=self.model_dict)
             if not cfg.reuse_neural:            # the random stream is only drawn from when the surface points are generated again
                 generator.reseed(s)
-            bm = ops.FeatureMaps({k: t[s:e] for k, t in big.items()}) if resident else None
+            bm = ops.FeatureMaps({k: t[s - lo:e - lo] for k, t in big.items()}) if resident else None
             pcg = None
             if cfg.reuse_neural:
                 tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
@@ -225,7 +232,8 @@ class SequencePipeline:
                 raise errors[0]
         self.log.setdefault("fit_steps", []).extend(steps)
         local = torch.cat(rows, 0) if rows else torch.zeros(0, packing.ROW_WIDTH, device=self.device)
-        full = self._gather(local, T, cfg.fit_bs)
+        full = self._gather(local, T, unit)
+        self.log["frames_encoded"] = getattr(self.net, "frames_encoded", 0) - enc0
         out["recon"] = packing.pack_recon(full, frames, gender, cfg.save_name, self.ctx.smpl, neural=neural_dict)
         lap("6_joint_fit")
         return out

@@ -26,6 +26,15 @@ def shard_batches(num_frames: int, bs: int, world: int, rank: int, start: int = 
     return allb[lo:hi]
 
 
+def shard_units(num_frames: int, bs_a: int, bs_b: int, world: int, rank: int) -> List[Tuple[int, int]]:
+    """Contiguous share of rank ``rank`` in units of lcm(bs_a, bs_b) frames: two per-batch stages with different batch sizes (the SIF-Net pass at 64,
+    the joint fit at 96: scripts/demo.sh:27, recon_fit_triplane.py:257) can then run over the SAME frames of a rank -- every unit boundary is a
+    batch boundary of both stages, so each stage cuts exactly the batches the single-process run cuts (same results), and what the first stage
+    leaves in HBM (the feature maps) is where the second one needs it."""
+    import math
+    return shard_batches(num_frames, math.lcm(bs_a, bs_b), world, rank)
+
+
 def frame_range(batches: List[Tuple[int, int]]) -> Tuple[int, int]:
     """the --start/--end pair equivalent to a shard (empty shard -> (0, 0))"""
     return (batches[0][0], batches[-1][1]) if batches else (0, 0)

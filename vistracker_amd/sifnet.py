@@ -68,6 +68,7 @@ class SIFNetQuery:
         if self.encoder is None:
             raise RuntimeError("this SIFNetQuery has no encoder weights: build it with from_state_dict(checkpoint) or call set_feature_maps()")
         self.maps = self.encoder(images, out=out)
+        self.frames_encoded = getattr(self, "frames_encoded", 0) + int(images.shape[0])      # bookkeeping for the pipeline (every frame is encoded once per run)
 
     def query(self, points, crop_center=None, body_center=None, **kwargs):
         assert self.maps is not None, "call set_feature_maps() (or filter()) first"

@@ -124,6 +124,33 @@ class SmoothNetSMPL:
         return torch.cat([self.pose_net(x[:, :144]), x[:, 144:154], self.trans_net(x[:, 154:])], 1)
 
 
+class ClipPaths:
+    """the frame names of the sliding clips, ``paths[b] == frames[starts[b] : starts[b] + W]``, without materialising B x W strings"""
+
+    def __init__(self, frames, starts, W):
+        self.frames, self.starts, self.W = list(frames), list(starts), W
+
+    def __len__(self):
+        return len(self.starts)
+
+    def __getitem__(self, b):
+        s = self.starts[b]
+        return self.frames[s:s + self.W]
+
+    def merged(self):
+        """SMPLTSmoother.merge_paths of the clips: every covered frame once, in order of first appearance (clips start at increasing frames,
+        so that is the frame order), image paths reduced to their frame folder (smooth_base.py:88-109)"""
+        cov = np.zeros(len(self.frames), bool)
+        for s in self.starts:
+            cov[s:s + self.W] = True
+        out, seen = [], set()
+        for i in np.nonzero(cov)[0]:
+            fr = self.frames[i]; p = fr.rsplit("/", 1)[0] if "color.jpg" in fr else fr
+            if p not in seen:
+                seen.add(p); out.append(p)
+        return out
+
+
 class SMPLTSmoother:
     """``SMPLTSmoother`` without the file IO: ``smooth(raw_data)`` = preprocess_input -> model -> post_processing"""
 
@@ -138,16 +165,17 @@ class SMPLTSmoother:
 
     def seq2batches(self, data_seq, raw_data):
         """(T,D) -> (B,W,D) clips with stride ``slide_window_step`` (+ a last clip flush with the end when the stride is not 1) and the
-        frame names of every clip (smooth_base.py:45-73)"""
+        frame names of every clip (smooth_base.py:45-73).  The clips are one strided view of the sequence (``unfold``: no Python loop over the
+        ~1400 windows of a 1500-frame sequence), the names a lazy ``ClipPaths`` (the reference builds B x W string lists only to merge them
+        back into the frame list)."""
         T = len(data_seq)
-        data_seq = torch.as_tensor(np.asarray(data_seq)).reshape(T, -1)
+        data_seq = torch.as_tensor(np.asarray(data_seq) if not torch.is_tensor(data_seq) else data_seq).reshape(T, -1)
         W, st = self.slide_window_size, self.slide_window_step
         starts = list(range(0, T - W + 1, st))
-        clips = [data_seq[i:i + W].clone() for i in starts]
-        paths = [list(raw_data["frames"][i:i + W]) for i in starts]
+        clips = data_seq.unfold(0, W, st).permute(0, 2, 1).contiguous()          # (B,W,D): clip b = frames b * st .. b * st + W - 1
         if st != 1:
-            clips.append(data_seq[-W:].clone()); paths.append(list(raw_data["frames"][-W:]))
-        return torch.stack(clips, 0), paths
+            clips = torch.cat([clips, data_seq[-W:][None]], 0); starts.append(T - W)
+        return clips, ClipPaths(raw_data["frames"], starts, W)
 
     def preprocess_input(self, raw_data):
         poses = np.asarray(raw_data["poses"])
@@ -155,7 +183,9 @@ class SMPLTSmoother:
         smpl_poses = self.smplh2smpl_pose(poses) if poses.shape[-1] == 156 else poses
         pose_6d = numpy_axis_to_rot6D(smpl_poses.reshape(-1, 3)).reshape(-1, 6 * 24)
         data_seq = np.concatenate([pose_6d, raw_data["betas"], raw_data["trans"]], 1)
-        input_data, paths = self.seq2batches(data_seq, raw_data)
+        # the sequence goes to the device ONCE; the ~1400 clips are cut there (a 1437 x 64 x 157 host tensor took longer to build and copy than
+        # the network takes to run)
+        input_data, paths = self.seq2batches(torch.as_tensor(data_seq).float().to(self.device), raw_data)
         s0 = 24 * 6 + 10
         init = input_data[:, 0:1, s0:s0 + 3].clone()                      # translation relative to the first frame of each clip
         input_data[:, :, s0:s0 + 3] = input_data[:, :, s0:s0 + 3] - init
@@ -163,6 +193,8 @@ class SMPLTSmoother:
 
     @staticmethod
     def merge_paths(paths):
+        if isinstance(paths, ClipPaths):
+            return paths.merged()
         out, seen = [], set()
         for clip in paths:
             for fr in clip:
@@ -229,7 +261,7 @@ class ObjrotSmoother(SMPLTSmoother):
 
     def preprocess_input(self, raw_data):
         rot6d = rotmat_to_6d(torch.as_tensor(np.asarray(raw_data["obj_rot"]))).reshape(-1, 6)
-        input_data, paths = self.seq2batches(rot6d, raw_data)
+        input_data, paths = self.seq2batches(rot6d.to(self.device), raw_data)
         return {"input_data": input_data, "paths": paths, "neural_visibility": raw_data["neural_visibility"]}
 
     def post_processing(self, data, denoised, input_pred):
