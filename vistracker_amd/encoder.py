@@ -246,9 +246,18 @@ class SIFNetEncoder:
             self._full_chunk_seen = self._full_chunk_seen or x.shape[0] == self.chunk
             feats, tmpx, _ = self.image(x[:, :5])
             maps = {"im_feat": feats[-1], "tmpx": tmpx}
-            for v in range(3):
-                f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
-                maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
+            if self.tri[0] is self.tri[1] and self.tri[1] is self.tri[2]:
+                # shared triplane encoder (chore_triplane.py:60-95 applies the same module to the three renders): ONE pass over the 3 x chunk
+                # single-channel images instead of three -- every op of the encoder is per frame, so the maps are the same; the launches are
+                # three times larger (the 16-frame ones leave the chip half empty at the 1/4- and 1/8-resolution levels of the hourglass)
+                nb = x.shape[0]
+                f, t, _ = self.tri[0](x[:, 5:8].transpose(0, 1).reshape(3 * nb, 1, *x.shape[2:]))
+                for v in range(3):
+                    maps[f"tri_tmpx{v}"] = t[v * nb:(v + 1) * nb]; maps[f"tri_feat{v}"] = f[-1][v * nb:(v + 1) * nb]
+            else:
+                for v in range(3):
+                    f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
+                    maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
             if out is None:
                 # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from; written per chunk
                 out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}

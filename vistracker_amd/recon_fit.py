@@ -81,6 +81,26 @@ class ReconFitterTriVisFull(ReconFitterBase):
         self.last = {}          # FitResult of the last optimize_* call (loss history, step counts, early-stop flag)
         self.profile = False    # True: fit_recon_batch records synchronised wall-clock per part in self.last["seconds"]
 
+    @classmethod
+    def from_paths(cls, seq_folder, debug=False, outpath=None, args=None, *, paths="PATHS.yml", obj_name=None, device="cuda:0"):
+        """The reference's constructor call, unchanged: ``ReconFitterTriVisFull.from_paths(seq_folder, debug, outpath, args)``
+        (recon_fit_trivis_full.py:477-485).  Reads what ``ReconFitterBase.__init__`` reads (recon_fit_base.py:53-120) from the places PATHS.yml names:
+        SMPL-H model of the sequence's gender, landmark regressors + priors, part labels, the object template of <seq_folder>/info.json
+        (centred, PCA axes, 3000 surface samples) and the SIF-Net checkpoint of ``args.exp_name`` (``args.checkpoint`` or best / latest) --
+        ``vistracker_amd.paths``.  Also sets what the reference keeps on the instance: ``gender``, ``pca_init``, ``obj_points``, ``obj_scale``,
+        ``part_labels``, ``net_in_size``, ``z_0``, ``state_dict`` (for ``SIFNetQuery.from_state_dict``)."""
+        from . import paths as P
+        kw, meta = P.recon_inputs(seq_folder, args, paths, obj_name)
+        self = cls(seq_folder, debug, outpath if outpath is not None else meta["outpath"], args, device=device, **kw)
+        self.gender, self.obj_name, self.state_dict, self.checkpoint = meta["gender"], meta["obj_name"], meta["state_dict"], meta["checkpoint"]
+        self.pca_init = torch.as_tensor(meta["pca_init"], dtype=torch.float32, device=device)
+        self.obj_points = torch.as_tensor(kw["obj_points"], dtype=torch.float32, device=device)
+        self.obj_scale = 1.0
+        self.part_labels = torch.as_tensor(kw["part_labels"], device=device)
+        self.net_in_size = args.net_img_size[0] if args is not None and hasattr(args, "net_img_size") else 512
+        self.z_0 = getattr(args, "z_0", 2.2)
+        return self
+
     # ---- schedules / weights (Appendix A.2 of SURVEY.md) ---------------------------------------------------
     def get_loss_weights(self):
         """name -> ``lambda cst, it: w * cst / (1 + it)`` for every term of recon_fit_trivis_full.py:124-153 (terms the fit path never

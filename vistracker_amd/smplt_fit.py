@@ -9,9 +9,9 @@ the HIP ops (autograd through ``vistracker_amd.smpl``), so code that steps the o
 the whole schedule (100 x 10 Adam steps, optimiser switch at ``get_globalopt_iters()``, decay ``it // 3``, the reference's stop rule)
 as ONE fused loop on the C ABI (``FitContext.fit_smplt``).
 
-Sequence IO is not reproduced (FrameDataReader, openpose json, per-frame pkl): ``init_smpl`` / ``load_kpts`` /
-``save_results`` are the three hooks ``fit_one_batch`` calls, exactly where the reference calls them; a ``source`` object supplies
-them (or a subclass overrides them).
+Sequence IO (mocap initialisation, openpose json, per-frame pkl) lives in ``vistracker_amd.sequence_io.SmpltFolderSource``:
+``init_smpl`` / ``load_kpts`` / ``save_results`` are the three hooks ``fit_one_batch`` calls, exactly where the reference calls them; a
+``source`` object supplies them (or a subclass overrides them).  ``from_paths`` builds a fitter from PATHS.yml like the reference's constructor.
 """
 from __future__ import annotations
 
@@ -46,6 +46,22 @@ class BaseFitter:
         self.source = source
         self.ctx = FitContext(smpl_model, regressors, priors, cam=(self.fx, self.fy, self.cx, self.cy, 1200.0), device=device)
         self.last = None            # FitResult of the last fit_one_batch
+
+    @classmethod
+    def from_paths(cls, device="cuda:0", debug=False, init_type="mocap", args=None, *, paths="PATHS.yml", gender="male", source=None):
+        """The reference's constructor call, unchanged: ``SMPLHFitter30fps.from_paths(device, debug, init_type, args)`` (fit_SMPLH_kpts.py:31-53,
+        fit_SMPLH_30fps.py:206-230): SMPL-H model, landmark regressors and priors from the places PATHS.yml names (``vistracker_amd.paths``);
+        ``source`` defaults to the sequence-folder IO of ``vistracker_amd.sequence_io.SmpltFolderSource``."""
+        from . import paths as P
+        model, regs, pri = P.smpl_inputs(paths, gender)
+        self = cls(device, debug, init_type, args, smpl_model=model, regressors=regs, priors=pri, source=source)
+        if source is None:
+            try:
+                from .sequence_io import SmpltFolderSource
+                self.source = SmpltFolderSource(self, init_type=init_type, smpl_model=model)
+            except Exception:       # noqa: BLE001 -- a source can always be attached later
+                pass
+        return self
 
     # ---- schedule / weights ----------------------------------------------------------------------------------
     def get_loss_weights(self):
