@@ -197,6 +197,17 @@ int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, int in_cstrid
                              const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
                              double *stats_ws, int stats_groups, void *stream);
 int vt_conv3x3_tiles(int H, int W);
+/* The 1 x 1 convolutions of the same encoders (conv_last / l / bl / al of a stack, the ConvBlock's down-sampling projection: model/HGFilters.py:150-203,
+ * model/net_util.py:364-372) on the same split-f16 kernel (one tap, the 8 x 16 tile as the patch).  weight (Cout, Cin) fp32 host, bias (Cout) or NULL,
+ * Cout in {64, 128, 256} (256 runs as two launches of 128), Cin a multiple of 32.  forward: out <- conv(in) + bias [+ res]; gn_stats != NULL applies
+ * max((x - mean) rstd gamma + beta, 0) to the input while it is staged (the GroupNorm -> ReLU in front of l / bl / the projection); stats_ws != NULL
+ * leaves the GroupNorm partial sums of conv(in) + bias behind like vt_conv3x3_forward_gn_stats (finalize with C = Cout). */
+typedef struct vt_conv1x1 vt_conv1x1;
+int vt_conv1x1_create(vt_conv1x1 **out, const float *weight, const float *bias, int cout, int cin, void *stream);
+void vt_conv1x1_destroy(vt_conv1x1 *h);
+int vt_conv1x1_forward(const vt_conv1x1 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma, const float *beta, int groups,
+                       int B, int H, int W, float *out, int out_cstride, int out_coff, const float *res, int res_cstride, int res_coff,
+                       double *stats_ws, int stats_groups, void *stream);
 int vt_groupnorm_finalize(double *ws, int nblk, int B, int HW, int C, int groups, float eps, void *stream);
 /* GroupNorm statistics of a channel slice: ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles; the (B, groups) {mean, rstd} float pairs
  * are written at the START of ws (pass `(const float *)ws` as gn_stats) */

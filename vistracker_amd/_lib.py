@@ -64,6 +64,9 @@ SIGNATURES = {
     "vt_groupnorm_workspace_doubles": (C.c_long, [ci, ci, ci, ci]),
     "vt_groupnorm_finalize": (ci, [fp, ci, ci, ci, ci, ci, cf, vp]),
     "vt_conv3x3_tiles": (ci, [ci, ci]),
+    "vt_conv1x1_create": (ci, [C.POINTER(vp), vp, vp, ci, ci, vp]),
+    "vt_conv1x1_destroy": (None, [vp]),
+    "vt_conv1x1_forward": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_conv3x3_forward_block": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_conv3x3_forward_gn_stats": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_triplane_render": (ci, [fp, fp, ci, ci, fp, ci, ci, fp, fp, fp, vp]),

@@ -50,21 +50,31 @@ __device__ __forceinline__ float cv_row16_sum(float v)
     v += CV_DPP(v, 0xB1); v += CV_DPP(v, 0x4E); v += CV_DPP(v, 0x141); return v + CV_DPP(v, 0x140);
 #undef CV_DPP
 }
-template <int NT>
+// K3 = true: the 3 x 3 convolution (halo patch of 10 x 18 pixels, nine taps).  K3 = false: the 1 x 1 convolutions of the encoder (conv_last, l, bl, al,
+// the ConvBlock's down-sampling projection: model/HGFilters.py:150-203, net_util.py:364-372) -- plain GEMMs over pixels -- on the same machinery: the
+// "patch" is the 8 x 16 tile itself, one tap, an optional per-channel bias, the GroupNorm + ReLU prologue, the residual add and the output
+// statistics all shared with the 3 x 3 form (stats_cstride / stats_coff: the channel count and offset of the statistics block when a layer of 256
+// output channels runs as two launches of 128).
+template <int NT, bool K3, int NCH>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
                                                          float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part,
-                                                         const float *__restrict__ res, int res_cstride, int res_coff, float *__restrict__ fin, int fin_cstride, int fin_coff)
+                                                         const float *__restrict__ res, int res_cstride, int res_coff, float *__restrict__ fin, int fin_cstride, int fin_coff,
+                                                         const float *__restrict__ bias, int stats_cstride, int stats_coff)
 {
-    // two patch buffers of {hi [4 kb][180], lo [4 kb][180]} uint4
+    constexpr int PW = K3 ? CV_PW : CV_TW, PX = K3 ? CV_PX : CV_TH * CV_TW, NLD = K3 ? 6 : 4, NTAP = K3 ? 9 : 1;
+    // 1 x 1 form: one tap per chunk makes an iteration nine times shorter than the 3 x 3 one, so the input loads run RING - 1 = 3 chunks ahead of
+    // their use (a ring of register sets; the chunk count NCH is a template parameter and the loop fully unrolled, so the ring indices are constants)
+    constexpr int RING = K3 ? 1 : 4;
+    // two patch buffers of {hi [4 kb][PX], lo [4 kb][PX]} uint4 (sized for the 3 x 3 form; the epilogue's staging tile needs 34 KB of it in both forms)
     __shared__ __attribute__((aligned(16))) uint4 patch[2][2 * 4 * CV_PX];
     __shared__ int sOvf;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int tiles_x = W / CV_TW, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-    const int y0 = ty * CV_TH - 1, x0 = tx * CV_TW - 1;            // image position of halo pixel (0, 0)
+    const int y0 = ty * CV_TH - (K3 ? 1 : 0), x0 = tx * CV_TW - (K3 ? 1 : 0);            // image position of patch pixel (0, 0)
     const float *__restrict__ inb = in + (size_t)b * H * W * in_cstride + in_coff;
     const int cg = gn_stats ? Cin / groups : 1;
-    const int nchunk = Cin >> 5;
+    const int nchunk = K3 ? (Cin >> 5) : NCH;
     if (tid == 0) sOvf = 0;
     float rmax = 0.f;
 
@@ -75,25 +85,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
         for (int p = 0; p < CV_TH; p++) acc[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // halo patch of one chunk: 180 px x 8 pieces of 16 B = 1440 items, 6 per thread (the last round partly idle)
-    float4 ld[6];
+    float4 ld[RING][NLD];
     unsigned inmask = 0;        // which of this thread's six halo pixels lie inside the image (the same for every chunk)
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-        const int it = tid + 256 * r, px = it >> 3, yy = y0 + px / CV_PW, xx = x0 + px % CV_PW;
-        inmask |= (unsigned)(it < CV_PX * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W) << r;
+    for (int r = 0; r < NLD; r++) {
+        const int it = tid + 256 * r, px = it >> 3, yy = y0 + px / PW, xx = x0 + px % PW;
+        inmask |= (unsigned)(it < PX * 8 && yy >= 0 && yy < H && xx >= 0 && xx < W) << r;
     }
-    auto issue = [&](int c) {
+    auto issue = [&](int c, int slot) {
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
+        for (int r = 0; r < NLD; r++) {
             const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
-            const int yy = y0 + px / CV_PW, xx = x0 + px % CV_PW;
+            const int yy = y0 + px / PW, xx = x0 + px % PW;
             const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
             const float4 v = *reinterpret_cast<const float4 *>(inb + ((size_t)yc * W + xc) * in_cstride + c * 32 + piece * 4);
-            ld[r] = v;          // outside pixels are read from a clamped address and zeroed in stage(): the padding pads the RECTIFIED activation
+            ld[slot][r] = v;    // outside pixels are read from a clamped address and zeroed in stage(): the padding pads the RECTIFIED activation
         }
     };
-    auto stage = [&](int buf, int c) {
-        uint2 *hi8 = reinterpret_cast<uint2 *>(patch[buf]), *lo8 = reinterpret_cast<uint2 *>(patch[buf] + 4 * CV_PX);
+    auto stage = [&](int buf, int c, int slot) {
+        uint2 *hi8 = reinterpret_cast<uint2 *>(patch[buf]), *lo8 = reinterpret_cast<uint2 *>(patch[buf] + 4 * PX);
         // fused GroupNorm + ReLU prologue (the pre-activated ConvBlock: GN -> ReLU -> conv): y = max(x * a + s, 0) with a = rstd gamma,
         // s = beta - mean a of this thread's four channels of the chunk (the piece index of a thread is the same in every round)
         float ga[4] = {CV_ACT_SCALE, CV_ACT_SCALE, CV_ACT_SCALE, CV_ACT_SCALE}, gs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -107,17 +117,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
             }
         }
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
+        for (int r = 0; r < NLD; r++) {
             const int it = tid + 256 * r, px = it >> 3, piece = it & 7;
-            if (it < CV_PX * 8) {
+            if (it < PX * 8) {
                 uint2 hi, lo;
                 const bool inside = (inmask >> r) & 1u;
-                float v0 = __builtin_fmaf(ld[r].x, ga[0], gs[0]), v1 = __builtin_fmaf(ld[r].y, ga[1], gs[1]), v2 = __builtin_fmaf(ld[r].z, ga[2], gs[2]), v3 = __builtin_fmaf(ld[r].w, ga[3], gs[3]);
+                float v0 = __builtin_fmaf(ld[slot][r].x, ga[0], gs[0]), v1 = __builtin_fmaf(ld[slot][r].y, ga[1], gs[1]), v2 = __builtin_fmaf(ld[slot][r].z, ga[2], gs[2]), v3 = __builtin_fmaf(ld[slot][r].w, ga[3], gs[3]);
                 if (gn_stats) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 if (!inside) v0 = v1 = v2 = v3 = 0.f;
                 cv_split2(v0, v1, hi.x, lo.x, rmax);
                 cv_split2(v2, v3, hi.y, lo.y, rmax);
-                const int idx = (((piece >> 1) * CV_PX + px) << 1) + (piece & 1);
+                const int idx = (((piece >> 1) * PX + px) << 1) + (piece & 1);
                 hi8[idx] = hi; lo8[idx] = lo;
             }
         }
@@ -130,26 +140,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 #define CV_LOAD_W(slot_, step_)                                                                                      \
     _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                \
         _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
-    issue(0);
-    if (live) { CV_LOAD_W(0, 0) }
-    stage(0, 0);
-    if (nchunk > 1) issue(1);
-    for (int c = 0; c < nchunk; c++) {
-        const uint4 *Xhi = patch[c & 1], *Xlo = Xhi + 4 * CV_PX;
+    auto chunk_mfma = [&](int c) {
+        const uint4 *Xhi = patch[c & 1], *Xlo = Xhi + 4 * PX;
         __syncthreads();                                        // patch of chunk c visible; the other buffer's readers are done
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int dy = t / 3, dx = t % 3, step = c * 9 + t;
-            if (live && step + 1 < nchunk * 9) { CV_LOAD_W((t + 1) & 1, step + 1) }          // 9 taps: slots alternate with t, chunk c + 1 starts on slot (9 & 1) = 1 ...
-            // ... so the slot of (c, t) is (c + t) & 1: handled by indexing with the running parity below
-            const int sl = t & 1;
+        for (int t = 0; t < NTAP; t++) {
+            const int dy = K3 ? t / 3 : 0, dx = K3 ? t % 3 : 0, step = c * NTAP + t;
+            // 3 x 3: nine taps, slots alternate with t (chunk c + 1 starts on slot (9 & 1) = 1, re-aligned below); 1 x 1: slots alternate with the chunk
+            if (live && step + 1 < nchunk * NTAP) { if (K3) { CV_LOAD_W((t + 1) & 1, step + 1) } else if (c & 1) { CV_LOAD_W(0, step + 1) } else { CV_LOAD_W(1, step + 1) } }
+            const int sl = K3 ? (t & 1) : (c & 1);
 #pragma unroll
             for (int ph = 0; ph < (live ? 2 : 0); ph++) {       // two halves of four image rows: 8 B fragments live at a time
                 h8 xh[4], xl[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    const int px = (4 * ph + p + dy) * CV_PW + j + dx;
-                    xh[p] = cv_h8(Xhi[q * CV_PX + px]); xl[p] = cv_h8(Xlo[q * CV_PX + px]);
+                    const int px = (4 * ph + p + dy) * PW + j + dx;
+                    xh[p] = cv_h8(Xhi[q * PX + px]); xl[p] = cv_h8(Xlo[q * PX + px]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
@@ -165,13 +171,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
                     for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][1]), xh[p], acc[nt][4 * ph + p]);
             }
         }
-        // nine taps flip the slot parity once per chunk: re-align so that tap 0 of the next chunk finds its fragments in slot 0
+        if (K3) {
+            // nine taps flip the slot parity once per chunk: re-align so that tap 0 of the next chunk finds its fragments in slot 0
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+            for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int hl = 0; hl < 2; hl++) wf[0][nt][hl] = wf[1][nt][hl];
-        if (c + 1 < nchunk) stage((c + 1) & 1, c + 1);
-        if (c + 2 < nchunk) issue(c + 2);
+                for (int hl = 0; hl < 2; hl++) wf[0][nt][hl] = wf[1][nt][hl];
+        }
+    };
+    if (K3) {
+        issue(0, 0);
+        if (live) { CV_LOAD_W(0, 0) }
+        stage(0, 0, 0);
+        if (nchunk > 1) issue(1, 0);
+        for (int c = 0; c < nchunk; c++) {
+            chunk_mfma(c);
+            if (c + 1 < nchunk) stage((c + 1) & 1, c + 1, 0);
+            if (c + 2 < nchunk) issue(c + 2, 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (RING < NCH ? RING : NCH); k++) issue(k, k);
+        if (live) { CV_LOAD_W(0, 0) }
+        stage(0, 0, 0);
+        if (RING < NCH) issue(RING, 0);                        // set 0 is free again
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            chunk_mfma(c);
+            if (c + 1 < NCH) stage((c + 1) & 1, c + 1, (c + 1) % RING);
+            if (c + 1 + RING < NCH) issue(c + 1 + RING, (c + 1) % RING);
+        }
     }
 #undef CV_LOAD_W
     if (rmax > CV_SPLIT_MAX) sOvf = 1;
@@ -185,6 +214,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     float *__restrict__ ob = out ? out + (size_t)b * H * W * out_cstride + out_coff : nullptr;
     float *__restrict__ fb = fin ? fin + (size_t)b * H * W * fin_cstride + fin_coff : nullptr;
     const float *__restrict__ rb = fin ? res + (size_t)b * H * W * res_cstride + res_coff : nullptr;
+    float bv[NT][4];                                            // bias of this lane's four output channels per channel tile (0 without one)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int co = (wave * NT + nt) * 16 + 4 * q + r; bv[nt][r] = (bias && co < cout) ? bias[co] : 0.f; }
     constexpr int TS = 68;                                      // floats per staged pixel row: 64 channels + 4 (bank spread)
     float *tile = reinterpret_cast<float *>(patch);            // 128 x 68 floats = 34 KB of the 46 KB patch buffers (all readers passed the barrier above)
 #pragma unroll
@@ -192,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
         if (nt) __syncthreads();                                // the readers of the previous pass are done
 #pragma unroll
         for (int p = 0; p < CV_TH; p++) {
-            float4 v = make_float4(acc[nt][p][0] * inv_scale, acc[nt][p][1] * inv_scale, acc[nt][p][2] * inv_scale, acc[nt][p][3] * inv_scale);
+            float4 v = make_float4(__builtin_fmaf(acc[nt][p][0], inv_scale, bv[nt][0]), __builtin_fmaf(acc[nt][p][1], inv_scale, bv[nt][1]),
+                                   __builtin_fmaf(acc[nt][p][2], inv_scale, bv[nt][2]), __builtin_fmaf(acc[nt][p][3], inv_scale, bv[nt][3]));
             if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             *reinterpret_cast<float4 *>(tile + (p * CV_TW + j) * TS + wave * 16 + 4 * q) = v;
         }
@@ -215,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     // the sum and the sum of squares over this workgroup's 8 x 16 pixels -- 8 rows in the lane, 16 columns across a DPP row -- written as one
     // block of partials [tile][frame][channel][2] (fp64) for vt_groupnorm_finalize.  Saves the statistics pass over the tensor.
     if (stats_part) {
-        double *pp = stats_part + (((size_t)blockIdx.x * gridDim.y + b) * cout) * 2;
+        double *pp = stats_part + (((size_t)blockIdx.x * gridDim.y + b) * stats_cstride + stats_coff) * 2;
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
             const int co = (wave * NT + nt) * 16 + 4 * q;
@@ -223,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
             for (int r = 0; r < 4; r++) {
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
-                for (int p = 0; p < CV_TH; p++) { const float v = acc[nt][p][r] * inv_scale; sm += v; sq = __builtin_fmaf(v, v, sq); }
+                for (int p = 0; p < CV_TH; p++) { const float v = __builtin_fmaf(acc[nt][p][r], inv_scale, bv[nt][r]); sm += v; sq = __builtin_fmaf(v, v, sq); }
                 sm = cv_row16_sum(sm); sq = cv_row16_sum(sq);
                 if (j == 0 && co + r < cout) { pp[(co + r) * 2] = (double)sm; pp[(co + r) * 2 + 1] = (double)sq; }
             }
@@ -280,8 +315,8 @@ extern "C" int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, in
     const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
     VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv3x3_forward_block: stats_groups must be positive");
     double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
-    if (h->nt == 2) hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff);
-    else hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff);
+    if (h->nt == 2) hipLaunchKernelGGL((conv3x3_kernel<2, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0);
+    else hipLaunchKernelGGL((conv3x3_kernel<1, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -302,4 +337,79 @@ extern "C" int vt_conv3x3_forward(const vt_conv3x3 *h, const float *in, int B, i
 {
     VT_REQUIRE(h, "vt_conv3x3_forward: null handle");
     return vt_conv3x3_forward_gn(h, in, h->cin, 0, nullptr, nullptr, nullptr, 0, B, H, W, out, out_cstride, out_coff, stream);
+}
+
+
+// ---- 1 x 1 convolutions (with bias) on the same kernel ------------------------------------------------------------------------------------------
+struct vt_conv1x1 {
+    uint4 *w[2];        // per part of <= 128 output channels: [Cin / 32][4 waves][NT][hi|lo][64 lanes]
+    float *bias;        // (Cout) or NULL
+    int cin, cout, parts, pcout, nt;
+    float inv_scale;
+};
+extern "C" int vt_conv1x1_create(vt_conv1x1 **out, const float *weight, const float *bias, int cout, int cin, void *stream)
+{
+    VT_REQUIRE(out && weight && (cout == 64 || cout == 128 || cout == 256) && (cin == 32 || cin == 64 || cin == 128 || cin == 256),
+               "vt_conv1x1_create: needs Cout in {64, 128, 256} and Cin in {32, 64, 128, 256}");
+    vt_conv1x1 *h = new vt_conv1x1();
+    h->cin = cin; h->cout = cout; h->parts = cout == 256 ? 2 : 1; h->pcout = cout / h->parts; h->nt = h->pcout == 128 ? 2 : 1; h->bias = nullptr; h->w[0] = h->w[1] = nullptr;
+    const int nt = h->nt, nchunk = cin / 32;
+    float m = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin; i++) m = fmaxf(m, fabsf(weight[i]));
+    float sw = 1.0f;
+    if (m > 0.f && std::isfinite(m)) { int e; frexpf(m, &e); sw = ldexpf(1.0f, 14 - e); }
+    h->inv_scale = 1.0f / (CV_ACT_SCALE * sw);
+    const size_t n16 = (size_t)nchunk * 4 * nt * 2 * 64;
+    _Float16 *host = new _Float16[n16 * 8];
+    hipStream_t st = vt_stream(stream);
+    for (int pt = 0; pt < h->parts; pt++) {
+        for (int c = 0; c < nchunk; c++) for (int w = 0; w < 4; w++) for (int n = 0; n < nt; n++) for (int l = 0; l < 64; l++) for (int k = 0; k < 8; k++) {
+            const int co = pt * h->pcout + (w * nt + n) * 16 + (l & 15), ci = 32 * c + 8 * (l >> 4) + k;
+            const float x = weight[(size_t)co * cin + ci] * sw;
+            const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+            const size_t base = ((((size_t)c * 4 + w) * nt + n) * 2) * 64;
+            host[(base + l) * 8 + k] = hi; host[(base + 64 + l) * 8 + k] = lo;
+        }
+        VT_HIP(hipMalloc(reinterpret_cast<void **>(&h->w[pt]), n16 * 16));
+        VT_HIP(hipMemcpyAsync(h->w[pt], host, n16 * 16, hipMemcpyHostToDevice, st));
+        VT_HIP(hipStreamSynchronize(st));
+    }
+    delete[] host;
+    if (bias) {
+        VT_HIP(hipMalloc(reinterpret_cast<void **>(&h->bias), sizeof(float) * cout));
+        VT_HIP(hipMemcpyAsync(h->bias, bias, sizeof(float) * cout, hipMemcpyHostToDevice, st));
+        VT_HIP(hipStreamSynchronize(st));
+    }
+    *out = h;
+    return VT_OK;
+}
+extern "C" void vt_conv1x1_destroy(vt_conv1x1 *h) { if (!h) return; (void)hipFree(h->w[0]); if (h->w[1]) (void)hipFree(h->w[1]); if (h->bias) (void)hipFree(h->bias); delete h; }
+
+extern "C" int vt_conv1x1_forward(const vt_conv1x1 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma, const float *beta, int groups,
+                                  int B, int H, int W, float *out, int out_cstride, int out_coff, const float *res, int res_cstride, int res_coff,
+                                  double *stats_ws, int stats_groups, void *stream)
+{
+    VT_REQUIRE(h && in && out && B > 0 && H % CV_TH == 0 && W % CV_TW == 0 && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
+               "vt_conv1x1_forward: needs H %% 8 == 0, W %% 16 == 0 and 16-byte aligned channel slices");
+    VT_REQUIRE(out_cstride >= out_coff + h->cout && out_cstride % 4 == 0 && out_coff % 4 == 0, "vt_conv1x1_forward: bad output slice");
+    VT_REQUIRE(!res || (res_cstride >= res_coff + h->cout && res_cstride % 4 == 0 && res_coff % 4 == 0), "vt_conv1x1_forward: bad residual slice");
+    VT_REQUIRE(!gn_stats || (gamma && beta && groups > 0 && h->cin % groups == 0), "vt_conv1x1_forward: GroupNorm prologue needs gamma, beta and Cin %% groups == 0");
+    VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv1x1_forward: stats_groups must be positive");
+    const dim3 grid((H / CV_TH) * (W / CV_TW), B);
+    const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
+    double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
+    for (int pt = 0; pt < h->parts; pt++) {
+        const int o = pt * h->pcout;
+        // with a residual the sum is the layer's only output (`fin`), without one the plain result (`out`): the statistics are those of conv + bias
+        float *o_plain = res ? nullptr : out; float *o_fin = res ? out : nullptr;
+        const float *bs = h->bias ? h->bias + o : nullptr;
+#define CV_L1(NT_, NCH_) hipLaunchKernelGGL((conv3x3_kernel<NT_, false, NCH_>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w[pt], st2, gamma, beta, groups, \
+                                          o_plain, out_cstride, out_coff + o, h->inv_scale, h->pcout, part, res, res_cstride, res_coff + o, o_fin, out_cstride, out_coff + o, bs, h->cout, o)
+        const int nch = h->cin / 32;
+        if (h->nt == 2) { if (nch == 1) CV_L1(2, 1); else if (nch == 2) CV_L1(2, 2); else if (nch == 4) CV_L1(2, 4); else CV_L1(2, 8); }
+        else { if (nch == 1) CV_L1(1, 1); else if (nch == 2) CV_L1(1, 2); else if (nch == 4) CV_L1(1, 4); else CV_L1(1, 8); }
+#undef CV_L1
+        VT_LAUNCH_CHECK();
+    }
+    return VT_OK;
 }

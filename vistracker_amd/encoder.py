@@ -75,8 +75,8 @@ class HGFilterEncoder:
 
     def __del__(self):
         try:
-            for h in getattr(self, "_conv_handles", {}).values():
-                L.lib().vt_conv3x3_destroy(h)
+            for k, h in getattr(self, "_conv_handles", {}).items():
+                (L.lib().vt_conv1x1_destroy if k.startswith("1x1:") else L.lib().vt_conv3x3_destroy)(h)
         except Exception:
             pass
 
@@ -91,6 +91,47 @@ class HGFilterEncoder:
                 L.check(L.lib().vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
             self._conv_handles[name] = h
         return h
+
+    def _conv1x1_handle(self, wname, bname, device):
+        import ctypes as C
+        h = self._conv_handles.get("1x1:" + wname)
+        if h is None:
+            w = self.sd[wname]; cout, cin = w.shape[:2]
+            wh = np.ascontiguousarray(w.contiguous().cpu().numpy().reshape(cout, cin), np.float32)
+            bh = np.ascontiguousarray(self.sd[bname].cpu().numpy(), np.float32) if bname is not None and bname in self.sd else None
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                L.check(L.lib().vt_conv1x1_create(C.byref(h), wh.ctypes.data, bh.ctypes.data if bh is not None else None, cout, cin, L.stream_ptr()))
+            self._conv_handles["1x1:" + wname] = h
+        return h
+
+    def _hip_conv1x1_ok(self, wname, H, W, cuda):
+        cout, cin = self.sd[wname].shape[:2]
+        return self.use_hip_conv and cuda and cout in (64, 128, 256) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0 and tuple(self.sd[wname].shape[2:]) == (1, 1)
+
+    def _conv1x1(self, x, wname, bname=None, gn=None, res=None, want_stats=False):
+        """1 x 1 convolution (+ bias) of a channels-last tensor on the split-f16 kernel (vt_conv1x1_forward).  ``gn`` = (stats workspace, norm name):
+        GroupNorm(32) + ReLU of the INPUT with those {mean, rstd} pairs, applied while the operand is staged; ``res``: tensor added to the result;
+        ``want_stats``: also return the workspace holding the GroupNorm statistics of the OUTPUT ({mean, rstd} pairs after vt_groupnorm_finalize)."""
+        sd, lib = self.sd, L.lib()
+        B, Cin, H, W = x.shape
+        cout = sd[wname].shape[0]
+        x = x.contiguous(memory_format=torch.channels_last)
+        out = torch.empty(B, cout, H, W, device=x.device, memory_format=torch.channels_last)
+        if res is not None:
+            res = res.contiguous(memory_format=torch.channels_last)
+        ws_out = None
+        if want_stats:
+            tiles = lib.vt_conv3x3_tiles(H, W)
+            ws_out = torch.empty(B * 32 + tiles * B * cout * 2, dtype=torch.float64, device=x.device)
+        L.check(lib.vt_conv1x1_forward(self._conv1x1_handle(wname, bname, x.device), x.data_ptr(), Cin, 0,
+                                       gn[0].data_ptr() if gn else None, sd[gn[1] + ".weight"].data_ptr() if gn else None, sd[gn[1] + ".bias"].data_ptr() if gn else None, 32,
+                                       B, H, W, out.data_ptr(), cout, 0, res.data_ptr() if res is not None else None, cout, 0,
+                                       ws_out.data_ptr() if want_stats else None, 32, L.stream_ptr()))
+        if want_stats:
+            L.check(lib.vt_groupnorm_finalize(ws_out.data_ptr(), tiles, B, H * W, cout, 32, 1e-5, L.stream_ptr()))
+            return out, ws_out
+        return out
 
     def _hip_conv_ok(self, name, H, W, cuda):
         cout, cin = self.sd[name].shape[:2]
@@ -155,16 +196,20 @@ class HGFilterEncoder:
         sd, lib = self.sd, L.lib()
         B, Cin, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)
-        res = x
-        if p + "downsample.2.weight" in sd:         # see _conv_block: Sequential(bn4, ReLU, conv1x1)
-            res = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"]).contiguous(memory_format=torch.channels_last)
         Ct, Cr = sum(couts), couts[0] + couts[1]
-        assert res.shape[1] == Ct
-        raw = torch.empty(B, Cr, H, W, device=x.device, memory_format=torch.channels_last)
-        fin = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)
         tiles = lib.vt_conv3x3_tiles(H, W)
         ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, Cin, 32), dtype=torch.float64, device=x.device)
         L.check(lib.vt_groupnorm_stats(x.data_ptr(), Cin, 0, B, H * W, Cin, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+        res = x
+        if p + "downsample.2.weight" in sd:         # see _conv_block: Sequential(bn4, ReLU, conv1x1)
+            if self._hip_conv1x1_ok(p + "downsample.2.weight", H, W, True):
+                # the projection's GroupNorm normalises the same tensor as bn1: same {mean, rstd}, its own gamma / beta, fused into the staging
+                res = self._conv1x1(x, p + "downsample.2.weight", None, gn=(ws, p + "downsample.0"))
+            else:
+                res = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"]).contiguous(memory_format=torch.channels_last)
+        assert res.shape[1] == Ct
+        raw = torch.empty(B, Cr, H, W, device=x.device, memory_format=torch.channels_last)
+        fin = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)
         src, cstride, coff, C, off = x, Cin, 0, Cin, 0
         for i, co in zip((1, 2, 3), couts):
             wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
@@ -201,6 +246,18 @@ class HGFilterEncoder:
         outputs = []
         for i in range(self.num_stack):
             ll = self._conv_block(self._hourglass(self.depth, previous, f"m{i}."), f"top_m_{i}.")
+            H, W = ll.shape[2:]
+            names = [f"conv_last{i}.weight", f"l{i}.weight"] + ([f"bl{i}.weight", f"al{i}.weight"] if i < self.num_stack - 1 else [])
+            if ll.is_cuda and all(self._hip_conv1x1_ok(n, H, W, True) for n in names):
+                # the tail of a stack as four launches of the 1 x 1 kernel: conv_last leaves the statistics of its output behind, bn_end + ReLU is
+                # applied in the operand staging of its two consumers (l, bl), and `previous + bl(ll) + al(out)` is the residual input of bl and al
+                raw, ws = self._conv1x1(ll, f"conv_last{i}.weight", f"conv_last{i}.bias", want_stats=True)
+                out = self._conv1x1(raw, f"l{i}.weight", f"l{i}.bias", gn=(ws, f"bn_end{i}"))
+                outputs.append(out)
+                if i < self.num_stack - 1:
+                    tmp = self._conv1x1(raw, f"bl{i}.weight", f"bl{i}.bias", gn=(ws, f"bn_end{i}"), res=previous)
+                    previous = self._conv1x1(out, f"al{i}.weight", f"al{i}.bias", res=tmp)
+                continue
             ll = _gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}", relu=True)
             out = F.conv2d(ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
             outputs.append(out)
