@@ -241,6 +241,41 @@ int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *
                           float *df_target, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Fused heads / tails of one Adam step of the two fit loops (the vt_objfit_step / vt_smplfit_step of SURVEY.md 8(b)): the arithmetic of the
+ * single-purpose entry points below, element for element and in the same order, in 4 launches per object-stage step (head, query, stencils,
+ * tail) and one tail per SMPL-stage step.  `terms` (device fp64), `w` (host, per-term weights), `state`, `stop_flag`, `history`, `slot`, `tol`,
+ * `armed` as in vt_loss_reduce_and_stop; `ticket`: one zero-initialised device int per fit loop; the workgroup that finishes last closes the step
+ * (loss, history, the reference's stop rule recon_fit_trivis_full.py:372 / recon_fit_behave.py:447) and zeroes terms[0, nzero).
+ *   vt_objstep_head   R = project_so3(M0 + 1e-4 noise) (recon_fit_base.py:179-199,462-469); X = (X0 R + t) s for the surface points and, if X_verts
+ *                     != NULL, the template vertices (recon_fit_base.py:455-459); terms[0, nzero) = 0
+ *   vt_temporal_loss2 vt_accel_loss then vt_velocity_loss of (B, D) in one pass; init_zero: dv is written, not accumulated
+ *   vt_objstep_tail   rigid VJP over the vertex set (dX_verts != NULL: phase 'sil') and the points, the translation regulariser
+ *                     mean (t - t_init)^2 (t_init != NULL; recon_fit_trivis_full.py:227), SO(3) VJP, Adam (torch.optim.Adam) on pR (B,9) / pT (B,3)
+ *                     (NULL: that group is not optimised), step end
+ *   vt_smplstep_tail  body-pose prior th_Mahalanobis on pose[:, 3:66] (th_smpl_prior.py:30-38; gscale_prior = w / B), pinit term mean_B sum
+ *                     (pose[:, 3:72] - pose_init)^2 (recon_fit_behave.py:500-503), Adam on up to three column slices (p, stride, g, stride, m, v,
+ *                     columns, lr; p == NULL: unused), step end
+ * ------------------------------------------------------------------------------------------------- */
+int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
+                    const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, void *stream);
+int vt_temporal_loss2(const float *v, int B, int D, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, float *dv,
+                      int init_zero, void *stream);
+int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_verts, const float *X0_points, int N, const float *dX_points, const float *s, int B,
+                    const float *M0, const float *noise, const float *t, const float *t_init, float w_trans, double *term_trans,
+                    float *dR, float *dt, float *dM,
+                    float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
+                    double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                    void *stream);
+int vt_smplstep_tail(float *pose, const float *pose_init, float *dpose, int B, const float *prior_mean, const float *prior_prec, float gscale_prior,
+                     double *term_prior, float w_pinit, double *term_pinit,
+                     float *p0, int ps0, const float *g0, int gs0, float *m0, float *v0, int n0, float lr0,
+                     float *p1, int ps1, const float *g1, int gs1, float *m1, float *v1, int n1, float lr1,
+                     float *p2, int ps2, const float *g2, int gs2, float *m2, float *v2, int n2, float lr2,
+                     int adam_step, float beta1, float beta2, float eps,
+                     double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * SO(3) projection.  Replaces ReconFitterBase.project_so3 / decopose_axis (recon/recon_fit_base.py:179-199,
  * 462-469): R = U diag(1,1,det(U V^T)) V^T of M; noise (B,3,3) or NULL is the U[0,1) sample, M = M0 + 1e-4*noise.
  * ------------------------------------------------------------------------------------------------- */

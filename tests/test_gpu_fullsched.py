@@ -176,3 +176,34 @@ def test_full_schedule_object_stage_vs_oracle(synth, with_sil):
         # path started 1e-6 m away 4.7e-3 m.  The bar is therefore the path's own sensitivity: the oracle must be no further from the HIP result
         # than twice what a 1e-6 m perturbation of the start does to it (floor 1.5e-3 m), and never beyond 1e-2 m
         assert mean < 2 * max(self_mean, 1.5e-3) and mean < 1e-2, f"HIP vs oracle mean {mean:.3e} m (max {mx:.3e}); HIP vs HIP from 1e-6 m away {self_mean:.3e} m"
+
+
+def test_fused_step_launches_are_bit_identical(synth):
+    """The fused heads / tails of an Adam step (vt_objstep_head, vt_temporal_loss2, vt_objstep_tail, vt_smplstep_tail) are the single-purpose launches'
+    arithmetic in the same order: the optimised parameters of both stages -- all phases, incl. the stop rule -- come out bit for bit the same, the
+    loss histories agree to the last bits of the fp64 term sums (the per-frame shares of a term are added in a different order)."""
+    from conftest import golden
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext
+    B, N = 4, 600
+    c = _object_case(synth, B, N, seed=17)
+    kw = dict(iter_for_obj=3, iter_for_sil=3, joint_iter=2, max_iter=8)
+    nsteps = (kw["iter_for_obj"] + kw["iter_for_sil"] + kw["joint_iter"] + kw["max_iter"]) * 10
+    noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
+    g = golden("smplfit")
+    out = []
+    for fused in (True, False):
+        ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], c["ov"], c["of"], c["pts"])
+        ctx.fused_steps = fused
+        res, R, t = _run_hip_object(ctx, ops.FeatureMaps.from_nchw(c["mp"]), c, noise, c["t0"], **kw)
+        maps = ops.FeatureMaps.from_nchw(syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+        pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+        r1 = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 6))
+        out.append((R, t, res.losses, res.steps, pose.cpu().numpy(), betas.cpu().numpy(), trans.cpu().numpy(), r1.losses, r1.steps))
+    a, b = out
+    assert a[3] == b[3] and a[8] == b[8], (a[3], b[3], a[8], b[8])
+    for k in (0, 1, 4, 5, 6):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    for k in (2, 7):
+        fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
+        assert np.array_equal(fa, fb) and np.allclose(a[k][fa], b[k][fb], rtol=2e-6, atol=0)

@@ -336,6 +336,43 @@ def test_silhouette(hip):
     assert rel(npy(v.grad), dv_o) < 2e-3
 
 
+def test_silhouette_per_call_at_bench_size(hip):
+    """ONE vt_sil_forward / vt_sil_backward call against the oracle at the size the fit runs it (B = 96 frames, 256 x 256 ROI, the 2500-face
+    chairwood-size template at 96 random poses, the object filling the crop like SilLossROI's box does, obj_pose_roi.py:77-94,183-202): the
+    agreement per CALL -- pixel disagreements per frame, gradient cosine and relative error per frame -- pinned at bench size instead of
+    inferred from trajectories.  Oracle and kernel are two independent writings of neural_renderer's rule (scan-line over all faces vs
+    scatter rasteriser + edge sweeps); what may differ are fp32 edge ties (a pixel centre within round-off of an edge)."""
+    from oracle import oracle as O
+    from vistracker_amd import synthetic as syn
+    ops = hip["ops"]
+    B = 96
+    rng = np.random.default_rng(31)
+    verts0, faces = syn.object_template()
+    R = syn.random_rotations(B, rng); t = (rng.normal(0, 0.15, (B, 3)) + [0, 0, 2.4]).astype(np.float32)
+    verts = (np.einsum("nc,bcd->bnd", verts0, R) + t[:, None]).astype(np.float32)
+    # ROI intrinsics: a square box 1.3 x the projected extent around the projected centre (the role of SilLossROI's crop)
+    ext = (np.abs(verts0).max() * 1.3 / t[:, 2]).astype(np.float32)
+    K = np.zeros((B, 9), np.float32)
+    K[:, 0] = K[:, 4] = 0.5 / ext; K[:, 2] = 0.5 - K[:, 0] * t[:, 0] / t[:, 2]; K[:, 5] = 0.5 - K[:, 4] * t[:, 1] / t[:, 2]; K[:, 8] = 1
+    img_o = O.sil_forward(verts, faces, K, 256)
+    cover = img_o.reshape(B, -1).mean(1)
+    assert 0.08 < cover.min() and cover.max() < 0.9, (cover.min(), cover.max())          # every frame shows the object, none fills the crop
+    v = cu(verts).requires_grad_(True)
+    img = ops.silhouette(v, cu(faces), cu(K), 256)
+    bad = (npy(img) != img_o).reshape(B, -1).sum(1)
+    assert bad.max() <= 3 and bad.sum() <= 24, f"pixel disagreements per frame: max {bad.max()}, total {bad.sum()} of {B * 65536}"
+    # upstream gradient of the mask term of phase 'sil': rendered minus a reference silhouette shifted by a few pixels, half of the crop occluded
+    ref = np.roll(img_o, (3, -4), axis=(1, 2)); keep = np.ones_like(ref); keep[:, 96:160, :80] = 0
+    gimg = (2 * (img_o * keep - ref * keep) * keep / (256 * 256)).astype(np.float32)
+    (img * cu(gimg)).sum().backward()
+    dv = npy(v.grad); dv_o = O.sil_backward(verts, faces, K, gimg, 256, 1e-4)
+    num = (dv * dv_o).reshape(B, -1).sum(1); den = np.linalg.norm(dv.reshape(B, -1), axis=1) * np.linalg.norm(dv_o.reshape(B, -1), axis=1)
+    cos = num / np.maximum(den, 1e-30)
+    relf = np.abs(dv - dv_o).reshape(B, -1).max(1) / np.abs(dv_o).reshape(B, -1).max(1)
+    assert np.all(den > 0) and cos.min() > 0.9999 and np.median(relf) < 2e-3 and relf.max() < 5e-2, \
+        f"per-frame gradient cosine min {cos.min():.6f}; relative max error median {np.median(relf):.2e}, worst frame {relf.max():.2e}"
+
+
 def test_adam(hip):
     g = golden("adam"); ops = hip["ops"]
     p = cu(g["p0"].copy()); opt = ops.FusedAdam([p], lr=float(g["lr"]))

@@ -64,6 +64,14 @@ SIGNATURES = {
     "vt_groupnorm_workspace_doubles": (C.c_long, [ci, ci, ci, ci]),
     "vt_groupnorm_finalize": (ci, [fp, ci, ci, ci, ci, ci, cf, vp]),
     "vt_conv3x3_tiles": (ci, [ci, ci]),
+    "vt_objstep_head": (ci, [fp, fp, fp, fp, ci, fp, ci, fp, fp, ci, fp, fp, fp, ci, vp]),
+    "vt_temporal_loss2": (ci, [fp, ci, ci, cf, fp, cf, fp, fp, ci, vp]),
+    "vt_objstep_tail": (ci, [fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,
+                             fp, fp, fp, cf, fp, fp, fp, cf, ci, cf, cf, cf,
+                             fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
+    "vt_smplstep_tail": (ci, [fp, fp, fp, ci, fp, fp, cf, fp, cf, fp,
+                              fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, ci, cf, cf, cf,
+                              fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
     "vt_conv1x1_create": (ci, [C.POINTER(vp), vp, vp, ci, ci, vp]),
     "vt_conv1x1_destroy": (None, [vp]),
     "vt_conv1x1_forward": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),

@@ -734,3 +734,314 @@ extern "C" int vt_loss_reduce_and_stop(const double *terms, const float *w, int 
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
+
+// =====================================================================================================================
+// Fused heads / tails of an Adam step of the two fit loops (vt_objfit_step / vt_smplfit_step).  A step of the object stage
+// used to be ~11 launches of 4-16 us kernels around the one query launch (SO(3) projection, rigid transform, two temporal stencils, rigid VJP,
+// SO(3) VJP, one Adam launch per parameter group, loss reduction, term zeroing); the same arithmetic, element for element and in the same
+// order, now runs as head -> query -> stencils -> tail.  Per-frame work is done by the workgroup of the frame; what needs every frame (loss
+// reduction, stop rule, zeroing the term accumulators for the next step) is done by whichever workgroup finishes LAST (ticket counter), after
+// every other workgroup has read the stop flag and stepped its parameters.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restrict__ M0, const float *__restrict__ noise, const float *__restrict__ t,
+                                                           const float *__restrict__ s, const float *__restrict__ X0p, int N, float *__restrict__ Xp,
+                                                           const float *__restrict__ X0v, int NV, float *__restrict__ Xv, float *__restrict__ Rout,
+                                                           double *terms, int nzero)
+{
+    __shared__ float sR[9];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float M[9]; Svd3 sv;
+#pragma unroll
+        for (int e = 0; e < 9; e++) M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f);
+        svd3(M, sv);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) sR[3 * r + c] = sv.U[3 * r] * sv.V[3 * c] + sv.U[3 * r + 1] * sv.V[3 * c + 1] + sv.d * sv.U[3 * r + 2] * sv.V[3 * c + 2];
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int e = 0; e < 9; e++) Rout[9 * b + e] = sR[e];
+        }
+    }
+    if (blockIdx.x == 0 && b == 0 && terms && (int)threadIdx.x < nzero) terms[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const float sc = s[b], t0 = t[3 * b], t1 = t[3 * b + 1], t2 = t[3 * b + 2];
+    const float tt[3] = {t0, t1, t2};
+    if (n < N) {
+        const float *x = X0p + (size_t)n * 3; const float x0 = x[0], x1 = x[1], x2 = x[2];
+        float *o = Xp + ((size_t)b * N + n) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[c] = (x0 * sR[c] + x1 * sR[3 + c] + x2 * sR[6 + c] + tt[c]) * sc;
+    }
+    if (Xv && n < NV) {
+        const float *x = X0v + (size_t)n * 3; const float x0 = x[0], x1 = x[1], x2 = x[2];
+        float *o = Xv + ((size_t)b * NV + n) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[c] = (x0 * sR[c] + x1 * sR[3 + c] + x2 * sR[6 + c] + tt[c]) * sc;
+    }
+}
+extern "C" int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
+                               const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, void *stream)
+{
+    VT_REQUIRE(M0 && t && s && X0_points && X_points && R && B > 0 && N > 0 && (!X_verts || (X0_verts && NV > 0)) && nzero >= 0 && nzero <= 16, "vt_objstep_head: bad argument");
+    const int nmax = X_verts ? max(N, NV) : N;
+    hipLaunchKernelGGL(objstep_head_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, vt_stream(stream), M0, noise, t, s, X0_points, N, X_points, X0_verts, NV, X_verts,
+                       R, terms, nzero);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// acceleration + velocity stencils of (B, D) in one pass: dv (+)= gs_a (2 a_0 - a_m - a_p), then += gs_v (d_0 - d_1) -- the two updates of
+// vt_accel_loss and vt_velocity_loss in their order; init_zero: dv starts from zero (phase 'sil': no query gradient, no fill launch)
+__global__ __launch_bounds__(256) void temporal2_kernel(const float *__restrict__ v, int B, int D, float gs_a, double *term_a, float gs_v, double *term_v,
+                                                        float *__restrict__ dv, int init_zero)
+{
+    __shared__ double red[4];
+    double acc_a = 0, acc_v = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < B * D; t += gridDim.x * 256) {
+        const int f = t / D, i = t - f * D;
+        auto at = [&](int b) { return v[(size_t)min(max(b, 0), B - 1) * D + i]; };
+        const float vm2 = at(f - 2), vm1 = at(f - 1), v0 = at(f), vp1 = at(f + 1), vp2 = at(f + 2);
+        const float a_m = (f - 1 >= 1 && f - 1 <= B - 2) ? 2.f * vm1 - vm2 - v0 : 0.f;
+        const float a_0 = (f >= 1 && f <= B - 2) ? 2.f * v0 - vm1 - vp1 : 0.f;
+        const float a_p = (f + 1 >= 1 && f + 1 <= B - 2) ? 2.f * vp1 - v0 - vp2 : 0.f;
+        acc_a += (double)(1.f * a_0 * a_0);
+        float g = init_zero ? 0.f : dv[(size_t)f * D + i];
+        g += gs_a * 1.f * (2.f * a_0 - a_m - a_p);
+        const float d0 = f >= 1 ? v0 - vm1 : 0.f;
+        const float d1 = f + 1 < B ? vp1 - v0 : 0.f;
+        acc_v += (double)(d0 * d0);
+        g += gs_v * (d0 - d1);
+        dv[(size_t)f * D + i] = g;
+    }
+    term_add(acc_a / ((double)(B - 2) * D), term_a, red);
+    term_add(acc_v / ((double)(B - 1) * D), term_v, red);
+}
+extern "C" int vt_temporal_loss2(const float *v, int B, int D, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, float *dv,
+                                 int init_zero, void *stream)
+{
+    VT_REQUIRE(v && dv && B >= 3 && D > 0, "vt_temporal_loss2: bad argument (B >= 3)");
+    // derivative scales as in vt_accel_loss / vt_velocity_loss: d/dv of mean(a^2) resp. mean(d^2)
+    const float gs_a = 2.f * gscale_accel / ((float)(B - 2) * (float)D), gs_v = 2.f * gscale_velocity / ((float)(B - 1) * (float)D);
+    hipLaunchKernelGGL(temporal2_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, gs_a, term_accel, gs_v, term_velocity, dv, init_zero);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+struct AdamSlice { float *p; int pstride; const float *g; int gstride; float *m, *v; int ncols; float step_size; };
+struct StepEnd {
+    const double *terms_r; double *terms_w; TermW tw; int nterms; float tol; int armed; float *state; int *stop_flag; float *history; int slot;
+    int *ticket; int nzero;
+};
+// Adam on column c of row b of a slice (the arithmetic of adam2d_kernel)
+__device__ __forceinline__ void adam_one(const AdamSlice &a, int b, int c, float bc2s, float beta1, float beta2, float eps)
+{
+    const int i = b * a.ncols + c;
+    const float gi = a.g[(size_t)b * a.gstride + c];
+    const float mi = a.m[i] * beta1 + (1.f - beta1) * gi;
+    const float vi = a.v[i] * beta2 + (1.f - beta2) * gi * gi;
+    a.m[i] = mi; a.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    a.p[(size_t)b * a.pstride + c] = a.p[(size_t)b * a.pstride + c] - a.step_size * (mi / denom);
+}
+// the workgroup that takes the last ticket closes the step: weighted loss, history, the reference's stop rule (loss_reduce_kernel), and the term
+// accumulators [0, nzero) zeroed for the next step.  Every other workgroup has finished (its writes fenced) by then.
+__device__ __forceinline__ void step_end(const StepEnd &e, int nblocks, bool stopped)
+{
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = (atomicAdd(e.ticket, 1) == nblocks - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        *e.ticket = 0;
+        if (stopped) { if (e.history) e.history[e.slot] = nanf(""); }
+        else {
+            double l = 0;
+            for (int k = 0; k < e.nterms; k++) l += (double)e.tw.w[k] * __hip_atomic_load(e.terms_r + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float loss = (float)l, prev = e.state[0];
+            if (e.history) e.history[e.slot] = loss;
+            if (e.armed && e.stop_flag && (fabsf(prev - loss) / prev < prev * e.tol)) *e.stop_flag = 1;
+            e.state[0] = loss; e.state[1] = loss;
+        }
+        for (int k = 0; k < e.nzero; k++) e.terms_w[k] = 0.0;
+    }
+}
+
+// tail of an object-stage step, one workgroup per frame: rigid VJP over the vertex set (phase 'sil') and the surface points, the translation
+// regulariser of phase 'sil', the SO(3) VJP, Adam on the frame's rotation parameters (9) and translation (3), then step_end
+__global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restrict__ X0v, int NV, const float *__restrict__ dXv, const float *__restrict__ X0p, int N,
+                                                           const float *__restrict__ dXp, const float *__restrict__ s, const float *__restrict__ M0,
+                                                           const float *__restrict__ noise, const float *__restrict__ tpar, const float *__restrict__ t_init,
+                                                           float w_trans, double *term_trans, float *__restrict__ dR, float *__restrict__ dt, float *__restrict__ dM,
+                                                           AdamSlice aR, AdamSlice aT, float bc2s, float beta1, float beta2, float eps, StepEnd end)
+{
+    __shared__ float red[4];
+    __shared__ float sG[12];
+    const int b = blockIdx.x, B = gridDim.x;
+    const bool stopped = end.stop_flag && *end.stop_flag;          // read before any workgroup can close the step
+    const float sc = s[b];
+    float tot[12];
+#pragma unroll
+    for (int e = 0; e < 12; e++) tot[e] = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const float *X0 = pass == 0 ? X0v : X0p; const float *dX = pass == 0 ? dXv : dXp; const int n_ = pass == 0 ? NV : N;
+        if (!dX) continue;
+        float a[12];
+#pragma unroll
+        for (int e = 0; e < 12; e++) a[e] = 0.f;
+        for (int n = threadIdx.x; n < n_; n += 256) {
+            const float *x = X0 + (size_t)n * 3, *g = dX + ((size_t)b * n_ + n) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
+        }
+#pragma unroll
+        for (int e = 0; e < 12; e++) { const float v = block_sum<4>(a[e], red); tot[e] = (pass == 0 || !dXv) ? v : tot[e] + v; }     // rigid_bwd_kernel: first set written, second accumulated
+        if (pass == 0 && t_init) {
+            // trans = mean_{B,3} (t - t_init)^2  (vt_sqdiff_loss with denom 3 B) adds its gradient to dt BETWEEN the two rigid VJPs in the unfused
+            // sequence (vertex set, regulariser, surface points): same order of the three float additions here
+            const float inv_denom = 1.f / (float)(3 * B);
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float d = tpar[3 * b + c] - t_init[3 * b + c]; tot[9 + c] += 2.f * d * inv_denom * w_trans; }
+        }
+    }
+    if (threadIdx.x == 0) {
+        float g[12];
+#pragma unroll
+        for (int e = 0; e < 12; e++) g[e] = tot[e];
+        if (t_init) {
+            const float inv_denom = 1.f / (float)(3 * B);
+            double acc = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float d = tpar[3 * b + c] - t_init[3 * b + c]; acc += (double)(d * d); }
+            atomicAdd(term_trans, acc * (double)inv_denom);        // the frame's share of the term
+        }
+        // SO(3) VJP (so3_bwd_kernel)
+        float M[9], G[9]; Svd3 sv;
+#pragma unroll
+        for (int e = 0; e < 9; e++) { M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f); G[e] = g[e]; }
+        svd3(M, sv);
+        const float D[3] = {1.f, 1.f, sv.d}, h[3] = {sv.s[0], sv.s[1], sv.d * sv.s[2]};
+        float UtG[9], Q[9], Z[9], UDZ[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) UtG[3 * r + c] = sv.U[r] * G[c] + sv.U[3 + r] * G[3 + c] + sv.U[6 + r] * G[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Q[3 * r + c] = D[r] * (UtG[3 * r] * sv.V[c] + UtG[3 * r + 1] * sv.V[3 + c] + UtG[3 * r + 2] * sv.V[6 + c]);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Z[3 * r + c] = (r == c) ? 0.f : (Q[3 * r + c] - Q[3 * c + r]) / (h[r] + h[c]);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) UDZ[3 * r + c] = sv.U[3 * r] * D[0] * Z[c] + sv.U[3 * r + 1] * D[1] * Z[3 + c] + sv.U[3 * r + 2] * D[2] * Z[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float v = UDZ[3 * r] * sv.V[3 * c] + UDZ[3 * r + 1] * sv.V[3 * c + 1] + UDZ[3 * r + 2] * sv.V[3 * c + 2]; dM[9 * b + 3 * r + c] = v; sG[3 * r + c] = v; }
+#pragma unroll
+        for (int e = 0; e < 9; e++) dR[9 * b + e] = g[e];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { dt[3 * b + c] = g[9 + c]; sG[9 + c] = g[9 + c]; }
+    }
+    __syncthreads();
+    if (!stopped) {
+        // Adam reads the gradients the way adam2d_kernel does: from the gradient tensors (dM, dt) just written by thread 0 of this workgroup
+        if (aR.p && threadIdx.x < 9) adam_one(aR, b, threadIdx.x, bc2s, beta1, beta2, eps);
+        if (aT.p && threadIdx.x >= 64 && threadIdx.x < 67) adam_one(aT, b, threadIdx.x - 64, bc2s, beta1, beta2, eps);
+    }
+    step_end(end, B, stopped);
+}
+static StepEnd make_end(double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero)
+{
+    StepEnd e; e.terms_r = terms; e.terms_w = terms; e.nterms = nterms; e.tol = tol; e.armed = armed; e.state = state; e.stop_flag = stop_flag; e.history = history; e.slot = slot;
+    e.ticket = ticket; e.nzero = nzero;
+    for (int k = 0; k < 16; k++) e.tw.w[k] = k < nterms ? w[k] : 0.f;
+    return e;
+}
+extern "C" int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_verts, const float *X0_points, int N, const float *dX_points, const float *s, int B,
+                               const float *M0, const float *noise, const float *t, const float *t_init, float w_trans, double *term_trans,
+                               float *dR, float *dt, float *dM,
+                               float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
+                               double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                               void *stream)
+{
+    VT_REQUIRE(X0_points && dX_points && s && M0 && t && dR && dt && dM && B > 0 && N > 0 && (!dX_verts || (X0_verts && NV > 0)) && (!t_init || term_trans), "vt_objstep_tail: bad argument");
+    VT_REQUIRE(terms && w && state && ticket && nterms > 0 && nterms <= 16 && nzero >= 0 && nzero <= nterms && adam_step >= 1 && (!pR || (mR && vR)) && (!pT || (mT && vT)),
+               "vt_objstep_tail: bad optimiser / loss arguments");
+    const double bc1 = 1.0 - pow((double)beta1, adam_step), bc2 = 1.0 - pow((double)beta2, adam_step);
+    AdamSlice aR = {pR, 9, dM, 9, mR, vR, 9, (float)(lrR / bc1)}, aT = {pT, 3, dt, 3, mT, vT, 3, (float)(lrT / bc1)};
+    hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
+                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+
+// tail of a SMPL-stage step, one 64-thread workgroup per frame: body-pose prior (mahalanobis_kernel, n = 63 at pose[:, 3:66]) with its gradient,
+// the pose-initialisation term mean_B sum (pose[:, 3:72] - pose_init)^2 (vt_sqdiff_loss), Adam on up to three column slices, step_end
+__global__ __launch_bounds__(64) void smplstep_tail_kernel(float *__restrict__ pose, const float *__restrict__ pose_init, float *__restrict__ dpose,
+                                                           const float *__restrict__ mean, const float *__restrict__ prec, float gscale, double *term_prior,
+                                                           float w_pinit, double *term_pinit, AdamSlice a0, AdamSlice a1, AdamSlice a2, float bc2s, float beta1,
+                                                           float beta2, float eps, StepEnd end)
+{
+    __shared__ float d[64], t2[64];
+    const int b = blockIdx.x, B = gridDim.x, j = threadIdx.x, n = 63, off = 3, stride = 156;
+    const bool stopped = end.stop_flag && *end.stop_flag;
+    d[j] = (j < n) ? pose[(size_t)b * stride + off + j] - mean[j] : 0.f;
+    __syncthreads();
+    float a = 0.f;
+    if (j < n) for (int i = 0; i < n; i++) a += d[i] * prec[i * n + j];
+    t2[j] = a;
+    const float val = wave_sum(a * a);
+    __syncthreads();
+    if (j < n) {
+        float g = 0.f;
+        for (int k = 0; k < n; k++) g += t2[k] * prec[j * n + k];
+        dpose[(size_t)b * stride + off + j] += 2.f * g * gscale;
+    }
+    // pinit over columns 3 .. 71 (69 of them): thread j takes columns j and j + 64
+    double acc = 0;
+    const float inv_denom = 1.f / (float)B;
+    for (int c = j; c < 69; c += 64) {
+        const float dd = pose[(size_t)b * stride + 3 + c] - pose_init[(size_t)b * stride + 3 + c];
+        acc += (double)(dd * dd);
+        dpose[(size_t)b * stride + 3 + c] += 2.f * dd * inv_denom * w_pinit;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (j == 0) { atomicAdd(term_pinit, acc * (double)inv_denom); atomicAdd(term_prior, (double)val / (double)B); }
+    __syncthreads();          // the frame's gradients are complete (same workgroup wrote them)
+    if (!stopped) {
+        const AdamSlice *sl[3] = {&a0, &a1, &a2};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (sl[k]->p) for (int c = j; c < sl[k]->ncols; c += 64) adam_one(*sl[k], b, c, bc2s, beta1, beta2, eps);
+    }
+    step_end(end, B, stopped);
+}
+extern "C" int vt_smplstep_tail(float *pose, const float *pose_init, float *dpose, int B, const float *prior_mean, const float *prior_prec, float gscale_prior,
+                                double *term_prior, float w_pinit, double *term_pinit,
+                                float *p0, int ps0, const float *g0, int gs0, float *m0, float *v0, int n0, float lr0,
+                                float *p1, int ps1, const float *g1, int gs1, float *m1, float *v1, int n1, float lr1,
+                                float *p2, int ps2, const float *g2, int gs2, float *m2, float *v2, int n2, float lr2,
+                                int adam_step, float beta1, float beta2, float eps,
+                                double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                                void *stream)
+{
+    VT_REQUIRE(pose && pose_init && dpose && prior_mean && prior_prec && term_prior && term_pinit && B > 0 && adam_step >= 1, "vt_smplstep_tail: bad argument");
+    VT_REQUIRE(terms && w && state && ticket && nterms > 0 && nterms <= 16 && nzero >= 0 && nzero <= nterms, "vt_smplstep_tail: bad loss arguments");
+    const double bc1 = 1.0 - pow((double)beta1, adam_step), bc2 = 1.0 - pow((double)beta2, adam_step);
+    AdamSlice a0 = {p0, ps0, g0, gs0, m0, v0, n0, (float)(lr0 / bc1)}, a1 = {p1, ps1, g1, gs1, m1, v1, n1, (float)(lr1 / bc1)}, a2 = {p2, ps2, g2, gs2, m2, v2, n2, (float)(lr2 / bc1)};
+    hipLaunchKernelGGL(smplstep_tail_kernel, dim3(B), dim3(64), 0, vt_stream(stream), pose, pose_init, dpose, prior_mean, prior_prec, gscale_prior, term_prior, w_pinit, term_pinit,
+                       a0, a1, a2, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

@@ -13,6 +13,7 @@ prior gradient.  Loss VALUES keep every term the reference sums (the early-stop 
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from dataclasses import dataclass, field
 
@@ -167,6 +168,10 @@ class FitContext:
     # human / object interpenetration term of phase 'joint' (recon_fit_base.py:736-765).  The reference computes it only on two machines of its
     # authors' cluster (hostname test, recon_fit_base.py:106); off here too unless switched on.
     collision_loss = False
+    # heads / tails of an Adam step as fused launches (vt_objstep_head / vt_temporal_loss2 / vt_objstep_tail / vt_smplstep_tail: 4 launches around the
+    # query per object-stage step instead of ~11, one tail instead of 8 in the SMPL stage); False = the single-purpose launches (same arithmetic in
+    # the same order: the trajectories are bit-identical, tests/test_gpu_fit.py)
+    fused_steps = os.environ.get("VT_FUSED_STEPS", "1") != "0"
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -347,6 +352,7 @@ class FitContext:
         pose_init = pose.clone()
         stop = torch.zeros(1, dtype=torch.int32, device=dev)
         state = torch.tensor([300.0, 300.0], device=dev)          # prev_loss = 300 (recon_fit_behave.py:408)
+        fused = bool(self.fused_steps); ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         if self.sort_query_points:
             # processing order for this batch: Morton order of the IMAGE positions of the initial vertices of the middle frame (the body moves
             # little inside a batch and during the fit); a little better than the template's 3-D order because the perspective maps -- the
@@ -373,7 +379,8 @@ class FitContext:
             decay = 1 if phase != "kpts" else it / 3
             w = terms.weights(FIT_WEIGHTS, decay)
             for i in range(10):
-                terms.zero(0, 6)
+                if not fused:
+                    terms.zero(0, 6)        # (fused: the tail of the previous step left them zeroed)
                 self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
                 ev = _ev_begin(prof)
                 _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
@@ -388,13 +395,28 @@ class FitContext:
                 if B >= 4:
                     _chk(_lib().vt_accel_loss(verts.data_ptr(), B, V * 3, None, float(w[5]), terms.ptr("stemp"), dverts.data_ptr(), L.stream_ptr()))
                 self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
-                self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
-                # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
-                _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
-                                           terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
-                adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(),
-                                                    stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
+                if fused:
+                    # body prior + pinit + Adam on every group + loss reduction / stop rule + term zeroing: one launch
+                    adam.t += 1
+                    sl = []
+                    for k in range(3):
+                        if k < len(adam.slices):
+                            (p_, n_, g_, lr_), m_, v_ = adam.slices[k], adam.m[k], adam.v[k]
+                            sl += [p_.data_ptr(), p_.shape[1], g_.data_ptr(), g_.shape[1], m_.data_ptr(), v_.data_ptr(), n_, lr_]
+                        else:
+                            sl += [None, 0, None, 0, None, None, 0, 0.0]
+                    _chk(_lib().vt_smplstep_tail(pose.data_ptr(), pose_init.data_ptr(), dpose.data_ptr(), B, self.pri["body_mean"].data_ptr(), self.pri["body_prec"].data_ptr(),
+                                                 float(w[2]) / B, terms.ptr("pose"), float(w[3]), terms.ptr("pinit"), *sl, adam.t, 0.9, 0.999, 1e-8,
+                                                 terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(), stop.data_ptr(),
+                                                 hist.data_ptr(), (it - start) * 10 + i, ticket.data_ptr(), 6, L.stream_ptr()))
+                else:
+                    self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
+                    # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
+                    _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
+                                               terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
+                    adam.step()
+                    _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(),
+                                                        stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                 res.steps += 1
             res.outer_iters += 1
             if (it - start) % check_every == check_every - 1 and int(stop.item()):
@@ -438,6 +460,7 @@ class FitContext:
         R = torch.empty(B, 3, 3, device=dev); X = torch.empty(B, N, 3, device=dev); dX = torch.empty_like(X)
         dR = torch.empty(B, 3, 3, device=dev); dM = torch.empty(B, 3, 3, device=dev); dt = torch.empty(B, 3, device=dev)
         stop = torch.zeros(1, dtype=torch.int32, device=dev); state = torch.tensor([300.0, 300.0], device=dev)
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         hist = torch.full((nsteps,), float("nan"), device=dev)
         Rv, tv = obj_R.view(B, 9), obj_t
         if sil is not None:
@@ -446,6 +469,7 @@ class FitContext:
             sws = torch.empty(_lib().vt_sil_workspace_floats(B, NV, self.obj_faces.shape[0], sil.size), device=dev)
             dimg = torch.empty_like(img); per = torch.empty(B, device=dev)
         adam = None; res = FitResult(); contact = None; trans_init = None; cws = None; Vc = None
+        contact_box = [None]        # 'Computing contacts once': filled by the first step of phase 'joint', whichever step form runs it
         # 'scale' = mean((obj_s - 1)^2) (recon_fit_trivis_full.py:161,227): obj_s is never optimised, so the term is a constant of the call
         # -- zero for the obj_s == 1 that fit_recon passes -- but it is part of the summed loss the stop rule looks at
         ones = torch.ones_like(obj_s)
@@ -467,9 +491,21 @@ class FitContext:
             decay = 1 if phase == "object only" else (it - iter_for_obj + 1 if phase == "sil" else (it - iter_for_obj + 1) / 3)
             tw = 10.0 if phase == "joint" else 1.0
             w = terms.weights(FIT_WEIGHTS, decay, {"otemp": tw, "ovtemp": tw})
+            # the fused step launches cover everything but the interpenetration term (it adds to dt between the rigid VJP and the SO(3) VJP)
+            fused = bool(self.fused_steps) and not (phase == "joint" and self.collision_loss)
             for i in range(10):
                 k = (it - start) * 10 + i
                 nz = noise[k]
+                if fused:
+                    if phase == "sil" and sil is None:
+                        raise L.VtError("phase 'sil' needs a SilSetup")
+                    self._object_step_fused(phase, maps, nz, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, w, terms, names, adam, B, N, NV, R, X, dX, dR, dM, dt,
+                                            Vt if sil is not None else None, dVt if sil is not None else None, img if sil is not None else None,
+                                            fidx if sil is not None else None, sws if sil is not None else None, dimg if sil is not None else None,
+                                            per if sil is not None else None, trans_init, smpl_verts, prof, state, stop, hist, k, ticket,
+                                            int(early_stop and phase == "joint" and it > 0.25 * max_iter), contact_box)
+                    res.steps += 1
+                    continue
                 terms.zero(0, 7)
                 _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
                 _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
@@ -498,8 +534,9 @@ class FitContext:
                     _chk(_lib().vt_sqdiff_loss(obj_t.data_ptr(), 3, trans_init.data_ptr(), 3, B, 3, float(B * 3), float(w[4]), terms.ptr("trans"), dt.data_ptr(), L.stream_ptr()))
                     acc = 1
                 if phase == "joint":
-                    if contact is None:
-                        contact = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
+                    if contact_box[0] is None:
+                        contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
+                    contact = contact_box[0]
                     if contact["P"] > 0:
                         y = X.view(-1, 3).index_select(0, contact["idx_o"])
                         dy = torch.zeros_like(y)
@@ -530,6 +567,52 @@ class FitContext:
             res.steps = int(np.isfinite(res.losses).sum())
         _check_finite(res, "fit")
         return res
+
+    def _object_step_fused(self, phase, maps, nz, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, w, terms, names, adam, B, N, NV, R, X, dX, dR, dM, dt,
+                           Vt, dVt, img, fidx, sws, dimg, per, trans_init, smpl_verts, prof, state, stop, hist, k, ticket, armed, contact_box):
+        """one Adam step of the object stage as head -> (query | silhouette) -> stencils -> (contacts) -> tail; the arithmetic of the single-purpose
+        launches of _optimize_smpl_object in the same order"""
+        lib = _lib(); st = L.stream_ptr()
+        is_sil = phase == "sil"
+        _chk(lib.vt_objstep_head(obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, self.obj_points.data_ptr(), N, X.data_ptr(),
+                                 self.obj_verts.data_ptr() if is_sil else None, NV, Vt.data_ptr() if is_sil else None, R.data_ptr(), terms.buf.data_ptr(), 7, st))
+        if not is_sil:
+            ev = _ev_begin(prof)
+            _chk(lib.vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
+                                          occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), st))
+            _ev_end(prof, "object", ev, B)
+        if B >= 4:
+            _chk(lib.vt_temporal_loss2(X.data_ptr(), B, N * 3, float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), int(is_sil), st))
+        elif is_sil:
+            _chk(lib.vt_fill(dX.data_ptr(), dX.numel(), 0.0, st))
+        if is_sil:
+            _chk(lib.vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                    img.data_ptr(), fidx.data_ptr(), sws.data_ptr(), st))
+            _chk(lib.vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
+                                      terms.ptr("mask"), per.data_ptr(), dimg.data_ptr(), st))
+            _chk(lib.vt_sil_backward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                     fidx.data_ptr(), dimg.data_ptr(), 1e-4, sws.data_ptr(), dVt.data_ptr(), st))
+        if phase == "joint":
+            if contact_box[0] is None:
+                contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
+            contact = contact_box[0]
+            if contact["P"] > 0:
+                y = X.view(-1, 3).index_select(0, contact["idx_o"])
+                dy = torch.zeros_like(y)
+                _chk(lib.vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
+                                           contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), st))
+                dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
+        adam.t += 1
+        gR = gT = (None, None, None, 0.0)
+        for (p_, n_, g_, lr_), m_, v_ in zip(adam.slices, adam.m, adam.v):
+            if n_ == 9:
+                gR = (p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), lr_)
+            else:
+                gT = (p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), lr_)
+        _chk(lib.vt_objstep_tail(self.obj_verts.data_ptr() if is_sil else None, NV, dVt.data_ptr() if is_sil else None, self.obj_points.data_ptr(), N, dX.data_ptr(),
+                                 obj_s.data_ptr(), B, obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), trans_init.data_ptr() if is_sil else None, float(w[4]),
+                                 terms.ptr("trans"), dR.data_ptr(), dt.data_ptr(), dM.data_ptr(), *gR, *gT, adam.t, 0.9, 0.999, 1e-8,
+                                 terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, st))
 
     def _contacts_once(self, maps, smpl_verts, X, crop_center, body_center, thres=0.08):
         """'Computing contacts once' (recon_fit_trivis_full.py:242-253) + the pairing of compute_contact_loss (:393-457):
