@@ -406,11 +406,11 @@ def main():
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_query_human.json)",
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_query_human.json)",
                          "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
                          "avg_launch_ms": 1e3 * float(th.mean()), "effective_ms_per_launch": 1e3 * eff, "streams": args.streams,
                          # the kernel alone on the chip (20 back-to-back launches on one stream after the timed region): the number a single-stream
-                         # rocprofv3 kernel trace reports (profiles/r02_kernel_stats_1stream.csv)
+                         # rocprofv3 kernel trace reports (profiles/r03_kernel_stats_1stream.csv)
                          "solo_launch_ms": None if solo is None else 1e3 * solo,
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
                          "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "

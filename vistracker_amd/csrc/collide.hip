@@ -115,9 +115,14 @@ __global__ __launch_bounds__(256) void collide_loss_kernel(const float *__restri
 __global__ void collide_finish_kernel(const long long *__restrict__ acc, int B, float gscale, double *term, float *dt)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    if (term) atomicAdd(term, (double)acc[4 * b] * (1.0 / COL_FIX) / (double)B);
-    if (dt) for (int k = 0; k < 3; k++) dt[3 * b + k] += (float)((double)acc[4 * b + 1 + k] * (1.0 / COL_FIX) * (double)gscale / (double)B);
+    if (b < B && dt) for (int k = 0; k < 3; k++) dt[3 * b + k] += (float)((double)acc[4 * b + 1 + k] * (1.0 / COL_FIX) * (double)gscale / (double)B);
+    // the value: the per-frame sums stay in 64-bit FIXED POINT across the frames too (integer addition: the same bits whatever the order) and ONE
+    // thread converts and adds the total -- an fp64 atomic per frame made the term, which feeds the stop rule, depend on the arrival order
+    if (term && b == 0) {
+        long long tot = 0;
+        for (int f = 0; f < B; f++) tot += acc[4 * f];
+        atomicAdd(term, (double)tot * (1.0 / COL_FIX) / (double)B);
+    }
 }
 
 extern "C" long vt_collision_workspace_bytes(int B, int n_smpl_faces)

@@ -52,8 +52,8 @@ def _gn(x, sd, p, groups=32, relu=False):
 
 
 class HGFilterEncoder:
-    # 3x3 convolutions with 64 / 128 output channels and Cin % 32 == 0 (all but five of the 79 3x3 layers of an encoder: 2 x 9.4 of the
-    # 9.8 TFLOP per 16 frames) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_*); everything else stays on MIOpen
+    # 3x3 convolutions with 32 / 64 / 128 output channels and Cin % 32 == 0 and the 1x1 convolutions (conv_last / l / bl / al of a stack, the
+    # ConvBlocks' projections) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_* / vt_conv1x1_*); the 7x7 stem stays on MIOpen
     use_hip_conv = True
 
     def __init__(self, sd: dict, prefix: str, num_stack=3, num_hourglass=2, norm="group", hg_down="ave_pool", device="cuda:0"):
@@ -141,8 +141,8 @@ class HGFilterEncoder:
     def _conv_block(self, x, p):
         """ConvBlock (model/net_util.py:346-396): three pre-activated 3x3 convolutions (GN -> ReLU -> conv), outputs concatenated, + (projected)
         residual.  On the GPU every convolution writes its channel slice of ONE NHWC buffer (the concatenation is free) and reads its input from
-        the previous slice; supported shapes run GroupNorm statistics + the fused GN/ReLU/conv kernel (vt_groupnorm_stats, vt_conv3x3_forward_gn),
-        the others (32 output channels) normalise with vt_groupnorm_nhwc and convolve on MIOpen."""
+        the previous slice; supported shapes (32 / 64 / 128 output channels, Cin % 32 == 0, H % 8 == 0, W % 16 == 0) run GroupNorm statistics + the fused
+        GN/ReLU/conv kernel (vt_groupnorm_stats, vt_conv3x3_forward_gn), anything else normalises with vt_groupnorm_nhwc and convolves on MIOpen."""
         sd = self.sd
         B, Cin, H, W = x.shape
         couts = [sd[p + f"conv{i}.weight"].shape[0] for i in (1, 2, 3)]

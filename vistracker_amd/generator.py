@@ -23,8 +23,11 @@ class Generator:
     use_projection = True
     # frames that already hold 1.5 x the requested points sit the following rounds of gen_pc_batch out (their feature maps are not gathered, their
     # samples not projected).  The reference counts progress by the MINIMUM over the frames of the points a round keeps: a frame that is far ahead is
-    # never that minimum, so the common sample count -- and with it every output -- is the same as with all frames in every round (tested); should the
-    # final count overtake a frame that sat out, that frame alone is sampled further.
+    # never that minimum, so the common sample count -- and with it every output -- is the same as with all frames in every round (tested) AS LONG AS
+    # no frame has to be re-activated.  Should the final count overtake a frame that sat out, that frame alone is sampled further; its next samples then
+    # start from the grid-restart branch (its kept-point list of the round is empty: cnt = 0) instead of around its own kept points as the reference
+    # would draw them -- more rounds for that frame and another sample distribution: a deviation confined to that (rare: a frame 1.5 x ahead being
+    # overtaken by the common count) case.  Set False for the reference's every-frame-every-round behaviour.
     skip_done_frames = True
 
     def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,

@@ -247,9 +247,14 @@ class ReconFitterTriVisFull(ReconFitterBase):
         done = 0
         for data in loader:
             paths = data.get("path")
-            if hasattr(source, "is_done") and source.is_done(paths) and not getattr(args, "redo", False):
-                continue
             neural_only = bool(getattr(args, "neural_only", False))
+            if hasattr(source, "is_done") and not getattr(args, "redo", False):
+                try:            # recon_fit_triplane.py:50: is_done(paths, neural_only) -- a neural-only pass resumes on its own outputs (k1_densepc.npz)
+                    finished = source.is_done(paths, neural_only=neural_only)
+                except TypeError:
+                    finished = source.is_done(paths)
+                if finished:
+                    continue
             smpl = kpts = None
             if not neural_only:
                 smpl = source.get_smpl_init(paths, data["body_center"])

@@ -61,9 +61,12 @@ def _load_image(path):
 
 def masks2bbox(masks, thres=127):
     """BaseDataset.masks2bbox (data/base_data.py:139-157): bbox of the clipped sum of the masks; contour rectangles = tight box, +1 on the max edge"""
-    comb = np.zeros(masks[0].shape[:2], np.int32)
+    # the reference accumulates in the masks' own dtype (np.zeros_like of a uint8 mask: 255 + 255 wraps to 254, 200 + 100 to 44) and clips afterwards
+    m0 = masks[0] if masks[0].ndim == 2 else masks[0][..., 0]
+    comb = np.zeros_like(m0)
     for m in masks:
-        comb += (m if m.ndim == 2 else m[..., 0]).astype(np.int32)
+        with np.errstate(over="ignore"):
+            comb += (m if m.ndim == 2 else m[..., 0]).astype(comb.dtype)
     ys, xs = np.nonzero(np.clip(comb, 0, 255) > thres)
     if len(xs) == 0:
         return np.array(EMPTY_BBOX[:2]), np.array(EMPTY_BBOX[2:])
@@ -82,11 +85,17 @@ def crop(img: np.ndarray, center, crop_size: int) -> np.ndarray:
 
 
 def resize_bilinear(img: np.ndarray, size: int) -> np.ndarray:
-    """cv2.resize(img, (size, size), INTER_LINEAR): bilinear, half-pixel centres, no anti-aliasing"""
+    """cv2.resize(img, (size, size), INTER_LINEAR): bilinear, half-pixel centres, no anti-aliasing.  A uint8 image comes back as uint8 like from
+    cv2 (rounded to the nearest grey level and clipped): the reference divides THAT by 255, so masks / RGB are multiples of 1/255 and the
+    `> 0.5` of compose_images sees quantised values.  cv2's own 11-bit fixed-point coefficients are not emulated (cv2 is not a dependency): a
+    pixel may differ from cv2's by one grey level where the exact blend sits within ~2^-11 of a rounding boundary."""
     t = torch.as_tensor(np.ascontiguousarray(img), dtype=torch.float32)
     t = t[None, None] if t.dim() == 2 else t.permute(2, 0, 1)[None]
     out = torch.nn.functional.interpolate(t, size=(size, size), mode="bilinear", align_corners=False)[0]
-    return (out[0] if img.ndim == 2 else out.permute(1, 2, 0)).numpy()
+    out = (out[0] if img.ndim == 2 else out.permute(1, 2, 0)).numpy()
+    if np.asarray(img).dtype == np.uint8:
+        out = np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+    return out
 
 
 # ---- A0: the batch dict of TestDataTriplane ------------------------------------------------------------------------------------------
