@@ -10,7 +10,7 @@ trace() {   # name, command...
   tail -2 gpurun_out/${tag}_${n}.log
 }
 trace encoder python $R/tools/bench_scripts/encbench.py 16
-trace stage4 python $R/tools/bench_scripts/stage4_dbg.py
+trace stage4 python $R/tools/bench_scripts/stage4_bench.py
 trace collide python $R/tools/bench_scripts/collidebench.py 96
 trace inference python $R/tools/bench_scripts/sifnet_inference_bench.py
 # counters of the convolution kernels (encoder pass): separate passes per group
