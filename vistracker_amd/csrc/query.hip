@@ -670,7 +670,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         // waiting for them (top of the next iteration) does not also wait for the far slower gather
         if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid, rmax);
         SCHED_MFMA_VALU(24 * G, 2)
+#if !(defined(TA_ABL) && (TA_ABL & 1))      /* TIMING ABLATION (wrong results): 1 = layer-1 forward weights loaded once, 2 = backward slab staged once, 4 = backward taps not re-gathered */
         LOAD_W1(ci + 1)
+#endif
         if (ci + 2 < NCHUNK) {
             int mi, co; chunk_info(ci + 2, mi, co);
             if (co == 0) {
@@ -1035,7 +1037,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         float4 d4[2];
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) d4[pass] = *reinterpret_cast<const float4 *>(sD + (gpp + 32 * pass) * TS + 4 * gsub);
+#if !(defined(TA_ABL) && (TA_ABL & 2))
         if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) asm volatile("" ::: "memory"); }
+#endif
 #pragma unroll
         for (int pass = 0; pass < 2; pass++)
 #pragma unroll
@@ -1074,10 +1078,14 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                 } else
                     taps_geom(a, m2i, sUV, tid, tgb);
             }
+#if defined(TA_ABL) && (TA_ABL & 4)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
             taps_issue(a, b, m2i, c2o, tgb, tp);
             // slab(ci+1) landed, the d feat rows free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
             // 8 tap loads just issued; the DMA pieces are older than those, so "at most 8 outstanding" means the slab is in LDS.
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
