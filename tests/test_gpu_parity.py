@@ -773,3 +773,49 @@ def test_conv3x3_block_step_vs_float64(hip):
     mean = o.mean((1, 3)); var = o.var((1, 3))
     assert np.abs(st[..., 0] - mean).max() < 1e-5 * sc and np.abs(st[..., 1] - 1 / np.sqrt(var + 1e-5)).max() < 1e-4 * (1 / np.sqrt(var + 1e-5)).max()
     lib.vt_conv3x3_destroy(h)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 128), (64, 256), (256, 64), (256, 256), (128, 256)])
+def test_conv1x1_vs_float64(hip, cin, cout):
+    """vt_conv1x1_forward -- the 1 x 1 convolutions of the encoder (conv_last / l / bl / al, the ConvBlock's projection: model/HGFilters.py:150-203,
+    model/net_util.py:364-372) on the split-f16 kernel -- against float64 on the host, every shape class of the two encoders (one / two / four / eight
+    32-channel chunks, 64 / 128 / 2 x 128 outputs): bias, GroupNorm + ReLU prologue, residual add, channel-offset input and output, and the GroupNorm
+    statistics of the output (conv + bias) a consumer's prologue needs."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vistracker_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    B, H, W, groups = 2, 16, 32, 32
+    cpad = 8
+    x = torch.randn(B, cin + cpad, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(cout, cin, generator=g) / np.sqrt(cin); bias = torch.randn(cout, generator=g) * 0.3
+    gamma = torch.rand(cin, generator=g) + 0.5; beta = torch.randn(cin, generator=g) * 0.2
+    res = torch.randn(B, cout, H, W, generator=g)
+    xin = x[:, 4:4 + cin]                                                           # the layer reads a channel slice of a wider NHWC tensor
+    h = C.c_void_p()
+    L.check(lib.vt_conv1x1_create(C.byref(h), np.ascontiguousarray(w.numpy()).ctypes.data, np.ascontiguousarray(bias.numpy()).ctypes.data, cout, cin, L.stream_ptr()))
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda(); rn = res.permute(0, 2, 3, 1).contiguous().cuda()
+    tiles = lib.vt_conv3x3_tiles(H, W)
+    # (a) plain: conv + bias, output statistics
+    ref = (F.conv2d(xin.double(), w.double()[:, :, None, None], bias.double())).permute(0, 2, 3, 1).numpy(); sc = np.abs(ref).max()
+    out = torch.full((B, H, W, cout + 16), 7.0, device="cuda")
+    ws2 = torch.empty(B * groups + tiles * B * cout * 2, dtype=torch.float64, device="cuda")
+    L.check(lib.vt_conv1x1_forward(h, L.dptr(xn), cin + cpad, 4, None, None, None, 0, B, H, W, L.dptr(out), cout + 16, 8, None, 0, 0, L.dptr(ws2), groups, L.stream_ptr()))
+    L.check(lib.vt_groupnorm_finalize(L.dptr(ws2), tiles, B, H * W, cout, groups, 1e-5, L.stream_ptr()))
+    got = npy(out)
+    assert np.abs(got[..., 8:8 + cout] - ref).max() < 3e-6 * sc, np.abs(got[..., 8:8 + cout] - ref).max() / sc
+    assert (got[..., :8] == 7.0).all() and (got[..., 8 + cout:] == 7.0).all()
+    st = ws2[:B * groups].view(torch.float32).view(B, groups, 2).cpu().numpy().astype(np.float64)
+    o = ref.reshape(B, H * W, groups, cout // groups)
+    mean = o.mean((1, 3)); rstd = 1 / np.sqrt(o.var((1, 3)) + 1e-5)
+    assert np.abs(st[..., 0] - mean).max() < 1e-5 * sc and np.abs(st[..., 1] - rstd).max() < 1e-4 * rstd.max()
+    # (b) GroupNorm + ReLU prologue and residual add
+    ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, cin, groups), dtype=torch.float64, device="cuda")
+    L.check(lib.vt_groupnorm_stats(L.dptr(xn), cin + cpad, 4, B, H * W, cin, groups, 1e-5, L.dptr(ws), L.stream_ptr()))
+    act = F.relu(F.group_norm(xin.double(), groups, gamma.double(), beta.double(), 1e-5))
+    ref2 = (F.conv2d(act, w.double()[:, :, None, None], bias.double()) + res.double()).permute(0, 2, 3, 1).numpy()
+    out2 = torch.empty(B, H, W, cout, device="cuda"); ga, be = gamma.cuda(), beta.cuda()
+    L.check(lib.vt_conv1x1_forward(h, L.dptr(xn), cin + cpad, 4, L.dptr(ws), L.dptr(ga), L.dptr(be), groups, B, H, W, L.dptr(out2), cout, 0, L.dptr(rn), cout, 0, None, 0, L.stream_ptr()))
+    assert np.abs(npy(out2) - ref2).max() < 3e-6 * np.abs(ref2).max(), np.abs(npy(out2) - ref2).max() / np.abs(ref2).max()
+    lib.vt_conv1x1_destroy(h)
