@@ -70,10 +70,17 @@ class TransformerV2:
         o = torch.matmul(torch.softmax(s, -1), vv).transpose(1, 2).reshape(B, T, D)
         return F.linear(o, w["self_attn.out_proj.weight"], w["self_attn.out_proj.bias"])
 
+    def _pos(self, T, D):
+        key = (T, D)
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        if key not in cache:
+            cache[key] = position_embedding_sine_1d(T, D // 2, D).to(self.dev)[None]
+        return cache[key]
+
     @torch.no_grad()
     def __call__(self, x, key_padding_mask=None):
         B, T, D = x.shape
-        pos = position_embedding_sine_1d(T, D // 2, D).to(self.dev)[None]
+        pos = self._pos(T, D)
         for w in self.layers:
             y = F.layer_norm(x, (D,), w["norm1.weight"], w["norm1.bias"])
             x = x + self._attn(w, y + pos, y, key_padding_mask)
@@ -183,9 +190,46 @@ class MotionInfillAutoreg:
             data_[:, -od:] = data_[:, -od:] * (1 - np.expand_dims(mask.astype(float), -1))
             x = torch.from_numpy(np.stack([data_], 0)).float().to(self.device)
             m = torch.from_numpy(np.stack([mask], 0)).to(self.device)
+        return self._net(x, m)
+
+    # replay the per-clip network as a HIP graph (fixed clip shape): a clip is ~250 small launches (8 pre-norm encoder layers of library GEMMs, softmax,
+    # layer norms) whose host-side dispatch -- not their GPU time -- made a clip cost ~30 ms; the ~50 clips of a sequence are a serial chain
+    use_graph = True
+
+    def _net_eager(self, x, m):
+        od = self.obj_dim
         if self.conditional:
             return self.model(x[:, :, :-od], torch.zeros_like(m, dtype=torch.bool), x[:, :, -od:], m)
         return self.model(x, mask=None, src_key_padding_mask=m)
+
+    def _net(self, x, m):
+        if not (self.use_graph and x.is_cuda):
+            return self._net_eager(x, m)
+        key = (tuple(x.shape), str(x.device))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:
+            try:
+                sx, sm = x.clone(), m.clone()
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):                      # warm-up outside the capture (library handles, workspaces, the position tables)
+                        self._net_eager(sx, sm)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    so = self._net_eager(sx, sm)
+                ent = (g, sx, sm, so)
+            except Exception:                               # noqa: BLE001 -- no graph support for some op / build: run the clip eagerly
+                ent = False
+            graphs[key] = ent
+        if ent is False:
+            return self._net_eager(x, m)
+        g, sx, sm, so = ent
+        sx.copy_(x); sm.copy_(m)
+        g.replay()
+        return so
 
     def infill(self, dat: dict, obj_angles, occ_ratios):
         """``dat``: packed SMPL recon (poses, trans, obj_trans, frames, ...); ``obj_angles``: (L,3,3) object rotations of the packed object
