@@ -51,6 +51,8 @@ class PipelineConfig:
     # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
     fit_streams: int = 2
+    # encode batch k + 1 on a second stream while the surface-point generator works on batch k (needs resident maps)
+    overlap_encoder: bool = True
     args: SimpleNamespace = field(default_factory=lambda: SimpleNamespace(net_img_size=[512, 512], loadSize=1200, camera_params=None))
 
 
@@ -156,11 +158,42 @@ class SequencePipeline:
         big = {k: torch.empty(hi - lo, r, r, c, device=self.device) for k, r, c in MAPSPEC} if resident else None
         self.log["resident_maps"] = bool(resident); self.log["frame_range"] = (lo, hi)
         enc0 = getattr(self.net, "frames_encoded", 0)
-        for s, e in sharding.batches_of(T, cfg.neural_bs, lo, hi):
+        nb4 = sharding.batches_of(T, cfg.neural_bs, lo, hi)
+        # With resident maps the encoder of batch k + 1 runs on a second stream (own host thread) while the surface-point generator works on batch k:
+        # the two are bound by different parts of the CU -- the convolutions by the matrix pipe and LDS staging, the projection steps by the
+        # vector-memory path -- so they share the chip better than either shares it with itself.  Results do not depend on it:
+        # every kernel involved is deterministic and the generator's random stream is keyed by the batch.
+        overlap = bool(resident and cfg.overlap_encoder and len(nb4) > 1 and self.net.encoder is not None)
+        enc_maps = [None] * len(nb4)
+        if overlap:
+            import threading
+            enc_stream = torch.cuda.Stream(device=self.device); enc_stream.wait_stream(torch.cuda.current_stream())
+            enc_done = [threading.Event() for _ in nb4]; enc_ev = [torch.cuda.Event() for _ in nb4]; enc_err = []
+
+            def encode_all():
+                try:
+                    torch.cuda.set_device(self.device)
+                    with torch.cuda.stream(enc_stream):
+                        for i, (s, e) in enumerate(nb4):
+                            enc_maps[i] = self.net.encoder(images[s:e], out={k: t[s - lo:e - lo] for k, t in big.items()})
+                            self.net.frames_encoded = getattr(self.net, "frames_encoded", 0) + (e - s)
+                            enc_ev[i].record(enc_stream); enc_done[i].set()
+                except BaseException as ex:      # noqa: BLE001 -- re-raised in the caller's thread
+                    enc_err.append(ex)
+                    for d_ in enc_done:
+                        d_.set()
+            enc_thread = threading.Thread(target=encode_all); enc_thread.start()
+        for i, (s, e) in enumerate(nb4):
             batch = {k: v[s:e] for k, v in data.items()}
             self.generator.reseed(s)            # random stream keyed by the batch's first frame: the same samples on any rank
             bm = None
-            if resident:
+            if overlap:
+                enc_done[i].wait()
+                if enc_err:
+                    enc_thread.join(); raise enc_err[0]
+                torch.cuda.current_stream().wait_event(enc_ev[i])
+                bm = enc_maps[i]
+            elif resident:
                 self.net.filter(batch["images"], out={k: t[s - lo:e - lo] for k, t in big.items()})
                 bm = self.net.maps
             # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
@@ -168,6 +201,9 @@ class SequencePipeline:
             pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm, targets=("object",))
             o = pc["object"]
             rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
+        if overlap:
+            enc_thread.join()
+            torch.cuda.current_stream().wait_stream(enc_stream)
         local = torch.cat(rows, 0) if rows else torch.zeros(0, 16, device=self.device)
         neural = self._gather(local, T, unit).cpu().numpy()
         neural_dict = {"pca_axis": neural[:, :9].reshape(T, 3, 3), "centers": neural[:, 9:15], "visibility": neural[:, 15:16]}
