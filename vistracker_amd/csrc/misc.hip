@@ -880,8 +880,7 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
                                                            float w_trans, double *term_trans, float *__restrict__ dR, float *__restrict__ dt, float *__restrict__ dM,
                                                            AdamSlice aR, AdamSlice aT, float bc2s, float beta1, float beta2, float eps, StepEnd end)
 {
-    __shared__ float red[4];
-    __shared__ float sG[12];
+    __shared__ float red12[4][12];
     const int b = blockIdx.x, B = gridDim.x;
     const bool stopped = end.stop_flag && *end.stop_flag;          // read before any workgroup can close the step
     const float sc = s[b];
@@ -900,8 +899,22 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
 #pragma unroll
             for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
         }
+        // the twelve block sums of rigid_bwd_kernel (wave tree, then the four waves in order: the same additions) with ONE barrier pair instead of twelve
 #pragma unroll
-        for (int e = 0; e < 12; e++) { const float v = block_sum<4>(a[e], red); tot[e] = (pass == 0 || !dXv) ? v : tot[e] + v; }     // rigid_bwd_kernel: first set written, second accumulated
+        for (int e = 0; e < 12; e++) a[e] = wave_sum(a[e]);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int e = 0; e < 12; e++) red12[threadIdx.x >> 6][e] = a[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 12; e++) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v += red12[i][e];
+            tot[e] = (pass == 0 || !dXv) ? v : tot[e] + v;         // rigid_bwd_kernel: first set written, second accumulated
+        }
         if (pass == 0 && t_init) {
             // trans = mean_{B,3} (t - t_init)^2  (vt_sqdiff_loss with denom 3 B) adds its gradient to dt BETWEEN the two rigid VJPs in the unfused
             // sequence (vertex set, regulariser, surface points): same order of the three float additions here
@@ -947,11 +960,11 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) { const float v = UDZ[3 * r] * sv.V[3 * c] + UDZ[3 * r + 1] * sv.V[3 * c + 1] + UDZ[3 * r + 2] * sv.V[3 * c + 2]; dM[9 * b + 3 * r + c] = v; sG[3 * r + c] = v; }
+            for (int c = 0; c < 3; c++) { const float v = UDZ[3 * r] * sv.V[3 * c] + UDZ[3 * r + 1] * sv.V[3 * c + 1] + UDZ[3 * r + 2] * sv.V[3 * c + 2]; dM[9 * b + 3 * r + c] = v; }
 #pragma unroll
         for (int e = 0; e < 9; e++) dR[9 * b + e] = g[e];
 #pragma unroll
-        for (int c = 0; c < 3; c++) { dt[3 * b + c] = g[9 + c]; sG[9 + c] = g[9 + c]; }
+        for (int c = 0; c < 3; c++) dt[3 * b + c] = g[9 + c];
     }
     __syncthreads();
     if (!stopped) {
