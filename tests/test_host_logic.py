@@ -219,3 +219,60 @@ def test_sequence_io_helpers(tmp_path):
     for i in range(3):
         os.makedirs(tmp_path / "seq" / f"t000{i}.000")
     assert [os.path.basename(x) for x in S.frame_folders(str(tmp_path / "seq"))] == ["t0000.000", "t0001.000", "t0002.000"]
+
+
+def test_shard_units_align_both_batch_sizes():
+    """stages with different batch sizes over the SAME frames of a rank (pipeline stages 4 and 6): shards are runs of lcm(bs_a, bs_b)-frame units, so
+    every shard boundary is a batch boundary of both stages and each stage cuts exactly the batches the single-process run cuts"""
+    from vistracker_amd.sharding import batches_of, frame_range, shard_units
+    T, a, b = 1500, 64, 96
+    for world in (1, 2, 3, 4, 8, 16):
+        cov = []
+        for r in range(world):
+            lo, hi = frame_range(shard_units(T, a, b, world, r))
+            if hi > lo:
+                assert lo % 192 == 0 and (hi % 192 == 0 or hi == T)
+                for bs in (a, b):                                   # the rank's batches are batches of the whole-sequence run
+                    assert set(batches_of(T, bs, lo, hi)) <= set(batches_of(T, bs))
+            cov.append((lo, hi))
+        assert sum(h - l for l, h in cov) == T
+        nz = [c for c in cov if c[1] > c[0]]
+        assert all(nz[i][1] == nz[i + 1][0] for i in range(len(nz) - 1)) and nz[0][0] == 0 and nz[-1][1] == T
+    assert [frame_range(shard_units(1500, 64, 96, 8, r)) for r in range(8)] == [(192 * r, min(192 * (r + 1), 1500)) for r in range(8)]
+
+
+def test_bench_strong_mode_job_split():
+    """bench.py --mode strong: K batches taken cyclically from the 16 batches of the 1500-frame sequence, contiguous runs per rank (first K % N ranks
+    one more); the frames of the timed region are counted from the batch sizes (the 60-frame tail included)"""
+    from vistracker_amd.sharding import batches_of
+    seq = batches_of(1500, 96)
+    for K, world in ((16, 1), (20, 1), (20, 8), (16, 8), (3, 4), (5, 2)):
+        base, extra = divmod(K, world)
+        jobs = []
+        for r in range(world):
+            lo = r * base + min(r, extra)
+            jobs.append(list(range(lo, lo + base + (1 if r < extra else 0))))
+        assert sum(jobs, []) == list(range(K)) and max(map(len, jobs)) - min(map(len, jobs)) <= 1
+        frames = sum(e - s for s, e in (seq[j % 16] for j in range(K)))
+        assert frames == (1500 if K == 16 else {20: 1884, 3: 288, 5: 480}[K])
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "divmod(args.steps, world)" in src and "seq_batches[j % len(seq_batches)]" in src      # the arithmetic above is bench.py's
+
+
+def test_sliding_windows_as_one_view_and_lazy_clip_paths():
+    """SMPLTSmoother.seq2batches: the clips are one unfold view of the sequence (identical to the per-window loop of smooth_base.py:45-73, stride 1 and
+    stride 8 with the flush last clip), ClipPaths answers like the B x W list of frame names and merges like merge_paths"""
+    import torch
+    from vistracker_amd import smoothing as S
+    T, W, D = 150, 64, 7
+    seq = torch.arange(T * D, dtype=torch.float32).reshape(T, D)
+    frames = [f"seq/t{i:04d}.000/k1.color.jpg" for i in range(T)]
+    for st in (1, 8):
+        sm = S.SMPLTSmoother(None, W, st, device="cpu")
+        clips, paths = sm.seq2batches(seq, {"frames": frames})
+        starts = list(range(0, T - W + 1, st)) + ([T - W] if st != 1 else [])
+        ref = torch.stack([seq[i:i + W] for i in starts])
+        assert torch.equal(clips, ref) and len(paths) == len(starts)
+        listed = [frames[i:i + W] for i in starts]
+        assert paths[0] == listed[0] and paths[-1] == listed[-1] and paths[len(starts) // 2] == listed[len(starts) // 2]
+        assert S.SMPLTSmoother.merge_paths(paths) == S.SMPLTSmoother.merge_paths(listed)
