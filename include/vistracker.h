@@ -256,6 +256,15 @@ int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *
  *                     (pose[:, 3:72] - pose_init)^2 (recon_fit_behave.py:500-503), Adam on up to three column slices (p, stride, g, stride, m, v,
  *                     columns, lr; p == NULL: unused), step end
  * ------------------------------------------------------------------------------------------------- */
+/* SMPL-stage step forms: vt_kpts_step = vt_landmarks_forward + vt_kpts_loss + vt_landmarks_backward in one launch (J (B,K,3) or NULL receives the joints; dverts
+ * is written -- accumulate = 0 -- or accumulated); vt_query_human_step = vt_query_human_loss whose gradient is ADDED to dpts (accumulate != 0: after vt_kpts_step)
+ * and, with term_accel != NULL, the vertex acceleration stencil vt_accel_loss(pts, B, 3 N, NULL, w_accel, term_accel, dpts) in the same launch.  Same values as the
+ * separate launches (float additions in the same order).  Split-f16 route only. */
+int vt_kpts_step(const vt_landmarks *h, const float *verts, const float *kpts, const float *crop_center, int B, int mode, const float *cam, float net_size,
+                 float gscale, double *term, float *J, float *dverts, int accumulate, void *stream);
+int vt_query_human_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
+                        int B, int N, const int *labels, const int *order, float w_dfh, float w_part, int accumulate, float w_accel,
+                        double *term_accel, float *dpts, double *terms, void *stream);
 int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
                     const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, void *stream);
 int vt_temporal_loss2(const float *v, int B, int D, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, float *dv,

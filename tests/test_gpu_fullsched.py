@@ -192,18 +192,19 @@ def test_fused_step_launches_are_bit_identical(synth):
     noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
     g = golden("smplfit")
     out = []
-    for fused in (True, False):
+    for fused, smpl_query in ((True, False), (False, False), (True, True)):      # default; single-purpose launches; + the step forms of the SMPL-stage query (off by default: slower)
         ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], c["ov"], c["of"], c["pts"])
-        ctx.fused_steps = fused
+        ctx.fused_steps = fused; ctx.fused_smpl_query = smpl_query
         res, R, t = _run_hip_object(ctx, ops.FeatureMaps.from_nchw(c["mp"]), c, noise, c["t0"], **kw)
         maps = ops.FeatureMaps.from_nchw(syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
         pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
         r1 = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), it_range=(0, 6))
         out.append((R, t, res.losses, res.steps, pose.cpu().numpy(), betas.cpu().numpy(), trans.cpu().numpy(), r1.losses, r1.steps))
-    a, b = out
-    assert a[3] == b[3] and a[8] == b[8], (a[3], b[3], a[8], b[8])
-    for k in (0, 1, 4, 5, 6):
-        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
-    for k in (2, 7):
-        fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
-        assert np.array_equal(fa, fb) and np.allclose(a[k][fa], b[k][fb], rtol=2e-6, atol=0)
+    a = out[0]
+    for b in out[1:]:
+        assert a[3] == b[3] and a[8] == b[8], (a[3], b[3], a[8], b[8])
+        for k in (0, 1, 4, 5, 6):
+            assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+        for k in (2, 7):
+            fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
+            assert np.array_equal(fa, fb) and np.allclose(a[k][fa], b[k][fb], rtol=2e-6, atol=0)

@@ -17,6 +17,9 @@ torch = pytest.importorskip("torch")
 W_DFH, W_PART, W_OBJ = 100.0, 0.0025, 900.0
 
 
+MEASURED = []        # what grad_close measured in this session (printed at the end of the test: run with -s / -rP to see it)
+
+
 def rel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
@@ -30,7 +33,10 @@ def grad_close(a, b, tol=3e-4, frac=2e-3):
     a = np.asarray(a, np.float64).reshape(-1, 3); b = np.asarray(b, np.float64).reshape(-1, 3)
     err = np.abs(a - b).max(-1) / (np.abs(b).max() + 1e-30)
     bad = float((err > tol).mean())
-    assert bad <= frac and err.max() < 1.0, (bad, float(np.quantile(err, 0.999)), float(err.max()))
+    msg = (f"outlier fraction {bad:.2e} of {len(err)} points beyond {tol:g} of the gradient scale (bar {frac:g}); error quantiles 50 / 99 / 99.9 %: "
+           f"{np.quantile(err, 0.5):.2e} / {np.quantile(err, 0.99):.2e} / {np.quantile(err, 0.999):.2e}; worst point {err.max():.2e}")
+    MEASURED.append(msg)
+    assert bad <= frac and err.max() < 1.0, msg
 
 
 def _device_maps(B, seed):
@@ -140,3 +146,6 @@ def test_fused_query_kernels_vs_oracle_at_bench_size(synth, B):
     grad_close(dp_o[frames], g_o)
     pf_obj = np.minimum(dfo_all[:, 1].astype(np.float64), 0.8).mean(-1) * occ_np
     assert abs(t_o.cpu().numpy()[0] - pf_obj.mean()) < 1e-6 * abs(pf_obj.mean()) + 1e-9
+    # what the three gradient comparisons of this case measured (256- vs 512-thread kernel, SMPL-stage objective vs oracle, object objective vs oracle):
+    # visible with `pytest -rP`; a regression from the usual ~1e-5 outlier fraction towards the 2e-3 bar shows here before it fails
+    print(f"[fullsize B={B}] " + " | ".join(MEASURED[-3:]))

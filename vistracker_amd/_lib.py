@@ -64,6 +64,8 @@ SIGNATURES = {
     "vt_groupnorm_workspace_doubles": (C.c_long, [ci, ci, ci, ci]),
     "vt_groupnorm_finalize": (ci, [fp, ci, ci, ci, ci, ci, cf, vp]),
     "vt_conv3x3_tiles": (ci, [ci, ci]),
+    "vt_kpts_step": (ci, [vp, fp, fp, fp, ci, ci, vp, cf, cf, fp, fp, fp, ci, vp]),
+    "vt_query_human_step": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, fp, cf, cf, ci, cf, fp, fp, fp, vp]),
     "vt_objstep_head": (ci, [fp, fp, fp, fp, ci, fp, ci, fp, fp, ci, fp, fp, fp, ci, vp]),
     "vt_temporal_loss2": (ci, [fp, ci, ci, cf, fp, cf, fp, fp, ci, vp]),
     "vt_objstep_tail": (ci, [fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,

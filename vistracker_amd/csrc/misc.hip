@@ -1058,3 +1058,66 @@ extern "C" int vt_smplstep_tail(float *pose, const float *pose_init, float *dpos
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
+
+
+// the keypoint chain of a SMPL-stage step in one launch, one workgroup per frame: body25 joints J = regressor . verts (landmarks_fwd_kernel: wave per
+// joint, lane-strided sum, wave tree), the 2-D keypoint term and dJ (kpts_loss_kernel), d verts = regressor^T dJ written -- not accumulated -- for every
+// vertex (landmarks_bwd_kernel): the query launch that follows adds its gradient to it (vt_query_human_step)
+__global__ __launch_bounds__(256) void kpts_step_kernel(const int *__restrict__ indptr, const int *__restrict__ indices, const float *__restrict__ data,
+                                                        const int *__restrict__ colptr, const int *__restrict__ rowidx, const float *__restrict__ cdata,
+                                                        const float *__restrict__ verts, int V, int K, const float *__restrict__ kpts, const float *__restrict__ cc,
+                                                        int mode, Cam5 cam, float net_size, float gscale, float inv_cnt, double *term, float *__restrict__ Jout,
+                                                        float *__restrict__ dverts, int accumulate)
+{
+    __shared__ float sJ[64 * 3], sdJ[64 * 3];
+    __shared__ double red[4];
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < K; k += 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int e = indptr[k] + lane; e < indptr[k + 1]; e += 64) {
+            const float w = data[e]; const float *v = verts + ((size_t)b * V + indices[e]) * 3;
+            a0 += w * v[0]; a1 += w * v[1]; a2 += w * v[2];
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) {
+            sJ[3 * k] = a0; sJ[3 * k + 1] = a1; sJ[3 * k + 2] = a2;
+            if (Jout) { float *o = Jout + ((size_t)b * K + k) * 3; o[0] = a0; o[1] = a1; o[2] = a2; }
+        }
+    }
+    __syncthreads();
+    double acc = 0;
+    if ((int)threadIdx.x < K) {
+        const int k = threadIdx.x, i = b * K + k;
+        const float x = sJ[3 * k], y = sJ[3 * k + 1], z = sJ[3 * k + 2];
+        float px = cam.fx * x / z + cam.cx, py = cam.fy * y / z + cam.cy, sc = 1.f;
+        if (mode == 1) {
+            px = cam.crop / 2 + px - cc[2 * b]; py = cam.crop / 2 + py - cc[2 * b + 1];
+            sc = net_size / cam.crop; px *= sc; py *= sc;
+        }
+        const float ex = px - kpts[3 * i], ey = py - kpts[3 * i + 1], conf = kpts[3 * i + 2];
+        acc = (double)((ex * ex + ey * ey) * conf);
+        const float gpx = 2.f * ex * conf * gscale * inv_cnt * sc, gpy = 2.f * ey * conf * gscale * inv_cnt * sc;
+        sdJ[3 * k] = gpx * cam.fx / z; sdJ[3 * k + 1] = gpy * cam.fy / z;
+        sdJ[3 * k + 2] = -gpx * cam.fx * x / (z * z) - gpy * cam.fy * y / (z * z);
+    }
+    term_add(acc * (double)inv_cnt, term, red);          // (its barriers also publish sdJ)
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const int s = colptr[v], e = colptr[v + 1];
+        if (s == e && accumulate) continue;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int i = s; i < e; i++) { const float w = cdata[i]; const float *g = sdJ + rowidx[i] * 3; a0 += w * g[0]; a1 += w * g[1]; a2 += w * g[2]; }
+        float *o = dverts + ((size_t)b * V + v) * 3;
+        if (accumulate) { o[0] += a0; o[1] += a1; o[2] += a2; } else { o[0] = a0; o[1] = a1; o[2] = a2; }
+    }
+}
+extern "C" int vt_kpts_step(const vt_landmarks *h, const float *verts, const float *kpts, const float *crop_center, int B, int mode, const float *cam, float net_size,
+                            float gscale, double *term, float *J, float *dverts, int accumulate, void *stream)
+{
+    VT_REQUIRE(h && verts && kpts && cam && dverts && B > 0 && h->K <= 64 && (mode == 0 || (mode == 1 && crop_center)), "vt_kpts_step: bad argument (at most 64 landmarks)");
+    Cam5 c{cam[0], cam[1], cam[2], cam[3], cam[4]};
+    const float inv_cnt = 1.f / (mode == 0 ? (float)(B * h->K * 2) : (float)(B * h->K));
+    hipLaunchKernelGGL(kpts_step_kernel, dim3(B), dim3(256), 0, vt_stream(stream), h->indptr, h->indices, h->data, h->colptr, h->rowidx, h->cdata, verts, h->V, h->K,
+                       kpts, crop_center, mode, c, net_size, gscale, inv_cnt, term, J, dverts, accumulate);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

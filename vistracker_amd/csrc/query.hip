@@ -96,6 +96,10 @@ struct QArgs {
     // fused objectives
     const int *labels; const float *occ; float w0, w1; double *terms;
     const int *order;       // optional processing order of the points: workgroup slot n handles point order[n] (NULL = identity)
+    // MODE_HUMAN step form (vt_query_human_step): the gradient is ADDED to what dpts already holds (the keypoint term written by vt_kpts_step), then
+    // the vertex acceleration stencil of the batch (fit_SMPLH_30fps.py:196-200 / recon_fit_behave.py:488-495: a_f = 2 v_f - v_(f-1) - v_(f+1)) adds its
+    // gradient gs (2 a_f - a_(f-1) - a_(f+1)) and its share of the term -- vt_accel_loss without a launch and without a pass over (B, V, 3)
+    int accum; float accel_gs; double *term_accel;
     // surface projection step (MODE_PROJECT): w0 = clamp threshold
     int df_idx; float *pts_out, *dft_out;
 };
@@ -1128,6 +1132,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     }
     // (all three parts -- hoisted projection, gathered maps, xyz -- were accumulated by the owner lane q == 0 of the point)
     if (*sOvf) gx = gy = gz = __builtin_nanf("");
+    double acc_accel = 0.0;
     if (q == 0) {
         const int n = n0 + mypt;
         if (n < a.N) {
@@ -1138,11 +1143,40 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
                 float *o = a.pts_out + ((size_t)b * a.N + pn) * 3;
                 o[0] = px_ - gx * s; o[1] = py_ - gy * s; o[2] = sPt[mypt * 3 + 2] - gz * s;
                 if (a.dft_out) a.dft_out[(size_t)b * a.N + pn] = dft;
+            } else if (MODE == MODE_HUMAN && (a.accum || a.term_accel)) {
+                float *o = a.dpts + ((size_t)b * a.N + pn) * 3;
+                float g[3] = {gx, gy, gz};
+                if (a.accum) { g[0] = o[0] + gx; g[1] = o[1] + gy; g[2] = o[2] + gz; }      // (l + q): the same bits as the (q + l) of the separate launches
+                if (a.term_accel) {
+                    // accel_loss_kernel for the three elements of this vertex in frame b (frames clamped exactly like there)
+                    const int B = a.B, f = b;
+                    const float *vb = a.pts + (size_t)pn * 3; const size_t fs = (size_t)a.N * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float vm2 = vb[(size_t)min(max(f - 2, 0), B - 1) * fs + c], vm1 = vb[(size_t)min(max(f - 1, 0), B - 1) * fs + c], v0 = vb[(size_t)f * fs + c],
+                                    vp1 = vb[(size_t)min(max(f + 1, 0), B - 1) * fs + c], vp2 = vb[(size_t)min(max(f + 2, 0), B - 1) * fs + c];
+                        const float a_m = (f - 1 >= 1 && f - 1 <= B - 2) ? 2.f * vm1 - vm2 - v0 : 0.f;
+                        const float a_0 = (f >= 1 && f <= B - 2) ? 2.f * v0 - vm1 - vp1 : 0.f;
+                        const float a_p = (f + 1 >= 1 && f + 1 <= B - 2) ? 2.f * vp1 - v0 - vp2 : 0.f;
+                        acc_accel += (double)(1.f * a_0 * a_0);
+                        g[c] += a.accel_gs * 1.f * (2.f * a_0 - a_m - a_p);
+                    }
+                }
+                o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
             } else {
                 float *o = a.dpts + ((size_t)b * a.N + pn) * 3;
                 o[0] = gx; o[1] = gy; o[2] = gz;
             }
         }
+    }
+    if (MODE == MODE_HUMAN && a.term_accel) {
+        // the stencil term: mean over (B - 2) frames x 3 N elements of a_f^2; one fp64 atomic per workgroup
+        double s_ = acc_accel;
+        for (int o_ = 32; o_ > 0; o_ >>= 1) s_ += __shfl_xor(s_, o_, 64);
+        __syncthreads();
+        if (lane == 0) sRed[wave] = s_;
+        __syncthreads();
+        if (tid == 0) atomicAdd(a.term_accel, (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / ((double)(a.B - 2) * (double)a.N * 3.0));
     }
 }
 
@@ -2107,6 +2141,19 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
     const bool use8 = g_human_kernel_threads.load(std::memory_order_relaxed) == 512;
     const bool usep = a.proj != nullptr && a.pw == PROJ_COLS && (long)a.res[0] * a.res[0] * PROJ_COLS < (1L << 32);
     if (use8 && usep) return launch_human8(a, vt_stream(stream));
+    return launch<2, MODE_HUMAN>(a, vt_stream(stream));
+}
+
+extern "C" int vt_query_human_step(const vt_sifnet *h, const vt_maps *maps, const float *pts, const float *crop_center, const float *body_center,
+                                   int B, int N, const int *labels, const int *order, float w_dfh, float w_part, int accumulate, float w_accel,
+                                   double *term_accel, float *dpts, double *terms, void *stream)
+{
+    VT_REQUIRE(!VT_IS_F32(h, maps), "vt_query_human_step: split-f16 route only (run vt_query_human_loss + vt_accel_loss on the strict-fp32 route)");
+    QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
+    VT_REQUIRE(labels && dpts && terms && (!term_accel || B >= 3), "vt_query_human_step: null argument, or the acceleration term with fewer than 3 frames");
+    a.hw[0] = head_at(h, 0, maps->act_level); a.hw[1] = head_at(h, 2, maps->act_level); a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
+    a.accum = accumulate ? 1 : 0; a.term_accel = term_accel;
+    a.accel_gs = term_accel ? 2.f * w_accel / ((float)(B - 2) * (float)(N * 3)) : 0.f;      // vt_accel_loss: d/dv of mean(a^2)
     return launch<2, MODE_HUMAN>(a, vt_stream(stream));
 }
 

@@ -172,6 +172,11 @@ class FitContext:
     # query per object-stage step instead of ~11, one tail instead of 8 in the SMPL stage); False = the single-purpose launches (same arithmetic in
     # the same order: the trajectories are bit-identical, tests/test_gpu_fit.py)
     fused_steps = os.environ.get("VT_FUSED_STEPS", "1") != "0"
+    # SMPL stage: keypoint chain as one launch + the query adding its gradient and the vertex acceleration stencil in its epilogue (vt_kpts_step /
+    # vt_query_human_step: 8 launches per step instead of 11, bit-identical).  MEASURED SLOWER and therefore off: the twelve neighbour-frame loads per
+    # point in the tail of the dominant kernel cost it 1 % (1.684 -> 1.700 ms), more than the three small launches it replaces were worth behind
+    # the query (one stream 767.9 -> 777.8 ms per batch, two streams 690 -> 696; same box, two repetitions)
+    fused_smpl_query = os.environ.get("VT_FUSED_SMPL_QUERY", "0") != "0"
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -353,6 +358,7 @@ class FitContext:
         stop = torch.zeros(1, dtype=torch.int32, device=dev)
         state = torch.tensor([300.0, 300.0], device=dev)          # prev_loss = 300 (recon_fit_behave.py:408)
         fused = bool(self.fused_steps); ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        split_route = self.net.precision != "fp32" and not maps.force_fp32          # the step forms of the query exist on the split-f16 route only
         if self.sort_query_points:
             # processing order for this batch: Morton order of the IMAGE positions of the initial vertices of the middle frame (the body moves
             # little inside a batch and during the fit); a little better than the template's 3-D order because the perspective maps -- the
@@ -382,6 +388,22 @@ class FitContext:
                 if not fused:
                     terms.zero(0, 6)        # (fused: the tail of the previous step left them zeroed)
                 self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+                if fused and split_route and self.fused_smpl_query:
+                    # keypoint chain (joints, 2-D term, its gradient written to dverts) in one launch, then the query adds its gradient and the vertex
+                    # acceleration stencil in its own epilogue: 8 launches per step with the two forward and three backward SMPL-H kernels and the tail
+                    if phase == "kpts":
+                        _chk(_lib().vt_kpts_step(self.b25.h, verts.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 1, self.cam.ctypes.data, net_size,
+                                                 float(w[4]), terms.ptr("j2d"), J.data_ptr(), dverts.data_ptr(), 0, L.stream_ptr()))
+                    ev = _ev_begin(prof)
+                    _chk(_lib().vt_query_human_step(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
+                                                    self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
+                                                    int(phase == "kpts"), float(w[5]), terms.ptr("stemp") if B >= 4 else None, dverts.data_ptr(), terms.ptr("df_h"),
+                                                    L.stream_ptr()))
+                    _ev_end(prof, "human", ev, B)
+                    self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                    self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
+                    res.steps += 1
+                    continue
                 ev = _ev_begin(prof)
                 _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
                                                 self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
@@ -396,19 +418,7 @@ class FitContext:
                     _chk(_lib().vt_accel_loss(verts.data_ptr(), B, V * 3, None, float(w[5]), terms.ptr("stemp"), dverts.data_ptr(), L.stream_ptr()))
                 self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
                 if fused:
-                    # body prior + pinit + Adam on every group + loss reduction / stop rule + term zeroing: one launch
-                    adam.t += 1
-                    sl = []
-                    for k in range(3):
-                        if k < len(adam.slices):
-                            (p_, n_, g_, lr_), m_, v_ = adam.slices[k], adam.m[k], adam.v[k]
-                            sl += [p_.data_ptr(), p_.shape[1], g_.data_ptr(), g_.shape[1], m_.data_ptr(), v_.data_ptr(), n_, lr_]
-                        else:
-                            sl += [None, 0, None, 0, None, None, 0, 0.0]
-                    _chk(_lib().vt_smplstep_tail(pose.data_ptr(), pose_init.data_ptr(), dpose.data_ptr(), B, self.pri["body_mean"].data_ptr(), self.pri["body_prec"].data_ptr(),
-                                                 float(w[2]) / B, terms.ptr("pose"), float(w[3]), terms.ptr("pinit"), *sl, adam.t, 0.9, 0.999, 1e-8,
-                                                 terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(), stop.data_ptr(),
-                                                 hist.data_ptr(), (it - start) * 10 + i, ticket.data_ptr(), 6, L.stream_ptr()))
+                    self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
                 else:
                     self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
                     # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
@@ -567,6 +577,21 @@ class FitContext:
             res.steps = int(np.isfinite(res.losses).sum())
         _check_finite(res, "fit")
         return res
+
+    def _smpl_tail(self, pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, slot, ticket, armed):
+        """body prior + pinit + Adam on every group + loss reduction / stop rule + term zeroing: one launch (vt_smplstep_tail)"""
+        adam.t += 1
+        sl = []
+        for k in range(3):
+            if k < len(adam.slices):
+                (p_, n_, g_, lr_), m_, v_ = adam.slices[k], adam.m[k], adam.v[k]
+                sl += [p_.data_ptr(), p_.shape[1], g_.data_ptr(), g_.shape[1], m_.data_ptr(), v_.data_ptr(), n_, lr_]
+            else:
+                sl += [None, 0, None, 0, None, None, 0, 0.0]
+        _chk(_lib().vt_smplstep_tail(pose.data_ptr(), pose_init.data_ptr(), dpose.data_ptr(), B, self.pri["body_mean"].data_ptr(), self.pri["body_prec"].data_ptr(),
+                                     float(w[2]) / B, terms.ptr("pose"), float(w[3]), terms.ptr("pinit"), *sl, adam.t, 0.9, 0.999, 1e-8,
+                                     terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, armed, state.data_ptr(), stop.data_ptr(),
+                                     hist.data_ptr(), slot, ticket.data_ptr(), 6, L.stream_ptr()))
 
     def _object_step_fused(self, phase, maps, nz, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, w, terms, names, adam, B, N, NV, R, X, dX, dR, dM, dt,
                            Vt, dVt, img, fidx, sws, dimg, per, trans_init, smpl_verts, prof, state, stop, hist, k, ticket, armed, contact_box):
