@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     // a 32-channel layer runs the 64-channel kernel with its upper rows packed as zeros: the waves that own none of its output channels take part in
     // the staging only (no weight loads, no MFMAs, no stores)
     const bool live = wave * NT * 16 < cout;
-    uint4 wf[2][NT][2];
+    // weight fragments: a ring of three register sets, requested TWO taps ahead of their use (round 3: one tap = 48 MFMAs was shorter than the latency of
+    // an L2 hit under load; nine taps per chunk keep the ring aligned across chunks: slot = tap % 3 (3 x 3), chunk % 3 (1 x 1, unrolled))
+    uint4 wf[3][NT][2];
 #define CV_LOAD_W(slot_, step_)                                                                                      \
     _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                \
         _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
@@ -146,9 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
 #pragma unroll
         for (int t = 0; t < NTAP; t++) {
             const int dy = K3 ? t / 3 : 0, dx = K3 ? t % 3 : 0, step = c * NTAP + t;
-            // 3 x 3: nine taps, slots alternate with t (chunk c + 1 starts on slot (9 & 1) = 1, re-aligned below); 1 x 1: slots alternate with the chunk
-            if (live && step + 1 < nchunk * NTAP) { if (K3) { CV_LOAD_W((t + 1) & 1, step + 1) } else if (c & 1) { CV_LOAD_W(0, step + 1) } else { CV_LOAD_W(1, step + 1) } }
-            const int sl = K3 ? (t & 1) : (c & 1);
+            if (live && step + 2 < nchunk * NTAP) { if (K3) { CV_LOAD_W((t + 2) % 3, step + 2) } else { CV_LOAD_W((c + 2) % 3, step + 2) } }
+            const int sl = K3 ? (t % 3) : (c % 3);
 #pragma unroll
             for (int ph = 0; ph < (live ? 2 : 0); ph++) {       // two halves of four image rows: 8 B fragments live at a time
                 h8 xh[4], xl[4];
@@ -171,17 +172,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
                     for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][1]), xh[p], acc[nt][4 * ph + p]);
             }
         }
-        if (K3) {
-            // nine taps flip the slot parity once per chunk: re-align so that tap 0 of the next chunk finds its fragments in slot 0
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int hl = 0; hl < 2; hl++) wf[0][nt][hl] = wf[1][nt][hl];
-        }
     };
     if (K3) {
         issue(0, 0);
-        if (live) { CV_LOAD_W(0, 0) }
+        if (live) { CV_LOAD_W(0, 0) CV_LOAD_W(1, 1) }
         stage(0, 0, 0);
         if (nchunk > 1) issue(1, 0);
         for (int c = 0; c < nchunk; c++) {
@@ -192,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
     } else {
 #pragma unroll
         for (int k = 0; k < (RING < NCH ? RING : NCH); k++) issue(k, k);
-        if (live) { CV_LOAD_W(0, 0) }
+        if (live) { CV_LOAD_W(0, 0) if (NCH > 1) { CV_LOAD_W(1, 1) } }
         stage(0, 0, 0);
         if (RING < NCH) issue(RING, 0);                        // set 0 is free again
 #pragma unroll
