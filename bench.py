@@ -254,7 +254,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if shared_gpu else dev
-    if world > 1:
+    # test hook: VT_FORCE_DIST=1 under torch.distributed.run with ONE rank takes the whole N > 1 path (process group over RCCL, barriers, the final
+    # all_gather, the MAX reduction of the time) on the one GPU of a test box -- the only way to execute the RCCL calls without a multi-GPU node
+    use_dist = world > 1 or (os.environ.get("VT_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
@@ -297,7 +300,7 @@ def main():
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     if args.streams <= 1:
@@ -322,7 +325,7 @@ def main():
         for t_ in th_: t_.join()
         for s_ in streams:
             torch.cuda.current_stream().wait_stream(s_)
-    if world > 1:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch), padded to the largest shard
+    if use_dist:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch), padded to the largest shard
         rows_max = (args.steps + world - 1) // world * BATCH if strong else args.steps * BATCH
         packed = torch.zeros(rows_max, 182, device=dev)
         if batches:
@@ -332,10 +335,10 @@ def main():
         out = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(out, packed)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
     extras = {}
@@ -435,7 +438,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

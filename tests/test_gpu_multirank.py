@@ -59,3 +59,33 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
         assert np.array_equal(a[k], b[k]), (k, diffs[k], int((a[k] != b[k]).sum()), a[k].size)
     worst = {k: float(np.abs(a[k] - b[k]).max()) for k in ("poses", "betas", "trans", "obj_angles", "obj_trans")}
     assert all(v == 0.0 for v in worst.values()), worst
+
+
+def test_rccl_path_with_a_group_of_one(tmp_path):
+    """No multi-GPU node has been available to this repository, so the RCCL calls of the N > 1 path (``init_process_group("nccl")``, the barriers, the
+    final all_gather of the fitted rows, the MAX all_reduce of the time; ``sharding.gather_params`` of the pipeline) are executed here with a process
+    group of ONE rank over RCCL on the test box's GPU (``VT_FORCE_DIST=1``): same calls, same tensors, no peer."""
+    env = dict(os.environ, VT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["config"]["frames_timed"] == 96 and line["value"] > 0
+    # the pipeline's gather through RCCL
+    script = tmp_path / "g.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from vistracker_amd import sharding\n"
+        "torch.cuda.set_device(0); dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "x = torch.arange(250 * 7, dtype=torch.float32, device='cuda').reshape(250, 7)\n"
+        "y = sharding.gather_params(x, 250, 96)\n"
+        "assert dist.get_backend() == 'nccl' and y.is_cuda and torch.equal(x, y)\n"
+        "t = torch.tensor([3.5], device='cuda', dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()\n"
+        "assert float(t) == 3.5\n"
+        "print('RCCL_OK'); dist.destroy_process_group()\n")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29562", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

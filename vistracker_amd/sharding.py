@@ -45,8 +45,9 @@ def gather_params(local, num_frames: int, bs: int, start: int = 0, end: int | No
     Works with any initialised torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and os.environ.get("VT_FORCE_DIST") != "1"):
+        return local            # (VT_FORCE_DIST=1: a group of ONE still goes through the collective -- executes the RCCL path on a one-GPU test box)
     world = dist.get_world_size()
     counts = [sum(e - s for s, e in shard_batches(num_frames, bs, world, r, start, end)) for r in range(world)]
     D = local.shape[1]
