@@ -420,6 +420,12 @@ int vt_loss_reduce_and_stop(const double *terms, const float *w, int nterms, flo
 /* small utilities */
 int vt_fill(float *p, long n, float value, void *stream);
 
+/* Device-side early stop.  The fits evaluate their stop rules on the device (the reference breaks out of its inner loop on the host:
+ * recon_fit_behave.py:447, recon_fit_trivis_full.py:372, fit_SMPLH_kpts.py:161) and the host reads the flag once per outer iteration of 10 steps; with
+ * `flag` registered for `stream` the query and SMPL-H launches queued behind the stopping step return at once when *flag != 0 (the Adam / loss-history
+ * launches ignore those steps already).  flag = NULL removes the registration; the owner must remove it before the flag's memory is released. */
+int vt_stream_set_skip_flag(void *stream, const int *flag);
+
 #ifdef __cplusplus
 }
 #endif

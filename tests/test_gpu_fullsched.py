@@ -208,3 +208,38 @@ def test_fused_step_launches_are_bit_identical(synth):
         for k in (2, 7):
             fa, fb = np.isfinite(a[k]), np.isfinite(b[k])
             assert np.array_equal(fa, fb) and np.allclose(a[k][fa], b[k][fb], rtol=2e-6, atol=0)
+
+
+def test_device_side_skip_after_the_stop_step(synth):
+    """The host reads the stop flag once per outer iteration, so the steps queued behind the one that stopped the fit are launched anyway; with the flag
+    registered for the stream (vt_stream_set_skip_flag, ``FitContext.device_skip``) their query / SMPL-H kernels return at once.  Nothing observable may
+    change: same parameters bit for bit, same step count, same loss history -- and a profiled run keeps the events of the executed launches only."""
+    from conftest import golden
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext
+    g = golden("smplfit")
+    c = _object_case(synth, 4, 600, seed=17)
+    out = []
+    for skip in (True, False):
+        ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], c["ov"], c["of"], c["pts"])
+        ctx.device_skip = skip
+        maps = ops.FeatureMaps.from_nchw(syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"])))
+        pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+        prof = {"human": [], "object": []}
+        r = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), max_iter=8, prof=prof)
+        kw = dict(iter_for_obj=3, iter_for_sil=3, joint_iter=2, max_iter=8)
+        noise = np.random.default_rng(23).uniform(0, 1, (160, 4, 3, 3)).astype(np.float32)
+        ro, R, t = _run_hip_object(ctx, ops.FeatureMaps.from_nchw(c["mp"]), c, noise, c["t0"], **kw)      # silhouette, Chamfer and object query behind its stop step
+        out.append((pose.cpu().numpy(), betas.cpu().numpy(), trans.cpu().numpy(), r.losses, r.steps, r.outer_iters, r.stopped_early, len(prof["human"]),
+                    R, t, ro.losses, ro.steps, ro.stopped_early))
+    a, b = out
+    assert a[11] == b[11] and a[12] == b[12] and np.array_equal(a[8], b[8]) and np.array_equal(a[9], b[9]), (a[11:], b[11:])
+    fa, fb = np.isfinite(a[10]), np.isfinite(b[10])
+    assert np.array_equal(fa, fb) and np.array_equal(a[10][fa], b[10][fb])
+    print(f"object stage: stopped early {a[12]} after {a[11]} steps; SMPL stage after {a[4]} steps")
+    assert a[6] and b[6] and a[4] == b[4] and a[4] % 10 != 0, (a[4:], b[4:])          # stopped inside an outer iteration
+    for k in range(3):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k] - b[k]).max()))
+    fa, fb = np.isfinite(a[3]), np.isfinite(b[3])
+    assert np.array_equal(fa, fb) and np.array_equal(a[3][fa], b[3][fb])
+    assert a[7] == a[4] and b[7] == b[5] * 10, (a[7], a[4], b[7], b[5])              # events: executed launches only / every launch

@@ -74,6 +74,7 @@ SIGNATURES = {
     "vt_smplstep_tail": (ci, [fp, fp, fp, ci, fp, fp, cf, fp, cf, fp,
                               fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, ci, cf, cf, cf,
                               fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
+    "vt_stream_set_skip_flag": (ci, [vp, vp]),
     "vt_conv1x1_create": (ci, [C.POINTER(vp), vp, vp, ci, ci, vp]),
     "vt_conv1x1_destroy": (None, [vp]),
     "vt_conv1x1_forward": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),

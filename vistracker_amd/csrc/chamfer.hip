@@ -54,8 +54,9 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
 }
 
 __global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ x, const int *__restrict__ offx, const float *__restrict__ y,
-                                                      const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy)
+                                                      const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     __shared__ float sB[CH_CHUNK * 3];
     __shared__ int sNN[256];
     __shared__ float sG[256 * 3];
@@ -80,7 +81,7 @@ extern "C" int vt_chamfer_ragged(const float *x, const int *offx, const float *y
                                  float *dx, float *dy, void *stream)
 {
     VT_REQUIRE(x && offx && y && offy && P > 0, "vt_chamfer_ragged: bad argument");
-    hipLaunchKernelGGL(chamfer_kernel, dim3(P), dim3(256), 0, vt_stream(stream), x, offx, y, offy, P, gscale / (float)P, term, dx, dy);
+    hipLaunchKernelGGL(chamfer_kernel, dim3(P), dim3(256), 0, vt_stream(stream), x, offx, y, offy, P, gscale / (float)P, term, dx, dy, vt_skip_flag_of(vt_stream(stream)));
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

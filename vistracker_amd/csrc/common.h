@@ -36,6 +36,11 @@ extern thread_local char vt_err_buf[512];
 
 static inline hipStream_t vt_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Device-side early stop (vt_stream_set_skip_flag, misc.hip): the int a fit registered for this stream, or NULL.  The heavy kernels of a step take it
+// as an argument and return at once when it is non-zero: the steps the host queued behind the one whose stop rule fired cost a launch, not a pass.
+const int *vt_skip_flag_of(hipStream_t st);
+#define VT_SKIP_RETURN(flag_) do { if ((flag_) != nullptr && *(volatile const int *)(flag_) != 0) return; } while (0)
+
 // Raise a kernel's dynamic-LDS limit once per (kernel, device).  The flag is a per-call-site bit mask indexed by the device ordinal:
 // thread-safe (bench.py drives two host threads), and a second GPU in the same process gets its own call (the attribute is per device).
 // Two threads racing on the same device both make the (idempotent) call; neither launches before its own call returned.

@@ -1121,3 +1121,31 @@ extern "C" int vt_kpts_step(const vt_landmarks *h, const float *verts, const flo
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
+
+// ---- device-side early stop: per-stream skip flag -------------------------------------------------------------------------------------------
+// The stop rules of the fits are evaluated on the device (vt_loss_reduce_and_stop / the step tails) and the host looks at the flag once per outer
+// iteration of 10 steps, so up to 9 steps are already queued behind the step that stopped the fit.  Adam and the loss history ignore them; with the
+// flag registered for the stream the query and SMPL-H kernels of those steps return at their first instruction as well (results unchanged: the
+// reference breaks out of its loop at that step, recon_fit_behave.py:447).  One entry per stream, set / cleared by the fit that owns the flag.
+#include <mutex>
+#include <vector>
+static std::mutex g_skip_mu;
+static std::vector<std::pair<hipStream_t, const int *>> g_skip_tab;
+const int *vt_skip_flag_of(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_skip_mu);
+    for (const auto &e : g_skip_tab) if (e.first == st) return e.second;
+    return nullptr;
+}
+extern "C" int vt_stream_set_skip_flag(void *stream, const int *flag)
+{
+    std::lock_guard<std::mutex> lk(g_skip_mu);
+    const hipStream_t st = vt_stream(stream);
+    for (size_t i = 0; i < g_skip_tab.size(); i++)
+        if (g_skip_tab[i].first == st) {
+            if (flag) g_skip_tab[i].second = flag; else { g_skip_tab[i] = g_skip_tab.back(); g_skip_tab.pop_back(); }
+            return VT_OK;
+        }
+    if (flag) g_skip_tab.emplace_back(st, flag);
+    return VT_OK;
+}

@@ -102,6 +102,7 @@ struct QArgs {
     int accum; float accel_gs; double *term_accel;
     // surface projection step (MODE_PROJECT): w0 = clamp threshold
     int df_idx; float *pts_out, *dft_out;
+    const int *skip;        // device-side early stop of the fit that owns the stream (vt_stream_set_skip_flag) or NULL
 };
 
 // chunk i (32 channels) -> map index, channel offset inside the map; map -> channels, projection.  Tables in constant memory: the
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // shared tap geometry (geom_compute / geom_fetch): -1.9 % on the two-head kernel; the one-head kernels (168 VGPRs, three workgroups per CU)
     // spill with it and lose 3 %: they keep the per-thread geometry
     constexpr bool SHGEO = (G == 2);
+    VT_SKIP_RETURN(a.skip);
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden-activation planes per head -> tap-difference
     // buffers + weight slab (layer-1 backward, after the d(hidden-1) fragments moved to registers).
@@ -1351,6 +1353,7 @@ __device__ __forceinline__ void gemm128x(Acc4 (&c)[G], const uint4 *Hp, const WP
 
 __global__ __launch_bounds__(512, 2) void query_human8_kernel(const QArgs a)
 {
+    VT_SKIP_RETURN(a.skip);
     constexpr int G = 2, C0 = PROJ_C0;
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     // region 0 (G x 2048 uint4 = 64 KB), time-shared: layer-1 chunk slots {hi [4 kb][64], lo [4 kb][64]} x 2 -> hidden-activation planes per head
@@ -1811,7 +1814,8 @@ static int launch_human8(const QArgs &a, hipStream_t st)
 {
     const size_t lds = lds_bytes_human8();
     VT_LDS_LIMIT(query_human8_kernel, lds);
-    hipLaunchKernelGGL(query_human8_kernel, dim3(((a.N + 63) / 64) * a.B), dim3(512), lds, st, a);
+    QArgs b8 = a; b8.skip = vt_skip_flag_of(st);
+    hipLaunchKernelGGL(query_human8_kernel, dim3(((a.N + 63) / 64) * a.B), dim3(512), lds, st, b8);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -2056,7 +2060,8 @@ static int launch_(const QArgs &a, hipStream_t st)
 {
     const size_t lds = lds_bytes(G);
     VT_LDS_LIMIT((query_kernel<G, MODE, USEP>), lds);
-    hipLaunchKernelGGL((query_kernel<G, MODE, USEP>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, a);
+    QArgs b = a; b.skip = vt_skip_flag_of(st);
+    hipLaunchKernelGGL((query_kernel<G, MODE, USEP>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, b);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

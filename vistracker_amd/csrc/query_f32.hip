@@ -51,6 +51,7 @@ struct QArgs {
     const int *labels; const float *occ; float w0, w1; double *terms;
     const int *order;       // optional processing order of the points (slot n handles point order[n])
     int df_idx; float *pts_out, *dft_out;      // MODE_PROJECT (w0 = clamp threshold)
+    const int *skip;        // device-side early stop (vt_stream_set_skip_flag) or NULL
 };
 
 __device__ __forceinline__ int map_channels(int mi) { return mi == 0 ? 256 : (mi == 1 ? 64 : (mi < 5 ? 32 : 64)); }
@@ -222,6 +223,7 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const float *H, const float *__
 template <int G, int MODE>
 __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArgs a)
 {
+    VT_SKIP_RETURN(a.skip);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden activations per head -> tap-difference double
     // buffers (layer-1 backward, after the d(hidden-1) fragments moved to registers).
@@ -641,7 +643,8 @@ static int launch(const QArgs &a, hipStream_t st)
 {
     const size_t lds = lds_bytes(G);
     VT_LDS_LIMIT((query_kernel<G, MODE>), lds);
-    hipLaunchKernelGGL((query_kernel<G, MODE>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, a);
+    QArgs b = a; b.skip = vt_skip_flag_of(st);
+    hipLaunchKernelGGL((query_kernel<G, MODE>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, b);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

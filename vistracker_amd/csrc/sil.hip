@@ -17,8 +17,9 @@
 #define TILE 16
 #define MAXLIST 8192
 
-__global__ void sil_project_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, float *__restrict__ proj)
+__global__ void sil_project_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, float *__restrict__ proj, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= NV) return;
     const float *v = verts + ((size_t)b * NV + i) * 3, *k = K + 9 * b;
@@ -77,8 +78,9 @@ extern "C" long vt_sil_workspace_floats(int B, int NV, int NF, int size)
 
 // per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
 __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int *__restrict__ faces, int NV, int NF, int is,
-                                      float *__restrict__ fcbuf, int2 *__restrict__ fbox, int *__restrict__ visible)
+                                      float *__restrict__ fcbuf, int2 *__restrict__ fbox, int *__restrict__ visible, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     const int f2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (f2 >= 2 * NF) return;
     float fc[9]; load_face(proj + (size_t)b * NV * 3, faces, NF, f2, fc);
@@ -160,8 +162,9 @@ __device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den,
     }
 }
 __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
-                                                          unsigned long long *__restrict__ zbuf)
+                                                          unsigned long long *__restrict__ zbuf, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     constexpr int FPW = 64 / SIL_G;
     __shared__ unsigned short sQ[4][FPW][SIL_BIG];              // per lane group: the box pixels that passed the inside test
     const int lane = threadIdx.x & 63, gl = lane % SIL_G, grp = lane / SIL_G, b = blockIdx.y;
@@ -228,8 +231,9 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
 }
 
 __global__ void sil_resolve_kernel(const unsigned long long *__restrict__ zbuf, int NF, int is, float *__restrict__ image,
-                                   int *__restrict__ face_index, int *__restrict__ visible)
+                                   int *__restrict__ face_index, int *__restrict__ visible, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     const int xi = blockIdx.x * blockDim.x + threadIdx.x, yi = blockIdx.y, b = blockIdx.z;
     if (xi >= is) return;
     const unsigned long long key = zbuf[((size_t)b * is + yi) * is + xi];
@@ -245,8 +249,9 @@ __global__ void sil_resolve_kernel(const unsigned long long *__restrict__ zbuf, 
 // a row's word is the ballot, a column's word collects one bit per row in its lane, the four 16-bit pieces meet in LDS.  Every pixel is read
 // once (the first version read it twice, once with a 1 KB lane stride: 52 us).
 __global__ __launch_bounds__(256) void sil_sweep_mask_kernel(const int *__restrict__ face_index, const float *__restrict__ d_image, int is,
-                                                            unsigned long long *__restrict__ rowmask, unsigned long long *__restrict__ colmask)
+                                                            unsigned long long *__restrict__ rowmask, unsigned long long *__restrict__ colmask, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     __shared__ unsigned sCol[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpl = is / 64;
     const int tile = blockIdx.x, b = blockIdx.y;
@@ -289,8 +294,9 @@ __device__ __forceinline__ float group_sum(float v)
 // the face itself.  Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
 __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
-                                    const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj)
+                                    const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     // a group of SIL_G lanes per ORIGINAL face (see sil_scatter_kernel): at most one of its two orientations won pixels.  A visible face is a chain
     // of dependent memory round trips (record -> face index at the edge -> sweep masks -> image gradient), ~8 us at full occupancy whatever the lane
     // count: four faces per wave share that latency (a face has ~40 walk positions: two or three rounds of 16 lanes instead of one of 64).
@@ -413,8 +419,9 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
 }
 
 __global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const double *__restrict__ gproj,
-                                     float *__restrict__ dverts)
+                                     float *__restrict__ dverts, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= NV) return;
     const float *v = verts + ((size_t)b * NV + i) * 3, *k = K + 9 * b;
@@ -427,8 +434,9 @@ __global__ void sil_unproject_kernel(const float *__restrict__ verts, const floa
 
 __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restrict__ image, const float *__restrict__ keep, const float *__restrict__ ref,
                                                             const float *__restrict__ occ, int B, int npx, float gs, double *term,
-                                                            float *per_frame, float *__restrict__ d_image)
+                                                            float *per_frame, float *__restrict__ d_image, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     // grid = (slices, B): a frame's pixels are split over gridDim.x blocks (one block per frame left most of the chip idle);
     // per_frame is only supported with one slice
     __shared__ double red[4];
@@ -462,16 +470,16 @@ extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *face
     VT_REQUIRE(verts && faces && K && image && face_index && ws && B > 0 && NV > 0 && NF > 0 && size > 0 && size % TILE == 0 && size < 32768,
                "vt_sil_forward: bad argument (size must be a multiple of 64)");
     VT_REQUIRE(size % 64 == 0, "vt_sil_forward: size must be a multiple of 64");
-    hipStream_t st = vt_stream(stream);
+    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
     const SilWs w = sil_ws(ws, B, NV, NF, size);
-    hipLaunchKernelGGL(sil_project_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.proj);
+    hipLaunchKernelGGL(sil_project_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.proj, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
+    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible, skip);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible);
+    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -486,12 +494,12 @@ extern "C" int vt_triplane_render(const float *verts, const float *center, int B
     const SilWs w = sil_ws(ws, B3, NV, NF, size);
     hipLaunchKernelGGL(sil_triplane_project_kernel, dim3((NV + 255) / 256, B3), dim3(256), 0, st, verts, center, NV, 10.0f, w.proj);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B3), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible);
+    hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B3), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible, nullptr);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B3 * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, nullptr);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B3), dim3(256), 0, st, w.zbuf, NF, size, masks, face_index, w.visible);
+    hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B3), dim3(256), 0, st, w.zbuf, NF, size, masks, face_index, w.visible, nullptr);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -500,15 +508,15 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
                                const float *d_image, float eps, float *ws, float *dverts, void *stream)
 {
     VT_REQUIRE(verts && faces && K && face_index && d_image && ws && dverts && B > 0, "vt_sil_backward: bad argument");
-    hipStream_t st = vt_stream(stream);
+    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
     const SilWs w = sil_ws(ws, B, NV, NF, size);
     VT_HIP(hipMemsetAsync(w.gproj, 0, sizeof(double) * (size_t)B * NV * 2, st));
-    hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, face_index, d_image, size, w.rowmask, w.colmask);
+    hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, face_index, d_image, size, w.rowmask, w.colmask, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
-                       w.rowmask, w.colmask, eps, w.gproj);
+                       w.rowmask, w.colmask, eps, w.gproj, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts);
+    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -519,7 +527,7 @@ extern "C" int vt_sil_mask_loss(const float *image, const float *keep, const flo
     VT_REQUIRE(image && keep && ref && occ && B > 0 && size > 0 && size % 2 == 0, "vt_sil_mask_loss: bad argument (size must be even)");
     VT_REQUIRE((((uintptr_t)image | (uintptr_t)keep | (uintptr_t)ref | (uintptr_t)d_image) & 15) == 0, "vt_sil_mask_loss: images must be 16-byte aligned");
     hipLaunchKernelGGL(sil_mask_loss_kernel, dim3(per_frame ? 1 : 16, B), dim3(256), 0, vt_stream(stream), image, keep, ref, occ, B, size * size, gscale / (float)B,
-                       term, per_frame, d_image);
+                       term, per_frame, d_image, vt_skip_flag_of(vt_stream(stream)));
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

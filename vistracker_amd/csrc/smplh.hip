@@ -118,8 +118,9 @@ __global__ void rodrigues_bwd_kernel(const float *aa, int n, const float *dR, fl
 __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict__ pose, const float *__restrict__ betas,
                                                         const float *__restrict__ trans, const float *__restrict__ J_t,
                                                         const float *__restrict__ J_s, SmplParents par,
-                                                        float *__restrict__ ws, float *__restrict__ jtr)
+                                                        float *__restrict__ ws, float *__restrict__ jtr, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     __shared__ float sR[J_ * 9], sJ[J_ * 3], sG[J_ * 12];
     const int b = blockIdx.x, j = threadIdx.x;
     float *w = ws + (size_t)b * WS_FRAME;
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restrict__ Q_kcv, const float *__restrict__ W_jv,
                                                           const float *__restrict__ betas, const float *__restrict__ trans,
                                                           const float *__restrict__ ws, int B,
-                                                          float *__restrict__ verts, float *__restrict__ v_posed, const float *__restrict__ W_sp, int nnz)
+                                                          float *__restrict__ verts, float *__restrict__ v_posed, const float *__restrict__ W_sp, int nnz, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sAx = lds;                       // [16][AXS] extended pose rows (GEMM phase) ...
     float *sA = lds;                        // ... then [8][SAS] A matrices of HALF the frames at a time (skinning phase)
@@ -298,8 +300,9 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
 template <int FB>
 __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__restrict__ W_v64, const float *__restrict__ ws,
                                                              const float *__restrict__ v_posed, const float *__restrict__ dverts,
-                                                             int B, float *__restrict__ part, float *__restrict__ dvp_g)
+                                                             int B, float *__restrict__ part, float *__restrict__ dvp_g, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sdT = lds;                        // [256][13]  dT rows of the frame in flight: dv (x) [v_posed; 1]
     float *sA = sdT + 256 * 13;              // [FB][624]  skinning transforms A_j (3x4) of the block's frames
@@ -396,8 +399,9 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
 #define BL_M 96
 #define BL_AS 132   /* LDS row stride of the staged A chunk (128 k + 4: stride = 4 mod 64 banks) */
 __global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__restrict__ Q_p, const float *__restrict__ dvp_g, int B,
-                                                              float *__restrict__ part3)
+                                                              float *__restrict__ part3, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     __shared__ __attribute__((aligned(16))) float sA[BL_M * BL_AS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int ks = blockIdx.x, m0 = blockIdx.z * BL_M, nt0 = blockIdx.y * 8 + wave * 2;
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
                                                               SmplParents par, const float *__restrict__ ws,
                                                               const float *__restrict__ part, const float *__restrict__ part3,
                                                               const float *__restrict__ djtr, int B, float *__restrict__ dpose, float *__restrict__ dbetas,
-                                                              float *__restrict__ dtrans)
+                                                              float *__restrict__ dtrans, const int *skip)
 {
+    VT_SKIP_RETURN(skip);
     __shared__ float red[PT_N], red3[NQ_];
     __shared__ float sdG[J_ * 12], sdJ[J_ * 3], sdR[J_ * 9];
     __shared__ float sG[J_ * 12], sRm[J_ * 9], sJr[J_ * 3];     // the frame's G, R, J: the serial chain below must not wait on HBM
@@ -619,13 +624,13 @@ extern "C" int vt_smplh_forward(const vt_smplh *h, const float *pose, const floa
                                 float *verts, float *jtr, float *v_posed, float *ws, void *stream)
 {
     VT_REQUIRE(h && pose && betas && trans && verts && v_posed && ws && B > 0, "vt_smplh_forward: null argument or B <= 0");
-    hipStream_t st = vt_stream(stream);
-    hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr);
+    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
+    hipLaunchKernelGGL(smplh_pose_kernel, dim3(B), dim3(64), 0, st, pose, betas, trans, h->J_t, h->J_s, h->par, ws, jtr, skip);
     VT_LAUNCH_CHECK();
     const size_t lds_f = sizeof(float) * (FWD_R0 + FWD_FB * 64 * 3 + (h->nnz > 0 ? 2 * SP_K * 64 : J_ * 64) + FWD_FB * 3);
     VT_LDS_LIMIT(smplh_verts_kernel, sizeof(float) * (FWD_R0 + FWD_FB * 64 * 3 + J_ * 64 + FWD_FB * 3));     // the limit is set once per device: the dense-weights size
     hipLaunchKernelGGL(smplh_verts_kernel, dim3(VP_ / 64, (B + FWD_FB - 1) / FWD_FB), dim3(256), lds_f, st, h->Q_kcv, h->W_jv, betas, trans, ws, B,
-                       verts, v_posed, h->W_sp, h->nnz);
+                       verts, v_posed, h->W_sp, h->nnz, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -636,15 +641,15 @@ extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const flo
 {
     (void)betas;
     VT_REQUIRE(h && pose && dverts && v_posed && ws && scratch && dpose && dbetas && dtrans && B > 0, "vt_smplh_backward: null argument or B <= 0");
-    hipStream_t st = vt_stream(stream);
+    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
     const size_t lds = sizeof(float) * (256 * 13 + BWD_FB * 624);
     float *dvp_g = scratch + (size_t)NVT_ * B * PT_N, *part3 = dvp_g + (size_t)B * KTOT_;
     VT_LDS_LIMIT(smplh_bwd_tile_kernel<BWD_FB>, lds);
-    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->W_v64, ws, v_posed, dverts, B, scratch, dvp_g);
+    hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->W_v64, ws, v_posed, dverts, B, scratch, dvp_g, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, 4, (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3);
+    hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, 4, (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, part3, djtr, B, dpose, dbetas, dtrans);
+    hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, part3, djtr, B, dpose, dbetas, dtrans, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

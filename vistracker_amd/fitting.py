@@ -12,6 +12,7 @@ prior gradient.  Loss VALUES keep every term the reference sums (the early-stop 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -48,6 +49,15 @@ def _ev_begin(prof):
         return None
     e = torch.cuda.Event(enable_timing=True); e.record()
     return e
+
+
+def _flush_events(prof, local, executed):
+    """append a fit's per-launch events to the caller's lists; ``executed`` = the number of steps that ran before the device-side stop (one query launch
+    per step): the launches queued behind it returned at their first instruction and are not query work"""
+    if prof is None:
+        return
+    for k, v in local.items():
+        prof[k].extend(v if executed is None else v[:executed])       # list.extend is atomic under the GIL (two fits in flight share ``prof``)
 
 
 def _ev_end(prof, key, e0, frames):
@@ -177,6 +187,8 @@ class FitContext:
     # point in the tail of the dominant kernel cost it 1 % (1.684 -> 1.700 ms), more than the three small launches it replaces were worth behind
     # the query (one stream 767.9 -> 777.8 ms per batch, two streams 690 -> 696; same box, two repetitions)
     fused_smpl_query = os.environ.get("VT_FUSED_SMPL_QUERY", "0") != "0"
+    # the query / SMPL-H launches queued behind the step that stopped a fit return at their first instruction (vt_stream_set_skip_flag)
+    device_skip = os.environ.get("VT_DEVICE_SKIP", "1") != "0"
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -292,36 +304,37 @@ class FitContext:
         temporal = temporal and B >= 3
         adam = None
         res = FitResult()
-        for it in range(start, end):
-            if adam is None or it == iter_for_global:
-                if it < iter_for_global:      # init_globalpose_optimizer: trans, global_pose, top_betas
-                    adam = AdamState([(trans, 3, dtrans, lr_global), (pose, 3, dpose, lr_global), (betas, 2, dbetas, lr_global)], stop)
-                else:                         # init_allpose_optimizer: trans, global, body, top_betas, other_betas
-                    adam = AdamState([(trans, 3, dtrans, lr_all), (pose, 66, dpose, lr_all), (betas, 10, dbetas, lr_all)], stop)
-            decay = it // 3
-            w = terms.weights(table, decay)
-            for i in range(10):
-                terms.zero(0, 5)
-                self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
-                _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
-                _chk(_lib().vt_kpts_loss(J.data_ptr(), kpts.data_ptr(), None, B, 25, 0, self.cam.ctypes.data, 0.0, float(w[0]), terms.ptr("kpts"), dJ.data_ptr(), L.stream_ptr()))
-                _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 0, L.stream_ptr()))
-                if temporal:
-                    _chk(_lib().vt_accel_loss(verts.data_ptr(), B, 6890 * 3, None, float(w[1]), terms.ptr("temp"), dverts.data_ptr(), L.stream_ptr()))
-                self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
-                if temporal:
-                    _chk(_lib().vt_accel_loss_strided(pose.data_ptr(), B, 66, 156, self.jw66.data_ptr(), float(w[2]), terms.ptr("ptemp"), dpose.data_ptr(), L.stream_ptr()))
-                self.body_prior(pose, dpose, float(w[3]), terms, "pose", vb)
-                _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 63, float(B * 63), float(w[4]),
-                                           terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
-                adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > 0.3 * max_iter), state.data_ptr(),
-                                                    stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
-                res.steps += 1
-            res.outer_iters += 1
-            if (it - start) % check_every == check_every - 1 and int(stop.item()):
-                res.stopped_early = True
-                break
+        with self._skip_after_stop(stop):
+            for it in range(start, end):
+                if adam is None or it == iter_for_global:
+                    if it < iter_for_global:      # init_globalpose_optimizer: trans, global_pose, top_betas
+                        adam = AdamState([(trans, 3, dtrans, lr_global), (pose, 3, dpose, lr_global), (betas, 2, dbetas, lr_global)], stop)
+                    else:                         # init_allpose_optimizer: trans, global, body, top_betas, other_betas
+                        adam = AdamState([(trans, 3, dtrans, lr_all), (pose, 66, dpose, lr_all), (betas, 10, dbetas, lr_all)], stop)
+                decay = it // 3
+                w = terms.weights(table, decay)
+                for i in range(10):
+                    terms.zero(0, 5)
+                    self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+                    _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_kpts_loss(J.data_ptr(), kpts.data_ptr(), None, B, 25, 0, self.cam.ctypes.data, 0.0, float(w[0]), terms.ptr("kpts"), dJ.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 0, L.stream_ptr()))
+                    if temporal:
+                        _chk(_lib().vt_accel_loss(verts.data_ptr(), B, 6890 * 3, None, float(w[1]), terms.ptr("temp"), dverts.data_ptr(), L.stream_ptr()))
+                    self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                    if temporal:
+                        _chk(_lib().vt_accel_loss_strided(pose.data_ptr(), B, 66, 156, self.jw66.data_ptr(), float(w[2]), terms.ptr("ptemp"), dpose.data_ptr(), L.stream_ptr()))
+                    self.body_prior(pose, dpose, float(w[3]), terms, "pose", vb)
+                    _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 63, float(B * 63), float(w[4]),
+                                               terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
+                    adam.step()
+                    _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > 0.3 * max_iter), state.data_ptr(),
+                                                        stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
+                    res.steps += 1
+                res.outer_iters += 1
+                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                    res.stopped_early = True
+                    break
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
@@ -356,6 +369,7 @@ class FitContext:
         vb = torch.empty(B, device=dev)
         pose_init = pose.clone()
         stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        lp = {"human": [], "object": []} if prof is not None else None      # this fit's per-launch events (flushed to ``prof`` below)
         state = torch.tensor([300.0, 300.0], device=dev)          # prev_loss = 300 (recon_fit_behave.py:408)
         fused = bool(self.fused_steps); ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         split_route = self.net.precision != "fp32" and not maps.force_fp32          # the step forms of the query exist on the split-f16 route only
@@ -373,68 +387,70 @@ class FitContext:
         hist = torch.full(((end - start) * 10,), float("nan"), device=dev)
         arm_after = 0.25 * max_iter + iter_for_betas + iter_for_pose
         adam = None; res = FitResult()
-        for it in range(start, end):
-            if it < iter_for_betas:
-                phase = "global"
-                if adam is None:
-                    adam = AdamState([(betas, 2, dbetas, 0.02), (trans, 3, dtrans, 0.02)], stop)
-            else:
-                phase = "kpts" if it >= iter_for_betas + iter_for_pose else "smpl all pose"
-                if adam is None or it == iter_for_betas:
-                    adam = AdamState([(trans, 3, dtrans, 0.006), (pose, 66, dpose, 0.006), (betas, 10, dbetas, 0.006)], stop)
-            decay = 1 if phase != "kpts" else it / 3
-            w = terms.weights(FIT_WEIGHTS, decay)
-            for i in range(10):
-                if not fused:
-                    terms.zero(0, 6)        # (fused: the tail of the previous step left them zeroed)
-                self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
-                if fused and split_route and self.fused_smpl_query:
-                    # keypoint chain (joints, 2-D term, its gradient written to dverts) in one launch, then the query adds its gradient and the vertex
-                    # acceleration stencil in its own epilogue: 8 launches per step with the two forward and three backward SMPL-H kernels and the tail
-                    if phase == "kpts":
-                        _chk(_lib().vt_kpts_step(self.b25.h, verts.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 1, self.cam.ctypes.data, net_size,
-                                                 float(w[4]), terms.ptr("j2d"), J.data_ptr(), dverts.data_ptr(), 0, L.stream_ptr()))
-                    ev = _ev_begin(prof)
-                    _chk(_lib().vt_query_human_step(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
-                                                    self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
-                                                    int(phase == "kpts"), float(w[5]), terms.ptr("stemp") if B >= 4 else None, dverts.data_ptr(), terms.ptr("df_h"),
-                                                    L.stream_ptr()))
-                    _ev_end(prof, "human", ev, B)
-                    self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
-                    self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
-                    res.steps += 1
-                    continue
-                ev = _ev_begin(prof)
-                _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
-                                                self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
-                                                dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
-                _ev_end(prof, "human", ev, B)
-                if phase == "kpts":
-                    _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
-                                             float(w[4]), terms.ptr("j2d"), dJ.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 1, L.stream_ptr()))
-                if B >= 4:
-                    _chk(_lib().vt_accel_loss(verts.data_ptr(), B, V * 3, None, float(w[5]), terms.ptr("stemp"), dverts.data_ptr(), L.stream_ptr()))
-                self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
-                if fused:
-                    self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
+        with self._skip_after_stop(stop):
+            for it in range(start, end):
+                if it < iter_for_betas:
+                    phase = "global"
+                    if adam is None:
+                        adam = AdamState([(betas, 2, dbetas, 0.02), (trans, 3, dtrans, 0.02)], stop)
                 else:
-                    self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
-                    # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
-                    _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
-                                               terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
-                    adam.step()
-                    _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(),
-                                                        stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
-                res.steps += 1
-            res.outer_iters += 1
-            if (it - start) % check_every == check_every - 1 and int(stop.item()):
-                res.stopped_early = True
-                break
+                    phase = "kpts" if it >= iter_for_betas + iter_for_pose else "smpl all pose"
+                    if adam is None or it == iter_for_betas:
+                        adam = AdamState([(trans, 3, dtrans, 0.006), (pose, 66, dpose, 0.006), (betas, 10, dbetas, 0.006)], stop)
+                decay = 1 if phase != "kpts" else it / 3
+                w = terms.weights(FIT_WEIGHTS, decay)
+                for i in range(10):
+                    if not fused:
+                        terms.zero(0, 6)        # (fused: the tail of the previous step left them zeroed)
+                    self.smpl_forward(pose, betas, trans, verts, jtr, vposed, ws)
+                    if fused and split_route and self.fused_smpl_query:
+                        # keypoint chain (joints, 2-D term, its gradient written to dverts) in one launch, then the query adds its gradient and the vertex
+                        # acceleration stencil in its own epilogue: 8 launches per step with the two forward and three backward SMPL-H kernels and the tail
+                        if phase == "kpts":
+                            _chk(_lib().vt_kpts_step(self.b25.h, verts.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 1, self.cam.ctypes.data, net_size,
+                                                     float(w[4]), terms.ptr("j2d"), J.data_ptr(), dverts.data_ptr(), 0, L.stream_ptr()))
+                        ev = _ev_begin(lp)
+                        _chk(_lib().vt_query_human_step(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
+                                                        self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
+                                                        int(phase == "kpts"), float(w[5]), terms.ptr("stemp") if B >= 4 else None, dverts.data_ptr(), terms.ptr("df_h"),
+                                                        L.stream_ptr()))
+                        _ev_end(lp, "human", ev, B)
+                        self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                        self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
+                        res.steps += 1
+                        continue
+                    ev = _ev_begin(lp)
+                    _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
+                                                    self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
+                                                    dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
+                    _ev_end(lp, "human", ev, B)
+                    if phase == "kpts":
+                        _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
+                                                 float(w[4]), terms.ptr("j2d"), dJ.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_landmarks_backward(self.b25.h, dJ.data_ptr(), B, dverts.data_ptr(), 1, L.stream_ptr()))
+                    if B >= 4:
+                        _chk(_lib().vt_accel_loss(verts.data_ptr(), B, V * 3, None, float(w[5]), terms.ptr("stemp"), dverts.data_ptr(), L.stream_ptr()))
+                    self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
+                    if fused:
+                        self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
+                    else:
+                        self.body_prior(pose, dpose, float(w[2]), terms, "pose", vb)
+                        # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2
+                        _chk(_lib().vt_sqdiff_loss(pose.data_ptr() + 12, 156, pose_init.data_ptr() + 12, 156, B, 69, float(B), float(w[3]),
+                                                   terms.ptr("pinit"), dpose.data_ptr() + 12, L.stream_ptr()))
+                        adam.step()
+                        _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-3, int(early_stop and it > arm_after), state.data_ptr(),
+                                                            stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
+                    res.steps += 1
+                res.outer_iters += 1
+                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                    res.stopped_early = True
+                    break
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+        _flush_events(prof, lp, res.steps if (res.stopped_early and self.device_skip) else None)
         _check_finite(res, "fit")
         return res
 
@@ -470,6 +486,7 @@ class FitContext:
         R = torch.empty(B, 3, 3, device=dev); X = torch.empty(B, N, 3, device=dev); dX = torch.empty_like(X)
         dR = torch.empty(B, 3, 3, device=dev); dM = torch.empty(B, 3, 3, device=dev); dt = torch.empty(B, 3, device=dev)
         stop = torch.zeros(1, dtype=torch.int32, device=dev); state = torch.tensor([300.0, 300.0], device=dev)
+        lp = {"human": [], "object": []} if prof is not None else None
         ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         hist = torch.full((nsteps,), float("nan"), device=dev)
         Rv, tv = obj_R.view(B, 9), obj_t
@@ -484,99 +501,117 @@ class FitContext:
         # -- zero for the obj_s == 1 that fit_recon passes -- but it is part of the summed loss the stop rule looks at
         ones = torch.ones_like(obj_s)
         _chk(_lib().vt_sqdiff_loss(obj_s.data_ptr(), 1, ones.data_ptr(), 1, B, 1, float(B), 0.0, terms.ptr("scale"), None, L.stream_ptr()))
-        for it in range(start, end):
-            if it < iter_for_obj:
-                phase = "object only"
-                if adam is None:
-                    adam = AdamState([(Rv, 9, dM.view(B, 9), 0.002), (tv, 3, dt, 0.006)], stop)
-            elif it < iter_for_obj + iter_for_sil:
-                phase = "sil"
-                if adam is None or it == iter_for_obj:
-                    adam = AdamState([(Rv, 9, dM.view(B, 9), 0.006), (tv, 3, dt, 0.006)], stop)
-                    trans_init = obj_t.clone()
-            else:
-                phase = "joint"
-                if adam is None or it == iter_for_obj + iter_for_sil:
-                    adam = AdamState([(tv, 3, dt, 0.002)], stop)
-            decay = 1 if phase == "object only" else (it - iter_for_obj + 1 if phase == "sil" else (it - iter_for_obj + 1) / 3)
-            tw = 10.0 if phase == "joint" else 1.0
-            w = terms.weights(FIT_WEIGHTS, decay, {"otemp": tw, "ovtemp": tw})
-            # the fused step launches cover everything but the interpenetration term (it adds to dt between the rigid VJP and the SO(3) VJP)
-            fused = bool(self.fused_steps) and not (phase == "joint" and self.collision_loss)
-            for i in range(10):
-                k = (it - start) * 10 + i
-                nz = noise[k]
-                if fused:
-                    if phase == "sil" and sil is None:
-                        raise L.VtError("phase 'sil' needs a SilSetup")
-                    self._object_step_fused(phase, maps, nz, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, w, terms, names, adam, B, N, NV, R, X, dX, dR, dM, dt,
-                                            Vt if sil is not None else None, dVt if sil is not None else None, img if sil is not None else None,
-                                            fidx if sil is not None else None, sws if sil is not None else None, dimg if sil is not None else None,
-                                            per if sil is not None else None, trans_init, smpl_verts, prof, state, stop, hist, k, ticket,
-                                            int(early_stop and phase == "joint" and it > 0.25 * max_iter), contact_box)
-                    res.steps += 1
-                    continue
-                terms.zero(0, 7)
-                _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
-                _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
-                acc = 0
-                if phase == "sil":
-                    if sil is None:
-                        raise L.VtError("phase 'sil' needs a SilSetup")
-                    _chk(_lib().vt_fill(dX.data_ptr(), dX.numel(), 0.0, L.stream_ptr()))
+        with self._skip_after_stop(stop):
+            for it in range(start, end):
+                if it < iter_for_obj:
+                    phase = "object only"
+                    if adam is None:
+                        adam = AdamState([(Rv, 9, dM.view(B, 9), 0.002), (tv, 3, dt, 0.006)], stop)
+                elif it < iter_for_obj + iter_for_sil:
+                    phase = "sil"
+                    if adam is None or it == iter_for_obj:
+                        adam = AdamState([(Rv, 9, dM.view(B, 9), 0.006), (tv, 3, dt, 0.006)], stop)
+                        trans_init = obj_t.clone()
                 else:
-                    ev = _ev_begin(prof)
-                    _chk(_lib().vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
-                                                     occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), L.stream_ptr()))
-                    _ev_end(prof, "object", ev, B)
-                if B >= 4:
-                    _chk(_lib().vt_accel_loss(X.data_ptr(), B, N * 3, None, float(w[1]), terms.ptr("otemp"), dX.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_velocity_loss(X.data_ptr(), B, N * 3, float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), L.stream_ptr()))
-                if phase == "sil":
-                    _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vt.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
-                                               img.data_ptr(), fidx.data_ptr(), sws.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
-                                                 terms.ptr("mask"), per.data_ptr(), dimg.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_sil_backward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
-                                                fidx.data_ptr(), dimg.data_ptr(), 1e-4, sws.data_ptr(), dVt.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_rigid_backward(self.obj_verts.data_ptr(), 1, obj_s.data_ptr(), B, NV, dVt.data_ptr(), dR.data_ptr(), dt.data_ptr(), 0, L.stream_ptr()))
-                    _chk(_lib().vt_sqdiff_loss(obj_t.data_ptr(), 3, trans_init.data_ptr(), 3, B, 3, float(B * 3), float(w[4]), terms.ptr("trans"), dt.data_ptr(), L.stream_ptr()))
-                    acc = 1
-                if phase == "joint":
-                    if contact_box[0] is None:
-                        contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
-                    contact = contact_box[0]
-                    if contact["P"] > 0:
-                        y = X.view(-1, 3).index_select(0, contact["idx_o"])
-                        dy = torch.zeros_like(y)
-                        _chk(_lib().vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
-                                                      contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), L.stream_ptr()))
-                        dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
-                _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
-                if phase == "joint" and self.collision_loss:
-                    # prevent interpenetration (recon_fit_trivis_full.py:260-264): SMPL mesh vs the transformed object template
-                    if cws is None:
-                        Vc = torch.empty(B, NV, 3, device=dev)
-                        cws = torch.empty((_lib().vt_collision_workspace_bytes(B, self.smpl_faces.shape[0]) + 7) // 8, dtype=torch.int64, device=dev)
-                    _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vc.data_ptr(), L.stream_ptr()))
-                    _chk(_lib().vt_collision_loss(smpl_verts.data_ptr(), smpl_verts.shape[1], self.smpl_faces.data_ptr(), self.smpl_faces.shape[0], Vc.data_ptr(), NV,
-                                                  self.obj_faces.data_ptr(), self.obj_faces.shape[0], B, 0.5, 8, float(w[6]), terms.ptr("collide"), dt.data_ptr(), None,
-                                                  cws.data_ptr(), L.stream_ptr()))
-                _chk(_lib().vt_so3_project_backward(obj_R.data_ptr(), nz.data_ptr(), B, dR.data_ptr(), dM.data_ptr(), L.stream_ptr()))
-                adam.step()
-                _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(early_stop and phase == "joint" and it > 0.25 * max_iter),
-                                                    state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
-                res.steps += 1
-            res.outer_iters += 1
-            if (it - start) % check_every == check_every - 1 and int(stop.item()):
-                res.stopped_early = True
-                break
+                    phase = "joint"
+                    if adam is None or it == iter_for_obj + iter_for_sil:
+                        adam = AdamState([(tv, 3, dt, 0.002)], stop)
+                decay = 1 if phase == "object only" else (it - iter_for_obj + 1 if phase == "sil" else (it - iter_for_obj + 1) / 3)
+                tw = 10.0 if phase == "joint" else 1.0
+                w = terms.weights(FIT_WEIGHTS, decay, {"otemp": tw, "ovtemp": tw})
+                # the fused step launches cover everything but the interpenetration term (it adds to dt between the rigid VJP and the SO(3) VJP)
+                fused = bool(self.fused_steps) and not (phase == "joint" and self.collision_loss)
+                for i in range(10):
+                    k = (it - start) * 10 + i
+                    nz = noise[k]
+                    if fused:
+                        if phase == "sil" and sil is None:
+                            raise L.VtError("phase 'sil' needs a SilSetup")
+                        self._object_step_fused(phase, maps, nz, obj_R, obj_t, obj_s, crop_center, body_center, occ, sil, w, terms, names, adam, B, N, NV, R, X, dX, dR, dM, dt,
+                                                Vt if sil is not None else None, dVt if sil is not None else None, img if sil is not None else None,
+                                                fidx if sil is not None else None, sws if sil is not None else None, dimg if sil is not None else None,
+                                                per if sil is not None else None, trans_init, smpl_verts, lp, state, stop, hist, k, ticket,
+                                                int(early_stop and phase == "joint" and it > 0.25 * max_iter), contact_box)
+                        res.steps += 1
+                        continue
+                    terms.zero(0, 7)
+                    _chk(_lib().vt_so3_project_forward(obj_R.data_ptr(), nz.data_ptr(), B, R.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_rigid_forward(self.obj_points.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, N, X.data_ptr(), L.stream_ptr()))
+                    acc = 0
+                    if phase == "sil":
+                        if sil is None:
+                            raise L.VtError("phase 'sil' needs a SilSetup")
+                        _chk(_lib().vt_fill(dX.data_ptr(), dX.numel(), 0.0, L.stream_ptr()))
+                    else:
+                        ev = _ev_begin(lp)
+                        _chk(_lib().vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
+                                                         occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), L.stream_ptr()))
+                        _ev_end(lp, "object", ev, B)
+                    if B >= 4:
+                        _chk(_lib().vt_accel_loss(X.data_ptr(), B, N * 3, None, float(w[1]), terms.ptr("otemp"), dX.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_velocity_loss(X.data_ptr(), B, N * 3, float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), L.stream_ptr()))
+                    if phase == "sil":
+                        _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vt.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                                   img.data_ptr(), fidx.data_ptr(), sws.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
+                                                     terms.ptr("mask"), per.data_ptr(), dimg.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_sil_backward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
+                                                    fidx.data_ptr(), dimg.data_ptr(), 1e-4, sws.data_ptr(), dVt.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_rigid_backward(self.obj_verts.data_ptr(), 1, obj_s.data_ptr(), B, NV, dVt.data_ptr(), dR.data_ptr(), dt.data_ptr(), 0, L.stream_ptr()))
+                        _chk(_lib().vt_sqdiff_loss(obj_t.data_ptr(), 3, trans_init.data_ptr(), 3, B, 3, float(B * 3), float(w[4]), terms.ptr("trans"), dt.data_ptr(), L.stream_ptr()))
+                        acc = 1
+                    if phase == "joint":
+                        if contact_box[0] is None:
+                            contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
+                        contact = contact_box[0]
+                        if contact["P"] > 0:
+                            y = X.view(-1, 3).index_select(0, contact["idx_o"])
+                            dy = torch.zeros_like(y)
+                            _chk(_lib().vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
+                                                          contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), L.stream_ptr()))
+                            dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
+                    _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
+                    if phase == "joint" and self.collision_loss:
+                        # prevent interpenetration (recon_fit_trivis_full.py:260-264): SMPL mesh vs the transformed object template
+                        if cws is None:
+                            Vc = torch.empty(B, NV, 3, device=dev)
+                            cws = torch.empty((_lib().vt_collision_workspace_bytes(B, self.smpl_faces.shape[0]) + 7) // 8, dtype=torch.int64, device=dev)
+                        _chk(_lib().vt_rigid_forward(self.obj_verts.data_ptr(), 1, R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, NV, Vc.data_ptr(), L.stream_ptr()))
+                        _chk(_lib().vt_collision_loss(smpl_verts.data_ptr(), smpl_verts.shape[1], self.smpl_faces.data_ptr(), self.smpl_faces.shape[0], Vc.data_ptr(), NV,
+                                                      self.obj_faces.data_ptr(), self.obj_faces.shape[0], B, 0.5, 8, float(w[6]), terms.ptr("collide"), dt.data_ptr(), None,
+                                                      cws.data_ptr(), L.stream_ptr()))
+                    _chk(_lib().vt_so3_project_backward(obj_R.data_ptr(), nz.data_ptr(), B, dR.data_ptr(), dM.data_ptr(), L.stream_ptr()))
+                    adam.step()
+                    _chk(_lib().vt_loss_reduce_and_stop(terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, int(early_stop and phase == "joint" and it > 0.25 * max_iter),
+                                                        state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
+                    res.steps += 1
+                res.outer_iters += 1
+                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                    res.stopped_early = True
+                    break
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+        _flush_events(prof, lp, res.steps if (res.stopped_early and self.device_skip) else None)
         _check_finite(res, "fit")
         return res
+
+    @contextlib.contextmanager
+    def _skip_after_stop(self, stop):
+        """While the body runs, the query and SMPL-H kernels launched on the current stream return at once when ``stop`` is set
+        (vt_stream_set_skip_flag): the steps queued behind the one whose stop rule fired -- up to nine, the host reads the flag once per outer
+        iteration -- cost a launch each instead of a pass (results unchanged: Adam and the loss history ignore them already).  The callers drop the
+        per-launch events of those no-op launches from a profiled run, so that bench.py prices executed launches only."""
+        if not self.device_skip:
+            yield
+            return
+        sp = L.stream_ptr()
+        _chk(_lib().vt_stream_set_skip_flag(sp, stop.data_ptr()))
+        try:
+            yield
+        finally:
+            _lib().vt_stream_set_skip_flag(sp, None)
 
     def _smpl_tail(self, pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, slot, ticket, armed):
         """body prior + pinit + Adam on every group + loss reduction / stop rule + term zeroing: one launch (vt_smplstep_tail)"""
