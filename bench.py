@@ -233,6 +233,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
+    ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
+                    help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
+                         "stream runs the object stage of every batch as soon as its SMPL stage is done (the chip-filling query launches of one stage "
+                         "beside the small silhouette / rigid-transform launches of the other)")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs after the timed region (kernel alone, full schedule, "
                                                               "SIF-Net inference = configs[3], demo pipeline = configs[4])")
     ap.add_argument("--pipeline-frames", type=int, default=1500)
@@ -320,7 +324,35 @@ def main():
                 for i in range(k, len(batches), args.streams):
                     results[i] = fit_batch(ctx, torch, batches[i], prof)
 
-        th_ = [threading.Thread(target=worker, args=(k,)) for k in range(args.streams)]
+        ready = [threading.Event() for _ in batches]; half = [None] * len(batches)
+
+        def smpl_worker(k):
+            from vistracker_amd import ops
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[k]):
+                for i in range(k, len(batches), args.streams):
+                    d = batches[i]
+                    r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof)
+                    with torch.no_grad():
+                        verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
+                    ev = torch.cuda.Event(); ev.record(streams[k])
+                    half[i] = (r1, verts, ev); ready[i].set()
+
+        def object_worker():
+            torch.cuda.set_device(dev)
+            so = torch.cuda.Stream(device=dev); so.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(so):
+                for i, d in enumerate(batches):
+                    ready[i].wait()
+                    r1, verts, ev = half[i]; so.wait_event(ev)
+                    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof)
+                    results[i] = (r1, r2)
+                so.synchronize()
+
+        if args.schedule == "staged":
+            th_ = [threading.Thread(target=smpl_worker, args=(k,)) for k in range(args.streams)] + [threading.Thread(target=object_worker)]
+        else:
+            th_ = [threading.Thread(target=worker, args=(k,)) for k in range(args.streams)]
         for t_ in th_: t_.start()
         for t_ in th_: t_.join()
         for s_ in streams:

@@ -209,6 +209,19 @@ int vt_conv1x1_forward(const vt_conv1x1 *h, const float *in, int in_cstride, int
                        int B, int H, int W, float *out, int out_cstride, int out_coff, const float *res, int res_cstride, int res_coff,
                        double *stats_ws, int stats_groups, void *stream);
 int vt_groupnorm_finalize(double *ws, int nblk, int B, int HW, int C, int groups, float eps, void *stream);
+/* vt_conv3x3_forward_block + the GroupNorm partial sums of `fin` (convolution + residual: the ConvBlock's result, model/net_util.py:390-394) for the
+ * ConvBlock that reads it next: every launch of a block writes the partials of its channel slice [fin_coff, fin_coff + Cout) into one block of
+ * fin_cstride channels per 8 x 16 pixel tile at fin_stats_ws + B * fin_stats_groups doubles; after the block's last launch
+ * vt_groupnorm_finalize(fin_stats_ws, vt_conv3x3_tiles(H, W), B, H * W, fin_cstride, fin_stats_groups, eps) yields what vt_groupnorm_stats(fin) would. */
+int vt_conv3x3_forward_block_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                   const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff,
+                                   const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
+                                   double *stats_ws, int stats_groups, double *fin_stats_ws, int fin_stats_groups, void *stream);
+/* 2 x 2 average pooling of an NHWC tensor (F.avg_pool2d(x, 2, stride=2): model/HGFilters.py:33,131-136), x (B, H, W, C) -> out (B, H/2, W/2, C), and
+ * -- stats_ws != NULL -- the GroupNorm partial sums of the OUTPUT: vt_sweep_blocks(H/2 * W/2) blocks at stats_ws + B * stats_groups doubles, for
+ * vt_groupnorm_finalize(stats_ws, vt_sweep_blocks(..), B, H/2 * W/2, C, stats_groups, eps) in place of a statistics pass by the consumer. */
+int vt_avgpool2x2_stats(const float *x, int B, int H, int W, int C, float *out, double *stats_ws, int stats_groups, void *stream);
+int vt_sweep_blocks(int HW);
 /* GroupNorm statistics of a channel slice: ws >= vt_groupnorm_workspace_doubles(B, HW, C, groups) doubles; the (B, groups) {mean, rstd} float pairs
  * are written at the START of ws (pass `(const float *)ws` as gn_stats) */
 int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int C, int groups, float eps, double *ws, void *stream);
@@ -388,6 +401,9 @@ int vt_triplane_render(const float *verts, const float *center, int B, int NV, c
  * A = -0.75, source coordinate dst * (h-1)/(2h-1), taps clamped to the border.  low (B,h,w,C), skip (B,2h,2w,C) or NULL, out (B,2h,2w,C);
  * C must be a multiple of 4.  (The convolutions and group norms of the encoder run on MIOpen through PyTorch.) */
 int vt_upsample2x_bicubic_add(const float *low, const float *skip, int B, int h, int w, int C, float *out, void *stream);
+/* the same arithmetic + the GroupNorm partial sums of the output (vt_sweep_blocks(4 h w) blocks, see vt_avgpool2x2_stats) */
+int vt_upsample2x_bicubic_add_stats(const float *low, const float *skip, int B, int h, int w, int C, float *out, double *stats_ws, int stats_groups,
+                                    void *stream);
 
 /* GroupNorm (+ ReLU) of an NHWC fp32 tensor, the `bnK -> F.relu` prologue of every pre-activated convolution of the encoder
  * (model/net_util.py:374-388, model/HGFilters.py:176,192-193): y = [relu]((x - mean_g) / sqrt(var_g + eps) * gamma + beta) with the

@@ -819,3 +819,58 @@ def test_conv1x1_vs_float64(hip, cin, cout):
     L.check(lib.vt_conv1x1_forward(h, L.dptr(xn), cin + cpad, 4, L.dptr(ws), L.dptr(ga), L.dptr(be), groups, B, H, W, L.dptr(out2), cout, 0, L.dptr(rn), cout, 0, None, 0, L.stream_ptr()))
     assert np.abs(npy(out2) - ref2).max() < 3e-6 * np.abs(ref2).max(), np.abs(npy(out2) - ref2).max() / np.abs(ref2).max()
     lib.vt_conv1x1_destroy(h)
+
+
+def test_producer_side_groupnorm_statistics(hip):
+    """Round 3: the GroupNorm statistics of a ConvBlock's input come from partial sums its PRODUCER left behind -- the previous block's epilogue
+    (vt_conv3x3_forward_block_stats: convolution + residual), the pooling kernel (vt_avgpool2x2_stats), the up-sampling kernel
+    (vt_upsample2x_bicubic_add_stats), the 1 x 1 sum at the end of a stack -- instead of a pass over the tensor (vt_groupnorm_stats).  Every producer's
+    {mean, rstd} pairs against the pass over its output, the pooled tensor against torch, and the encoder with / without the hand-over."""
+    import torch.nn.functional as F
+    from vistracker_amd import synthetic as syn, _lib as L, encoder as E
+    lib = L.lib()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+
+    def pass_stats(t):
+        B, C, H, W = t.shape
+        ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, C, 32), dtype=torch.float64, device="cuda")
+        L.check(lib.vt_groupnorm_stats(t.data_ptr(), C, 0, B, H * W, C, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+        return ws[: B * 32].view(torch.float32).reshape(B, 32, 2).cpu().numpy().copy()
+
+    def handed(t):
+        ws = E._stats_of(t); assert ws is not None
+        return ws[: t.shape[0] * 32].view(torch.float32).reshape(t.shape[0], 32, 2).cpu().numpy().copy()
+
+    def check(t, what):
+        a, b = handed(t), pass_stats(t)
+        scale = np.abs(b[..., 0]).max() + 1.0 / b[..., 1].min()
+        assert np.abs(a[..., 0] - b[..., 0]).max() < 2e-6 * scale and np.abs(a[..., 1] / b[..., 1] - 1).max() < 2e-6, (what, np.abs(a - b).max())
+
+    x = (torch.randn(3, 64, 32, 48, device="cuda", generator=gen) * 2 + 0.7).contiguous(memory_format=torch.channels_last)
+    p = E.avgpool2x2(x)
+    assert torch.equal(p, F.avg_pool2d(x, 2, stride=2)) or (p - F.avg_pool2d(x, 2, stride=2)).abs().max().item() < 1e-6
+    check(p, "pool")
+    low = torch.randn(2, 128, 8, 16, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    skip = torch.randn(2, 128, 16, 32, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    u = E.upsample2x_bicubic_add(low, skip)
+    ref = skip.cpu() + F.interpolate(low.cpu(), scale_factor=2, mode="bicubic", align_corners=True)
+    assert (u.cpu() - ref).abs().max().item() < 5e-6
+    check(u, "upsample")
+    # a whole encoder: every block output carries statistics that match a pass over it; outputs with / without the hand-over agree to round-off
+    g = golden("encoder")
+    ks = [(str(n), tuple(int(v) for v in s[:d])) for n, s, d in zip(g["names"], g["shapes"], g["ndims"])]
+    enc = E.SIFNetEncoder.from_state_dict(syn.encoder_weights(ks))
+    hg = enc.image
+    xin = torch.randn(2, 64, 32, 32, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    blk = hg._conv_block(xin, "conv2.")
+    check(blk, "block result (conv + residual, with the 1 x 1 projection of conv2)")
+    blk2 = hg._conv_block(hg._conv_block(E.avgpool2x2(blk), "conv3."), "conv4.")
+    check(blk2, "block result, statistics of its input handed over twice")
+    img = cu(g["images"])
+    a = enc(img)
+    for h_ in (enc.image, *enc.tri):
+        h_.producer_stats = False
+    b = enc(img)
+    for name, ta, tb in zip(hip["ops"].MAP_ORDER, a.t, b.t):
+        e = (ta - tb).abs().max().item() / max(1.0, tb.abs().max().item())
+        assert e < 2e-6, (name, e)

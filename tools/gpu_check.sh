@@ -11,6 +11,9 @@ tail -c 3000 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err
 d=$(mktemp -d /tmp/prof.XXXX)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 2 --warmup 1 --no-extras --no-cpu-baseline ) > gpurun_out/${tag}_prof.log 2>&1
 f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_1stream.csv && head -12 $f
+# the launches queued behind a fit's stop step return at their first instruction (vt_stream_set_skip_flag) but are launches of the same kernel: the table's
+# average includes them; the per-dispatch trace gives the average of the launches that did the work (what bench.py's avg_launch_ms measures)
+t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/trace_summary.py $t "query_kernel<2, 2" "query_kernel<1, 3" > gpurun_out/${tag}_query_launches_1stream.json && cat gpurun_out/${tag}_query_launches_1stream.json
 tail -3 gpurun_out/${tag}_prof.log
 # HBM-side traffic of the query kernels: separate --pmc passes (FETCH_SIZE / WRITE_SIZE do not fit one pass), one stream, one batch
 for c in FETCH_SIZE WRITE_SIZE; do

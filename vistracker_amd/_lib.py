@@ -79,6 +79,10 @@ SIGNATURES = {
     "vt_conv1x1_destroy": (None, [vp]),
     "vt_conv1x1_forward": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_conv3x3_forward_block": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),
+    "vt_conv3x3_forward_block_stats": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, fp, ci, vp]),
+    "vt_avgpool2x2_stats": (ci, [fp, ci, ci, ci, ci, fp, fp, ci, vp]),
+    "vt_sweep_blocks": (ci, [ci]),
+    "vt_upsample2x_bicubic_add_stats": (ci, [fp, fp, ci, ci, ci, ci, fp, fp, ci, vp]),
     "vt_conv3x3_forward_gn_stats": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_triplane_render": (ci, [fp, fp, ci, ci, fp, ci, ci, fp, fp, fp, vp]),
     "vt_query_project_step": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, ci, cf, fp, fp, vp]),

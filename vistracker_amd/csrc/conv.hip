@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
                                                          float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part,
                                                          const float *__restrict__ res, int res_cstride, int res_coff, float *__restrict__ fin, int fin_cstride, int fin_coff,
-                                                         const float *__restrict__ bias, int stats_cstride, int stats_coff)
+                                                         const float *__restrict__ bias, int stats_cstride, int stats_coff,
+                                                         double *__restrict__ fstats_part, int fstats_cstride, int fstats_coff)
 {
     constexpr int PW = K3 ? CV_PW : CV_TW, PX = K3 ? CV_PX : CV_TH * CV_TW, NLD = K3 ? 6 : 4, NTAP = K3 ? 9 : 1;
     // 1 x 1 form: one tap per chunk makes an iteration nine times shorter than the 3 x 3 one, so the input loads run RING - 1 = 3 chunks ahead of
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
             *reinterpret_cast<float4 *>(tile + (p * CV_TW + j) * TS + wave * 16 + 4 * q) = v;
         }
         __syncthreads();
+        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};       // sum / sum of squares of `fin` over this thread's 8 pixels (4 channels)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int item = r * 256 + tid, piece = item & 15, px = item >> 4;                  // 128 pixels x 16 pieces of 4 channels
@@ -236,7 +238,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict
             if (ob) *reinterpret_cast<float4 *>(ob + ((size_t)y * W + x) * out_cstride + co) = v;
             if (fb) {
                 const float4 rr = *reinterpret_cast<const float4 *>(rb + ((size_t)y * W + x) * res_cstride + co);
-                *reinterpret_cast<float4 *>(fb + ((size_t)y * W + x) * fin_cstride + co) = make_float4(v.x + rr.x, v.y + rr.y, v.z + rr.z, v.w + rr.w);
+                const float4 o = make_float4(v.x + rr.x, v.y + rr.y, v.z + rr.z, v.w + rr.w);
+                *reinterpret_cast<float4 *>(fb + ((size_t)y * W + x) * fin_cstride + co) = o;
+                fs[0] += o.x; fs[1] += o.y; fs[2] += o.z; fs[3] += o.w;
+                fq[0] = __builtin_fmaf(o.x, o.x, fq[0]); fq[1] = __builtin_fmaf(o.y, o.y, fq[1]); fq[2] = __builtin_fmaf(o.z, o.z, fq[2]); fq[3] = __builtin_fmaf(o.w, o.w, fq[3]);
+            }
+        }
+        // GroupNorm statistics of the block's RESULT (convolution + residual) for the ConvBlock that reads it next: the piece index of a thread is
+        // tid & 15 in every round, so the 4 lanes x 4 waves that share it hold the tile's 128 pixels of its four channels; one block of partials
+        // per tile in the layout of vt_groupnorm_stats (the consumer calls vt_groupnorm_finalize instead of a statistics pass over the tensor)
+        if (fstats_part) {
+            float *xw = tile + 128 * TS;                        // [4 waves][16 pieces][8]: beyond the staged tile (34 KB of the 46 KB patch buffers)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                fs[k] += __shfl_xor(fs[k], 16, 64); fs[k] += __shfl_xor(fs[k], 32, 64);
+                fq[k] += __shfl_xor(fq[k], 16, 64); fq[k] += __shfl_xor(fq[k], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { xw[(wave * 16 + lane) * 8 + k] = fs[k]; xw[(wave * 16 + lane) * 8 + 4 + k] = fq[k]; }
+            }
+            __syncthreads();
+            if (tid < 16) {
+                const int co = ((tid >> 2) * NT + nt) * 16 + (tid & 3) * 4;
+                if (co < cout) {
+                    double *pp = fstats_part + (((size_t)blockIdx.x * gridDim.y + b) * fstats_cstride + fstats_coff + co) * 2;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        pp[2 * k] = (double)xw[tid * 8 + k] + (double)xw[(16 + tid) * 8 + k] + (double)xw[(32 + tid) * 8 + k] + (double)xw[(48 + tid) * 8 + k];
+                        pp[2 * k + 1] = (double)xw[tid * 8 + 4 + k] + (double)xw[(16 + tid) * 8 + 4 + k] + (double)xw[(32 + tid) * 8 + 4 + k] + (double)xw[(48 + tid) * 8 + 4 + k];
+                    }
+                }
             }
         }
     }
@@ -298,6 +330,17 @@ extern "C" int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, in
                                         const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
                                         double *stats_ws, int stats_groups, void *stream)
 {
+    return vt_conv3x3_forward_block_stats(h, in, in_cstride, in_coff, gn_stats, gamma, beta, groups, B, H, W, out, out_cstride, out_coff, res, res_cstride, res_coff,
+                                          fin, fin_cstride, fin_coff, stats_ws, stats_groups, nullptr, 0, stream);
+}
+// + the GroupNorm partial sums of `fin` (convolution + residual) for the NEXT ConvBlock, which normalises exactly this tensor: the launches of a block write
+// the partials of their channel slices [fin_coff, fin_coff + Cout) into ONE block of fin_cstride channels per tile at fin_stats_ws + B * fin_stats_groups
+// doubles; vt_groupnorm_finalize(fin_stats_ws, tiles, B, H * W, fin_cstride, fin_stats_groups, eps) after the last one replaces vt_groupnorm_stats(fin).
+extern "C" int vt_conv3x3_forward_block_stats(const vt_conv3x3 *h, const float *in, int in_cstride, int in_coff, const float *gn_stats, const float *gamma,
+                                              const float *beta, int groups, int B, int H, int W, float *out, int out_cstride, int out_coff,
+                                              const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
+                                              double *stats_ws, int stats_groups, double *fin_stats_ws, int fin_stats_groups, void *stream)
+{
     VT_REQUIRE(h && in && (out || fin) && B > 0 && H % CV_TH == 0 && W % CV_TW == 0
                    && in_cstride >= in_coff + h->cin && in_cstride % 4 == 0 && in_coff % 4 == 0,
                "vt_conv3x3_forward: needs H %% 8 == 0, W %% 16 == 0 and 16-byte aligned channel slices");
@@ -309,8 +352,10 @@ extern "C" int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, in
     const float2 *st2 = reinterpret_cast<const float2 *>(gn_stats);
     VT_REQUIRE(!stats_ws || stats_groups > 0, "vt_conv3x3_forward_block: stats_groups must be positive");
     double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
-    if (h->nt == 2) hipLaunchKernelGGL((conv3x3_kernel<2, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0);
-    else hipLaunchKernelGGL((conv3x3_kernel<1, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0);
+    VT_REQUIRE(!fin_stats_ws || (fin && fin_stats_groups > 0), "vt_conv3x3_forward_block_stats: the statistics of the result need the result (fin) and a positive group count");
+    double *fpart = fin_stats_ws ? fin_stats_ws + (size_t)B * fin_stats_groups : nullptr;
+    if (h->nt == 2) hipLaunchKernelGGL((conv3x3_kernel<2, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0, fpart, fin_cstride, fin_coff);
+    else hipLaunchKernelGGL((conv3x3_kernel<1, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0, fpart, fin_cstride, fin_coff);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -394,11 +439,12 @@ extern "C" int vt_conv1x1_forward(const vt_conv1x1 *h, const float *in, int in_c
     double *part = stats_ws ? stats_ws + (size_t)B * stats_groups : nullptr;
     for (int pt = 0; pt < h->parts; pt++) {
         const int o = pt * h->pcout;
-        // with a residual the sum is the layer's only output (`fin`), without one the plain result (`out`): the statistics are those of conv + bias
+        // with a residual the sum is the layer's only output (`fin`), without one the plain result (`out`): the statistics are those of what is written
         float *o_plain = res ? nullptr : out; float *o_fin = res ? out : nullptr;
         const float *bs = h->bias ? h->bias + o : nullptr;
 #define CV_L1(NT_, NCH_) hipLaunchKernelGGL((conv3x3_kernel<NT_, false, NCH_>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w[pt], st2, gamma, beta, groups, \
-                                          o_plain, out_cstride, out_coff + o, h->inv_scale, h->pcout, part, res, res_cstride, res_coff + o, o_fin, out_cstride, out_coff + o, bs, h->cout, o)
+                                          o_plain, out_cstride, out_coff + o, h->inv_scale, h->pcout, res ? nullptr : part, res, res_cstride, res_coff + o, o_fin, out_cstride, out_coff + o, bs, h->cout, o, \
+                                          res ? part : nullptr, h->cout, o)
         const int nch = h->cin / 32;
         if (h->nt == 2) { if (nch == 1) CV_L1(2, 1); else if (nch == 2) CV_L1(2, 2); else if (nch == 4) CV_L1(2, 4); else CV_L1(2, 8); }
         else { if (nch == 1) CV_L1(1, 1); else if (nch == 2) CV_L1(1, 2); else if (nch == 4) CV_L1(1, 4); else CV_L1(1, 8); }

@@ -512,6 +512,123 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     }
     *reinterpret_cast<float4 *>(y + pix * C + 4 * c4) = make_float4(out[0], out[1], out[2], out[3]);
 }
+// Producers that leave the GroupNorm partial sums of their OUTPUT behind (layout of gn_stats_kernel: one block of (B, C) x {sum, sum of squares} per
+// workgroup), so that the ConvBlock that reads the tensor next calls vt_groupnorm_finalize instead of a statistics pass over it:
+//   OP 0: 2 x 2 average pooling (F.avg_pool2d(x, 2, stride=2): model/HGFilters.py:33, 131-136), x (B, 2h, 2w, C) -> (B, h, w, C)
+//   OP 1: skip + bicubic x2 up-sampling of low (upsample2x_bicubic_add_kernel's arithmetic), low (B, h / 2, w / 2, C), skip / out (B, h, w, C)
+// grid = (blocks of output pixels, B); thread = (pixel slot, float4 of channels) like gn_stats_kernel.
+template <int OP>
+__global__ __launch_bounds__(256) void sweep_stats_kernel(const float *__restrict__ a, const float *__restrict__ skip, int h, int w, int C, int rows_per_block,
+                                                          float *__restrict__ out, double *__restrict__ part)
+{
+    // (h, w) = the output size.  OP 0: a block item is an output pixel; OP 1: an output QUAD (2 x 2 pixels = one pixel of `low`): its four pixels read
+    // their 4 x 4 taps from one 5 x 5 patch of `low` (the tap bases of neighbouring output pixels differ by at most one), 25 loads instead of 64
+    const int C4 = C >> 2, b = blockIdx.y, c4 = threadIdx.x % C4, slot = threadIdx.x / C4, nslot = 256 / C4, HW = h * w;
+    const int lh = h >> 1, lw = w >> 1, items = OP == 0 ? HW : lh * lw;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(items, p0 + rows_per_block);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    auto emit = [&](int oy, int ox, const float4 v) {
+        *reinterpret_cast<float4 *>(out + ((size_t)b * HW + (size_t)oy * w + ox) * C + 4 * c4) = v;
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    };
+    if (slot < nslot)
+        for (int p = p0 + slot; p < p1; p += nslot) {
+            if (OP == 0) {
+                const int oy = p / w, ox = p - oy * w;
+                const float *r0 = a + (((size_t)b * 2 * h + 2 * oy) * 2 * w + 2 * ox) * C + 4 * c4, *r1 = r0 + (size_t)2 * w * C;
+                const float4 v00 = *reinterpret_cast<const float4 *>(r0), v01 = *reinterpret_cast<const float4 *>(r0 + C);
+                const float4 v10 = *reinterpret_cast<const float4 *>(r1), v11 = *reinterpret_cast<const float4 *>(r1 + C);
+                // avg_pool2d: the window summed row by row, divided by 4
+                emit(oy, ox, make_float4((v00.x + v01.x + v10.x + v11.x) * 0.25f, (v00.y + v01.y + v10.y + v11.y) * 0.25f, (v00.z + v01.z + v10.z + v11.z) * 0.25f,
+                                         (v00.w + v01.w + v10.w + v11.w) * 0.25f));
+            } else {
+                const int qy = p / lw, qx = p - qy * lw;
+                const float sy = h > 1 ? (float)(lh - 1) / (float)(h - 1) : 0.f, sx = w > 1 ? (float)(lw - 1) / (float)(w - 1) : 0.f;
+                float fy[2], fx[2]; int iy[2], ix[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    fy[e] = sy * (float)(2 * qy + e); iy[e] = (int)floorf(fy[e]);
+                    fx[e] = sx * (float)(2 * qx + e); ix[e] = (int)floorf(fx[e]);
+                }
+                const int ry = iy[0] - 1, rx = ix[0] - 1;       // patch origin; iy[1] - iy[0], ix[1] - ix[0] are 0 or 1
+                float4 pt[5][5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    const int yy = min(max(ry + i, 0), lh - 1);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int xx = min(max(rx + k, 0), lw - 1);
+                        pt[i][k] = *reinterpret_cast<const float4 *>(a + (((size_t)b * lh + yy) * lw + xx) * C + 4 * c4);
+                    }
+                }
+#pragma unroll
+                for (int ey = 0; ey < 2; ey++) {
+                    float wy[4]; cubic_w(fy[ey] - iy[ey], wy);
+                    const bool dy = iy[ey] != iy[0];
+#pragma unroll
+                    for (int ex = 0; ex < 2; ex++) {
+                        float wx[4]; cubic_w(fx[ex] - ix[ex], wx);
+                        const bool dx = ix[ex] != ix[0];
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const float4 t0 = pt[i][k], t1 = pt[i][k + 1], u0 = pt[i + 1][k], u1 = pt[i + 1][k + 1];
+                                const float4 t = dy ? (dx ? u1 : u0) : (dx ? t1 : t0);
+                                row.x += wx[k] * t.x; row.y += wx[k] * t.y; row.z += wx[k] * t.z; row.w += wx[k] * t.w;
+                            }
+                            v.x += wy[i] * row.x; v.y += wy[i] * row.y; v.z += wy[i] * row.z; v.w += wy[i] * row.w;
+                        }
+                        const int oy = 2 * qy + ey, ox = 2 * qx + ex;
+                        if (skip) { const float4 k4 = *reinterpret_cast<const float4 *>(skip + ((size_t)b * HW + (size_t)oy * w + ox) * C + 4 * c4); v.x += k4.x; v.y += k4.y; v.z += k4.z; v.w += k4.w; }
+                        emit(oy, ox, v);
+                    }
+                }
+            }
+        }
+    if (!part) return;
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { red[threadIdx.x * 8 + k] = s[k]; red[threadIdx.x * 8 + 4 + k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        for (int sl = 0; sl < nslot; sl++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ds[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + k]; dq[k] += (double)red[(sl * C4 + threadIdx.x) * 8 + 4 + k]; }
+        double *o = part + (((size_t)blockIdx.x * gridDim.y + b) * C + 4 * threadIdx.x) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o[2 * k] = ds[k]; o[2 * k + 1] = dq[k]; }
+    }
+}
+// blocks of output pixels per frame of the sweeping producers: enough workgroups to fill the chip at B = 16 .. 48, few enough partials to finalize
+static int sweep_blocks(int HW) { return min(max(HW / 64, 1), 256); }
+extern "C" int vt_sweep_blocks(int HW) { return HW > 0 ? sweep_blocks(HW) : 0; }
+template <int OP>
+static int sweep_launch(const float *a, const float *skip, int B, int h, int w, int C, int groups, float *out, double *stats_ws, hipStream_t st)
+{
+    const int HW = h * w, nblk = sweep_blocks(HW), items = OP == 0 ? HW : HW / 4, rows = (items + nblk - 1) / nblk;
+    double *part = stats_ws ? stats_ws + (size_t)B * groups : nullptr;
+    hipLaunchKernelGGL(sweep_stats_kernel<OP>, dim3(nblk, B), dim3(256), 0, st, a, skip, h, w, C, rows, out, part);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_avgpool2x2_stats(const float *x, int B, int H, int W, int C, float *out, double *stats_ws, int stats_groups, void *stream)
+{
+    VT_REQUIRE(x && out && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0 && C <= 1024 && (!stats_ws || stats_groups > 0),
+               "vt_avgpool2x2_stats: bad argument (even H, W; C a multiple of 4, <= 1024)");
+    return sweep_launch<0>(x, nullptr, B, H / 2, W / 2, C, stats_groups, out, stats_ws, vt_stream(stream));
+}
+extern "C" int vt_upsample2x_bicubic_add_stats(const float *low, const float *skip, int B, int h, int w, int C, float *out, double *stats_ws, int stats_groups,
+                                               void *stream)
+{
+    VT_REQUIRE(low && out && B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0 && C <= 1024 && (!stats_ws || stats_groups > 0),
+               "vt_upsample2x_bicubic_add_stats: bad argument (C a multiple of 4, <= 1024)");
+    return sweep_launch<1>(low, skip, B, 2 * h, 2 * w, C, stats_groups, out, stats_ws, vt_stream(stream));
+}
 static int gn_blocks(int HW) { return min(max(HW / 256, 1), 128); }
 // workspace of vt_groupnorm_nhwc / vt_groupnorm_stats in doubles: (B, groups) x {mean, rstd} as float pairs FIRST, then the block partials
 extern "C" long vt_groupnorm_workspace_doubles(int B, int HW, int C, int groups)

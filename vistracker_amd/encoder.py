@@ -27,12 +27,49 @@ from . import _lib as L
 from . import ops
 
 
+def _attach_stats(t, ws, nblk):
+    """the GroupNorm(32) partial sums of ``t`` that its producer left behind (ws: {mean, rstd} area + nblk blocks of partials); finalized on first use"""
+    t._vt_stats = [ws, nblk, False]
+    return t
+
+
+def _stats_of(x):
+    """workspace with the finalized (B, 32) x {mean, rstd} of ``x`` if its producer left the partial sums behind, else None (the consumer runs a pass)"""
+    st = getattr(x, "_vt_stats", None)
+    if st is None:
+        return None
+    if not st[2]:
+        B, C, H, W = x.shape
+        L.check(L.lib().vt_groupnorm_finalize(st[0].data_ptr(), st[1], B, H * W, C, 32, 1e-5, L.stream_ptr()))
+        st[2] = True
+    return st[0]
+
+
+def avgpool2x2(x):
+    """F.avg_pool2d(x, 2, stride=2) of a channels-last GPU tensor on vt_avgpool2x2_stats: the pooled tensor + the GroupNorm partial sums of it for the
+    ConvBlock that reads it next (one pass instead of torch's pooling kernel + a statistics pass)"""
+    B, C, H, W = x.shape
+    if not (x.is_cuda and C % 32 == 0 and C <= 1024 and H % 2 == 0 and W % 2 == 0):
+        return F.avg_pool2d(x, 2, stride=2)
+    x = x.contiguous(memory_format=torch.channels_last)
+    out = torch.empty(B, C, H // 2, W // 2, device=x.device, memory_format=torch.channels_last)
+    nblk = L.lib().vt_sweep_blocks((H // 2) * (W // 2))
+    ws = torch.empty(B * 32 + nblk * B * C * 2, dtype=torch.float64, device=x.device)
+    L.check(L.lib().vt_avgpool2x2_stats(x.data_ptr(), B, H, W, C, out.data_ptr(), ws.data_ptr(), 32, L.stream_ptr()))
+    return _attach_stats(out, ws, nblk)
+
+
 def upsample2x_bicubic_add(low, skip):
     """skip + bicubic x2 (align_corners=True) of ``low``; both NCHW-shaped channels-last tensors on the GPU -> same format
     (``vt_upsample2x_bicubic_add``; torch's channels-last bicubic kernel took 78 % of the encoder time)."""
     B, C, h, w = low.shape
     low = low.contiguous(memory_format=torch.channels_last); skip = skip.contiguous(memory_format=torch.channels_last)
     out = torch.empty_like(skip, memory_format=torch.channels_last)
+    if C % 32 == 0 and C <= 1024:       # + the GroupNorm partial sums of the sum for the ConvBlock that reads it next (top_m / b3)
+        nblk = L.lib().vt_sweep_blocks(4 * h * w)
+        ws = torch.empty(B * 32 + nblk * B * C * 2, dtype=torch.float64, device=low.device)
+        L.check(L.lib().vt_upsample2x_bicubic_add_stats(low.data_ptr(), skip.data_ptr(), B, h, w, C, out.data_ptr(), ws.data_ptr(), 32, L.stream_ptr()))
+        return _attach_stats(out, ws, nblk)
     L.check(L.lib().vt_upsample2x_bicubic_add(low.data_ptr(), skip.data_ptr(), B, h, w, C, out.data_ptr(), L.stream_ptr()))
     return out
 
@@ -55,6 +92,9 @@ class HGFilterEncoder:
     # 3x3 convolutions with 32 / 64 / 128 output channels and Cin % 32 == 0 and the 1x1 convolutions (conv_last / l / bl / al of a stack, the
     # ConvBlocks' projections) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_* / vt_conv1x1_*); the 7x7 stem stays on MIOpen
     use_hip_conv = True
+    # GroupNorm statistics of a block's input from the partial sums its PRODUCER left behind (previous block's epilogue, pooling, up-sampling, the 1 x 1
+    # sum at the end of a stack) instead of a statistics pass over the tensor; False = round 2's passes (A/B, tests)
+    producer_stats = True
 
     def __init__(self, sd: dict, prefix: str, num_stack=3, num_hourglass=2, norm="group", hg_down="ave_pool", device="cuda:0"):
         """``sd``: state dict (tensors or arrays); ``prefix`` e.g. 'image_filter.' or 'triplane_encoder.' (a leading 'module.' is stripped)"""
@@ -128,8 +168,9 @@ class HGFilterEncoder:
                                        gn[0].data_ptr() if gn else None, sd[gn[1] + ".weight"].data_ptr() if gn else None, sd[gn[1] + ".bias"].data_ptr() if gn else None, 32,
                                        B, H, W, out.data_ptr(), cout, 0, res.data_ptr() if res is not None else None, cout, 0,
                                        ws_out.data_ptr() if want_stats else None, 32, L.stream_ptr()))
-        if want_stats:
+        if want_stats:      # of what was written: conv + bias, or conv + bias + res
             L.check(lib.vt_groupnorm_finalize(ws_out.data_ptr(), tiles, B, H * W, cout, 32, 1e-5, L.stream_ptr()))
+            out._vt_stats = [ws_out, tiles, True]
             return out, ws_out
         return out
 
@@ -198,8 +239,10 @@ class HGFilterEncoder:
         x = x.contiguous(memory_format=torch.channels_last)
         Ct, Cr = sum(couts), couts[0] + couts[1]
         tiles = lib.vt_conv3x3_tiles(H, W)
-        ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, Cin, 32), dtype=torch.float64, device=x.device)
-        L.check(lib.vt_groupnorm_stats(x.data_ptr(), Cin, 0, B, H * W, Cin, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
+        ws = _stats_of(x) if self.producer_stats else None      # left behind by the producer of x (previous block, pooling, up-sampling, 1 x 1 sum)
+        if ws is None:
+            ws = torch.empty(lib.vt_groupnorm_workspace_doubles(B, H * W, Cin, 32), dtype=torch.float64, device=x.device)
+            L.check(lib.vt_groupnorm_stats(x.data_ptr(), Cin, 0, B, H * W, Cin, 32, 1e-5, ws.data_ptr(), L.stream_ptr()))
         res = x
         if p + "downsample.2.weight" in sd:         # see _conv_block: Sequential(bn4, ReLU, conv1x1)
             if self._hip_conv1x1_ok(p + "downsample.2.weight", H, W, True):
@@ -211,22 +254,24 @@ class HGFilterEncoder:
         raw = torch.empty(B, Cr, H, W, device=x.device, memory_format=torch.channels_last)
         fin = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)
         src, cstride, coff, C, off = x, Cin, 0, Cin, 0
+        ws_fin = torch.empty(B * 32 + tiles * B * Ct * 2, dtype=torch.float64, device=x.device) if (self.producer_stats and Ct % 32 == 0) else None
         for i, co in zip((1, 2, 3), couts):
             wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
             ws_out = torch.empty(B * 32 + tiles * B * co * 2, dtype=torch.float64, device=x.device) if i < 3 else None
-            L.check(lib.vt_conv3x3_forward_block(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(), sd[gn + ".weight"].data_ptr(),
-                                                 sd[gn + ".bias"].data_ptr(), 32, B, H, W, raw.data_ptr() if i < 3 else None, Cr, off if i < 3 else 0,
-                                                 res.data_ptr(), Ct, off, fin.data_ptr(), Ct, off, ws_out.data_ptr() if i < 3 else None, 32, L.stream_ptr()))
+            L.check(lib.vt_conv3x3_forward_block_stats(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(), sd[gn + ".weight"].data_ptr(),
+                                                       sd[gn + ".bias"].data_ptr(), 32, B, H, W, raw.data_ptr() if i < 3 else None, Cr, off if i < 3 else 0,
+                                                       res.data_ptr(), Ct, off, fin.data_ptr(), Ct, off, ws_out.data_ptr() if i < 3 else None, 32,
+                                                       ws_fin.data_ptr() if ws_fin is not None else None, 32, L.stream_ptr()))
             if i < 3:
                 L.check(lib.vt_groupnorm_finalize(ws_out.data_ptr(), tiles, B, H * W, co, 32, 1e-5, L.stream_ptr()))
                 ws = ws_out
             src, cstride, coff, C = raw, Cr, off, co
             off += co
-        return fin
+        return _attach_stats(fin, ws_fin, tiles) if ws_fin is not None else fin
 
     def _hourglass(self, level, x, p):
         up1 = self._conv_block(x, f"{p}b1_{level}.")
-        low = self._conv_block(F.avg_pool2d(x, 2, stride=2), f"{p}b2_{level}.")
+        low = self._conv_block(avgpool2x2(x) if self.producer_stats else F.avg_pool2d(x, 2, stride=2), f"{p}b2_{level}.")
         low = self._hourglass(level - 1, low, p) if level > 1 else self._conv_block(low, f"{p}b2_plus_{level}.")
         low = self._conv_block(low, f"{p}b3_{level}.")
         if low.is_cuda and low.shape[1] % 4 == 0:
@@ -240,7 +285,8 @@ class HGFilterEncoder:
         x = x.to(self.device).float().contiguous(memory_format=torch.channels_last)
         x = _gn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1", relu=True)
         tmpx = x
-        x = F.avg_pool2d(self._conv_block(x, "conv2."), 2, stride=2)
+        x = self._conv_block(x, "conv2.")
+        x = avgpool2x2(x) if self.producer_stats else F.avg_pool2d(x, 2, stride=2)
         normx = x
         previous = self._conv_block(self._conv_block(x, "conv3."), "conv4.")
         outputs = []
@@ -256,7 +302,7 @@ class HGFilterEncoder:
                 outputs.append(out)
                 if i < self.num_stack - 1:
                     tmp = self._conv1x1(raw, f"bl{i}.weight", f"bl{i}.bias", gn=(ws, f"bn_end{i}"), res=previous)
-                    previous = self._conv1x1(out, f"al{i}.weight", f"al{i}.bias", res=tmp)
+                    previous, _ = self._conv1x1(out, f"al{i}.weight", f"al{i}.bias", res=tmp, want_stats=True)      # the next stack's b1 normalises it
                 continue
             ll = _gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}", relu=True)
             out = F.conv2d(ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
