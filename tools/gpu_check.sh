@@ -24,4 +24,4 @@ done
 python tools/pmc_summary.py "query_kernel<2, 2" gpurun_out/${tag}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_pmc_WRITE_SIZE.csv > gpurun_out/${tag}_pmc_query_human.json
 python tools/pmc_summary.py "query_kernel<1, 3" gpurun_out/${tag}_pmc_FETCH_SIZE.csv gpurun_out/${tag}_pmc_WRITE_SIZE.csv > gpurun_out/${tag}_pmc_query_object.json
 cat gpurun_out/${tag}_pmc_query_human.json
-rm -f gpurun_out/${tag}_pmc_*.csv
+# (the raw counter files stay in gpurun_out/ for the session)
