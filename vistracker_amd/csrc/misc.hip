@@ -1247,22 +1247,26 @@ extern "C" int vt_kpts_step(const vt_landmarks *h, const float *verts, const flo
 #include <mutex>
 #include <vector>
 static std::mutex g_skip_mu;
-static std::vector<std::pair<hipStream_t, const int *>> g_skip_tab;
+struct SkipEntry { int dev; hipStream_t st; const int *flag; };
+static std::vector<SkipEntry> g_skip_tab;       // keyed by (device, stream): the default stream is the same handle on every device
+static int skip_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 const int *vt_skip_flag_of(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_skip_mu);
-    for (const auto &e : g_skip_tab) if (e.first == st) return e.second;
+    if (g_skip_tab.empty()) return nullptr;
+    const int dev = skip_device();
+    for (const auto &e : g_skip_tab) if (e.st == st && e.dev == dev) return e.flag;
     return nullptr;
 }
 extern "C" int vt_stream_set_skip_flag(void *stream, const int *flag)
 {
     std::lock_guard<std::mutex> lk(g_skip_mu);
-    const hipStream_t st = vt_stream(stream);
+    const hipStream_t st = vt_stream(stream); const int dev = skip_device();
     for (size_t i = 0; i < g_skip_tab.size(); i++)
-        if (g_skip_tab[i].first == st) {
-            if (flag) g_skip_tab[i].second = flag; else { g_skip_tab[i] = g_skip_tab.back(); g_skip_tab.pop_back(); }
+        if (g_skip_tab[i].st == st && g_skip_tab[i].dev == dev) {
+            if (flag) g_skip_tab[i].flag = flag; else { g_skip_tab[i] = g_skip_tab.back(); g_skip_tab.pop_back(); }
             return VT_OK;
         }
-    if (flag) g_skip_tab.emplace_back(st, flag);
+    if (flag) g_skip_tab.push_back({dev, st, flag});
     return VT_OK;
 }
