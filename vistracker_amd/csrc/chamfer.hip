@@ -11,7 +11,7 @@
 // by the thread of point i; the far side's gb[j] collects the contributions of all points i whose nearest neighbour is j -- after each
 // block of 256 points the (nn index, gradient) records go through LDS and thread j adds the records that name j in record order (fixed
 // summation order, thread j is the only writer of gb[j]).  Costs one compare per (i, j) pair on top of the distance pass.
-__device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na, const float *__restrict__ bpts, int nb, float *sB, int *sNN, float *sG,
+__device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na, const float *__restrict__ bpts, int nb, float4 *sB4, int *sNN, float *sG,
                                             float gs, float *ga, float *gb, double &acc)
 {
     // for every point of a: nearest point of b
@@ -23,12 +23,22 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
         for (int c0 = 0; c0 < nb; c0 += CH_CHUNK) {
             const int cn = min(CH_CHUNK, nb - c0);
             __syncthreads();
-            for (int t = threadIdx.x; t < cn * 3; t += 256) sB[t] = bpts[3 * c0 + t];
+            // one float4 per far point (one ds_read_b128 per candidate instead of three scalar reads), the chunk padded to a multiple of four with
+            // points at infinity (their distance is +inf and never wins): the scan runs four candidates per iteration, in ascending order with a strict
+            // compare -- the same winner and the same bits as the scalar loop
+            for (int t = threadIdx.x; t < ((cn + 3) & ~3); t += 256)
+                sB4[t] = t < cn ? make_float4(bpts[3 * (c0 + t)], bpts[3 * (c0 + t) + 1], bpts[3 * (c0 + t) + 2], 0.f) : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
             __syncthreads();
-            if (i < na) for (int j = 0; j < cn; j++) {
-                const float d0 = ax - sB[3 * j], d1 = ay - sB[3 * j + 1], d2 = az - sB[3 * j + 2];
-                const float dd = d0 * d0 + d1 * d1 + d2 * d2;
-                if (dd < best) { best = dd; bj = c0 + j; }
+            if (i < na) for (int j = 0; j < cn; j += 4) {
+                float dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float4 b = sB4[j + u];
+                    const float d0 = ax - b.x, d1 = ay - b.y, d2 = az - b.z;
+                    dd[u] = d0 * d0 + d1 * d1 + d2 * d2;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (dd[u] < best) { best = dd[u]; bj = c0 + j + u; }
             }
         }
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ 
                                                       const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy, const int *skip)
 {
     VT_SKIP_RETURN(skip);
-    __shared__ float sB[CH_CHUNK * 3];
+    __shared__ float4 sB4[CH_CHUNK];
     __shared__ int sNN[256];
     __shared__ float sG[256 * 3];
     __shared__ double red[4];
@@ -66,9 +76,9 @@ __global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ 
     double acc = 0;
     if (nx > 0 && ny > 0) {
         float *gx = dx ? dx + 3 * (size_t)ox : nullptr, *gy = dy ? dy + 3 * (size_t)oy : nullptr;
-        chamfer_dir(x + 3 * (size_t)ox, nx, y + 3 * (size_t)oy, ny, sB, sNN, sG, gs, gx, gy, acc);
+        chamfer_dir(x + 3 * (size_t)ox, nx, y + 3 * (size_t)oy, ny, sB4, sNN, sG, gs, gx, gy, acc);
         __syncthreads();        // the second direction adds to the same gradient rows from other threads
-        chamfer_dir(y + 3 * (size_t)oy, ny, x + 3 * (size_t)ox, nx, sB, sNN, sG, gs, gy, gx, acc);
+        chamfer_dir(y + 3 * (size_t)oy, ny, x + 3 * (size_t)ox, nx, sB4, sNN, sG, gs, gy, gx, acc);
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     __syncthreads();

@@ -692,13 +692,20 @@ class FitContext:
             return {"P": 0}
         sel_h = mask_h & pair.gather(1, lab_h); sel_o = mask_o & pair.gather(1, lab_o)
         bh, vh = sel_h.nonzero(as_tuple=True); bo, no = sel_o.nonzero(as_tuple=True)
-        kh = bh * 14 + lab_h[bh, vh]; ko = bo * 14 + lab_o[bo, no]
-        oh_s = torch.sort(kh, stable=True); oo_s = torch.sort(ko, stable=True)
-        idx_h = (bh * V + vh)[oh_s.indices]; idx_o = (bo * N + no)[oo_s.indices]
         cnt_h = (oh * pair).reshape(-1); cnt_o = (oo * pair).reshape(-1)
         keep = pair.reshape(-1)
+        # the Chamfer kernel runs one workgroup per pair, brute force: the pairs are listed LARGEST FIRST (n_h x n_o evaluations each, 1 .. 5e5), so that the
+        # dispatcher starts the long ones first and the small ones fill the tail (the term is a sum over pairs, the gradients are per point: the order of
+        # the list is free); rank = position of a (frame, part) key in that list
+        ch, co = cnt_h[keep], cnt_o[keep]
+        perm = torch.argsort(ch * co, descending=True, stable=True)
+        rank_of_key = torch.zeros(B * 14, dtype=torch.long, device=dev)
+        rank_of_key[keep.nonzero(as_tuple=True)[0][perm]] = torch.arange(P, device=dev)
+        kh = rank_of_key[bh * 14 + lab_h[bh, vh]]; ko = rank_of_key[bo * 14 + lab_o[bo, no]]
+        oh_s = torch.sort(kh, stable=True); oo_s = torch.sort(ko, stable=True)
+        idx_h = (bh * V + vh)[oh_s.indices]; idx_o = (bo * N + no)[oo_s.indices]
         offx = torch.zeros(P + 1, dtype=torch.int32, device=dev); offy = torch.zeros(P + 1, dtype=torch.int32, device=dev)
-        offx[1:] = torch.cumsum(cnt_h[keep], 0).int(); offy[1:] = torch.cumsum(cnt_o[keep], 0).int()
+        offx[1:] = torch.cumsum(ch[perm], 0).int(); offy[1:] = torch.cumsum(co[perm], 0).int()
         return {"P": P, "x": smpl_verts.reshape(-1, 3).index_select(0, idx_h).contiguous(), "offx": offx, "offy": offy, "idx_o": idx_o}
 
 
