@@ -42,7 +42,7 @@ FLOP_PER_POINT_HUMAN_MFMA = FLOP_PER_POINT_HUMAN - 4 * 2 * 256 * 128
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
 
 
 def pmc_traffic_bytes():
