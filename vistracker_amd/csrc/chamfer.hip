@@ -6,6 +6,11 @@
 #include "common.h"
 
 #define CH_CHUNK 1024
+// threads per workgroup = points of the near cloud per sweep over the far cloud: a pair is ONE workgroup, so its sweeps are the launch's critical path
+// (the largest contact sets have ~1200 points: three sweeps of 512 instead of five of 256; 1024 threads measure the same)
+#ifndef CH_BLK
+#define CH_BLK 512
+#endif
 
 // Gradients are accumulated WITHOUT atomics so that the 'joint' phase is run-to-run reproducible: the near side's gradient ga[i] is owned
 // by the thread of point i; the far side's gb[j] collects the contributions of all points i whose nearest neighbour is j -- after each
@@ -15,7 +20,7 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
                                             float gs, float *ga, float *gb, double &acc)
 {
     // for every point of a: nearest point of b
-    for (int i0 = 0; i0 < na; i0 += 256) {
+    for (int i0 = 0; i0 < na; i0 += CH_BLK) {
         const int i = i0 + threadIdx.x;
         float ax = 0.f, ay = 0.f, az = 0.f;
         if (i < na) { ax = a[3 * i]; ay = a[3 * i + 1]; az = a[3 * i + 2]; }
@@ -26,7 +31,7 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
             // one float4 per far point (one ds_read_b128 per candidate instead of three scalar reads), the chunk padded to a multiple of four with
             // points at infinity (their distance is +inf and never wins): the scan runs four candidates per iteration, in ascending order with a strict
             // compare -- the same winner and the same bits as the scalar loop
-            for (int t = threadIdx.x; t < ((cn + 3) & ~3); t += 256)
+            for (int t = threadIdx.x; t < ((cn + 3) & ~3); t += CH_BLK)
                 sB4[t] = t < cn ? make_float4(bpts[3 * (c0 + t)], bpts[3 * (c0 + t) + 1], bpts[3 * (c0 + t) + 2], 0.f) : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
             __syncthreads();
             if (i < na) for (int j = 0; j < cn; j += 4) {
@@ -52,8 +57,8 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
             __syncthreads();
             sNN[threadIdx.x] = live ? bj : -1; sG[3 * threadIdx.x] = g0; sG[3 * threadIdx.x + 1] = g1; sG[3 * threadIdx.x + 2] = g2;
             __syncthreads();
-            const int nrec = min(256, na - i0);
-            for (int j = threadIdx.x; j < nb; j += 256) {
+            const int nrec = min(CH_BLK, na - i0);
+            for (int j = threadIdx.x; j < nb; j += CH_BLK) {
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f; bool any = false;
                 for (int t = 0; t < nrec; t++)
                     if (sNN[t] == j) { s0 += sG[3 * t]; s1 += sG[3 * t + 1]; s2 += sG[3 * t + 2]; any = true; }
@@ -63,14 +68,14 @@ __device__ __forceinline__ void chamfer_dir(const float *__restrict__ a, int na,
     }
 }
 
-__global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ x, const int *__restrict__ offx, const float *__restrict__ y,
+__global__ __launch_bounds__(CH_BLK) void chamfer_kernel(const float *__restrict__ x, const int *__restrict__ offx, const float *__restrict__ y,
                                                       const int *__restrict__ offy, int P, float gs, double *term, float *dx, float *dy, const int *skip)
 {
     VT_SKIP_RETURN(skip);
     __shared__ float4 sB4[CH_CHUNK];
-    __shared__ int sNN[256];
-    __shared__ float sG[256 * 3];
-    __shared__ double red[4];
+    __shared__ int sNN[CH_BLK];
+    __shared__ float sG[CH_BLK * 3];
+    __shared__ double red[CH_BLK / 64];
     const int p = blockIdx.x;
     const int ox = offx[p], nx = offx[p + 1] - ox, oy = offy[p], ny = offy[p + 1] - oy;
     double acc = 0;
@@ -84,14 +89,18 @@ __global__ __launch_bounds__(256) void chamfer_kernel(const float *__restrict__ 
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && term) atomicAdd(term, (red[0] + red[1] + red[2] + red[3]) / (double)P);
+    if (threadIdx.x == 0 && term) {
+        double tot = 0;
+        for (int w = 0; w < CH_BLK / 64; w++) tot += red[w];
+        atomicAdd(term, tot / (double)P);
+    }
 }
 
 extern "C" int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int *offy, int P, float gscale, double *term,
                                  float *dx, float *dy, void *stream)
 {
     VT_REQUIRE(x && offx && y && offy && P > 0, "vt_chamfer_ragged: bad argument");
-    hipLaunchKernelGGL(chamfer_kernel, dim3(P), dim3(256), 0, vt_stream(stream), x, offx, y, offy, P, gscale / (float)P, term, dx, dy, vt_skip_flag_of(vt_stream(stream)));
+    hipLaunchKernelGGL(chamfer_kernel, dim3(P), dim3(CH_BLK), 0, vt_stream(stream), x, offx, y, offy, P, gscale / (float)P, term, dx, dy, vt_skip_flag_of(vt_stream(stream)));
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
