@@ -306,7 +306,7 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
     if args.streams <= 1:
         results = [fit_batch(ctx, torch, d, prof) for d in batches]
     else:
@@ -370,6 +370,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    host_wait = float(ctx.host_wait_s) - host_wait0
     if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
@@ -437,6 +438,9 @@ def main():
                        "early_stop": "reference rule, evaluated on device",
                        # the stop rules make the step count data dependent: the steps-normalised rate lets runs with different counts be compared
                        "frame_steps_per_s": frame_steps / elapsed,
+                       # slack of the launching threads: seconds (summed over the host threads of rank 0) blocked on the device-side stop flag / wall-clock x threads;
+                       # near 1 = the GPU is the bottleneck, near 0 = the host cannot queue launches as fast as the GPU retires them
+                       "host_wait_frac": host_wait / (elapsed * max(1, args.streams + (1 if args.schedule == "staged" else 0))),
                        "sharding": (f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)" if strong
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,

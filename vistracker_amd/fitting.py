@@ -16,6 +16,7 @@ import contextlib
 import ctypes as C
 import os
 import threading
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -218,6 +219,7 @@ class FitContext:
     range_retries = 0       # fits of this context repeated at a wider operand-range level of the split-f16 decoders
     fp32_fallbacks = 0      # fits of this context that had to be repeated on the strict-fp32 kernels
     _counter_lock = threading.Lock()
+    host_wait_s = 0.0       # seconds the launching threads spent blocked on the stop flag (see _read_stop)
 
     def _with_range_fallback(self, maps, params, run):
         """Run a fit; if the split-f16 decoders produced a non-finite loss (an activation beyond the range of the split operands at the maps'
@@ -332,7 +334,7 @@ class FitContext:
                                                         stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
                     res.stopped_early = True
                     break
         res.losses = hist.cpu().numpy()
@@ -444,7 +446,7 @@ class FitContext:
                                                             stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
                     res.stopped_early = True
                     break
         res.losses = hist.cpu().numpy()
@@ -587,7 +589,7 @@ class FitContext:
                                                         state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and int(stop.item()):
+                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
                     res.stopped_early = True
                     break
         res.losses = hist.cpu().numpy()
@@ -596,6 +598,16 @@ class FitContext:
         _flush_events(prof, lp, res.steps if (res.stopped_early and self.device_skip) else None)
         _check_finite(res, "fit")
         return res
+
+    def _read_stop(self, stop):
+        """the host's look at the device-side stop flag, once per outer iteration: a stream synchronisation.  ``host_wait_s`` accumulates the time the host
+        spends blocked here -- the slack of the launching thread: close to the wall-clock of a fit when the GPU is the bottleneck, close to zero when the
+        host cannot queue launches as fast as the GPU retires them"""
+        t0 = time.perf_counter()
+        v = int(stop.item())
+        with self._counter_lock:
+            self.host_wait_s += time.perf_counter() - t0
+        return v
 
     @contextlib.contextmanager
     def _skip_after_stop(self, stop):
