@@ -371,6 +371,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_wait = float(ctx.host_wait_s) - host_wait0
+    batch_frames = [int(d_["pose"].shape[0]) for d_ in batches]        # (the informational legs below release the batches)
     if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
@@ -388,10 +389,27 @@ def main():
         def full_schedule():
             d = make_batch(ctx, syn, torch, seed=900, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize(); t1 = time.perf_counter()
             r1, r2 = fit_batch(ctx, torch, d, early_stop=False); torch.cuda.synchronize(); dt = time.perf_counter() - t1
-            return {"workload": "one 96-frame batch, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
-                                "steps, of which 1100 in phase 'joint' with the contact Chamfer term), one batch in flight",
-                    "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds": dt, "frames_per_s": BATCH / dt,
-                    "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
+            out = {"workload": "one 96-frame batch, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
+                               "steps, of which 1100 in phase 'joint' with the contact Chamfer term), one batch in flight",
+                   "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds": dt, "frames_per_s": BATCH / dt,
+                   "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
+            # the same with two batches in flight, like the headline
+            import threading
+            del d
+            ds = [make_batch(ctx, syn, torch, seed=901 + k_, dev=dev, res_scale=args.res_scale) for k_ in range(2)]; torch.cuda.synchronize()
+            ss = [torch.cuda.Stream(device=dev) for _ in ds]
+
+            def w2(k):
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(ss[k]):
+                    fit_batch(ctx, torch, ds[k], early_stop=False)
+            t1 = time.perf_counter()
+            th2 = [threading.Thread(target=w2, args=(k,)) for k in range(2)]
+            for t_ in th2: t_.start()
+            for t_ in th2: t_.join()
+            torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+            out["two_in_flight"] = {"seconds_per_batch": dt2 / 2, "frames_per_s": 2 * BATCH / dt2, "frame_steps_per_s": 2 * BATCH * (r1.steps + r2.steps) / dt2}
+            return out
         leg("full_schedule", full_schedule)
         del full96; batches.clear()
         torch.cuda.empty_cache()
@@ -402,8 +420,8 @@ def main():
         frames = total_frames
         smpl_steps = float(np.mean([r[0].steps for r in results])); obj_steps = float(np.mean([r[1].steps for r in results]))
         # frames x executed Adam steps of THIS rank's batches (the tail batch has fewer frames), scaled to the job
-        my_frames = sum(d_["pose"].shape[0] for d_ in batches)
-        frame_steps = sum(d_["pose"].shape[0] * (r[0].steps + r[1].steps) for d_, r in zip(batches, results)) * (frames / max(my_frames, 1))
+        my_frames = sum(batch_frames)
+        frame_steps = sum(n_ * (r[0].steps + r[1].steps) for n_, r in zip(batch_frames, results)) * (frames / max(my_frames, 1))
         th = np.array([a.elapsed_time(b) for a, b, _ in prof["human"]]) * 1e-3 if prof["human"] else np.zeros(1)
         to = np.array([a.elapsed_time(b) for a, b, _ in prof["object"]]) * 1e-3 if prof["object"] else np.zeros(1)
         fo = np.array([n for _, _, n in prof["object"]], np.float64) if prof["object"] else np.ones(1)
