@@ -361,6 +361,12 @@ int vt_collision_loss(const float *smpl_verts, int n_smpl_verts, const int *smpl
  * ------------------------------------------------------------------------------------------------- */
 int vt_chamfer_ragged(const float *x, const int *offx, const float *y, const int *offy, int P, float gscale,
                       double *term, float *dx, float *dy, void *stream);
+/* The same term and gradients with every pair split over several workgroups (one workgroup per pair makes the largest contact sets the launch's critical
+ * path): total_x / total_y = offx[P] / offy[P] (rows of x / y), ws = vt_chamfer_ws_bytes(total_x, total_y, P) bytes of device scratch.  Gradients are still
+ * accumulated without float atomics (run-to-run reproducible); the far-side sums associate differently from vt_chamfer_ragged (last-bit differences). */
+long vt_chamfer_ws_bytes(long total_x, long total_y, int P);
+int vt_chamfer_ragged_ws(const float *x, const int *offx, long total_x, const float *y, const int *offy, long total_y, int P, float gscale,
+                         double *term, float *dx, float *dy, void *ws, void *stream);
 
 /* Evaluation Chamfer, one direction (recon/eval/chamfer_distance.py:10-52, sklearn NearestNeighbors(k=1, metric='l2')): for each of
  * the nq points of cloud pair p the Euclidean distance to the nearest of the ns points of `search`; query (P,nq,3), search (P,ns,3),

@@ -307,6 +307,47 @@ def test_chamfer_ragged(hip):
     assert rel(npy(x.grad), dx) < 1e-4 and rel(npy(y.grad), dy) < 1e-4
 
 
+def test_chamfer_ragged_split_over_workgroups(hip):
+    """vt_chamfer_ragged_ws (a pair split over several workgroups, records through a workspace) against the oracle and against the one-workgroup-per-pair
+    kernel: empty pairs, one-point clouds, clouds longer than an LDS chunk (1024) on either side, gradients to one side only; bit-reproducible."""
+    import ctypes as C
+    from oracle import oracle as O
+    from vistracker_amd import _lib as L
+    lib = L.lib(); rng = np.random.default_rng(14)
+    sizes = [(1, 1), (5, 1700), (1300, 40), (64, 64), (0, 7), (2300, 1100), (3, 0), (257, 513)]
+    xs = [rng.normal(0, 1, (a, 3)).astype(np.float32) for a, _ in sizes]
+    ys = [rng.normal(0, 1, (b, 3)).astype(np.float32) for _, b in sizes]
+    live = [(a, b) for a, b in zip(xs, ys) if len(a) and len(b)]
+    val, dxo, dyo, _, _ = O.chamfer_ragged([a for a, _ in live], [b for _, b in live], 1.0, True)
+    val *= len(live) / len(sizes)                       # the oracle averages over the live pairs, the kernels over all P
+    offx = np.concatenate([[0], np.cumsum([len(a) for a in xs])]).astype(np.int32); offy = np.concatenate([[0], np.cumsum([len(b) for b in ys])]).astype(np.int32)
+    x = cu(np.concatenate(xs)); y = cu(np.concatenate(ys)); ox, oy = cu(offx), cu(offy); P = len(sizes)
+    ws = torch.empty(int(lib.vt_chamfer_ws_bytes(x.shape[0], y.shape[0], P)), dtype=torch.uint8, device="cuda")
+
+    def run(split, want_dx=True, want_dy=True):
+        term = torch.zeros(1, dtype=torch.float64, device="cuda"); dx = torch.zeros_like(x); dy = torch.zeros_like(y)
+        a = (dx.data_ptr() if want_dx else None, dy.data_ptr() if want_dy else None)
+        if split:
+            L.check(lib.vt_chamfer_ragged_ws(x.data_ptr(), ox.data_ptr(), x.shape[0], y.data_ptr(), oy.data_ptr(), y.shape[0], P, 1.0, term.data_ptr(), a[0], a[1],
+                                             ws.data_ptr(), L.stream_ptr()))
+        else:
+            L.check(lib.vt_chamfer_ragged(x.data_ptr(), ox.data_ptr(), y.data_ptr(), oy.data_ptr(), P, 1.0, term.data_ptr(), a[0], a[1], L.stream_ptr()))
+        return float(term.item()), npy(dx), npy(dy)
+
+    v1, dx1, dy1 = run(True); v0, dx0, dy0 = run(False)
+    assert abs(v1 - v0) < 1e-12 * abs(v0) and abs(v1 - val) < 1e-5 * abs(val), (v1, v0, val)
+    sx = P / len(live)                                  # gradient scale of the oracle's mean over live pairs
+    keep_x = np.concatenate([np.full(len(a), len(a) > 0 and len(b) > 0) for a, b in zip(xs, ys)]); keep_y = np.concatenate([np.full(len(b), len(a) > 0 and len(b) > 0) for a, b in zip(xs, ys)])
+    assert rel(dx1[keep_x] * sx, dxo) < 1e-4 and rel(dy1[keep_y] * sx, dyo) < 1e-4
+    assert np.abs(dx1 - dx0).max() < 1e-6 * np.abs(dx0).max() and np.abs(dy1 - dy0).max() < 1e-6 * np.abs(dy0).max()
+    assert not dx1[~keep_x].any() and not dy1[~keep_y].any()
+    v2, dx2, dy2 = run(True)
+    assert v2 == v1 or abs(v2 - v1) < 1e-15 * abs(v1)
+    assert np.array_equal(dx1, dx2) and np.array_equal(dy1, dy2)                        # no float atomics
+    _, dxa, dya = run(True, want_dx=False); assert not dxa.any() and np.array_equal(dya, dy1)
+    _, dxb, dyb = run(True, want_dy=False); assert not dyb.any() and np.array_equal(dxb, dx1)
+
+
 def _sil_case(B=3, seed=8):
     from vistracker_amd import synthetic as syn
     rng = np.random.default_rng(seed)

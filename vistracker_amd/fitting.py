@@ -570,8 +570,9 @@ class FitContext:
                         if contact["P"] > 0:
                             y = X.view(-1, 3).index_select(0, contact["idx_o"])
                             dy = torch.zeros_like(y)
-                            _chk(_lib().vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
-                                                          contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), L.stream_ptr()))
+                            _chk(_lib().vt_chamfer_ragged_ws(contact["x"].data_ptr(), contact["offx"].data_ptr(), contact["x"].shape[0], y.data_ptr(),
+                                                             contact["offy"].data_ptr(), y.shape[0], contact["P"], float(w[5]), terms.ptr("contact"), None,
+                                                             dy.data_ptr(), contact["ws"].data_ptr(), L.stream_ptr()))
                             dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
                     _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
                     if phase == "joint" and self.collision_loss:
@@ -671,8 +672,8 @@ class FitContext:
             if contact["P"] > 0:
                 y = X.view(-1, 3).index_select(0, contact["idx_o"])
                 dy = torch.zeros_like(y)
-                _chk(lib.vt_chamfer_ragged(contact["x"].data_ptr(), contact["offx"].data_ptr(), y.data_ptr(), contact["offy"].data_ptr(),
-                                           contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), st))
+                _chk(lib.vt_chamfer_ragged_ws(contact["x"].data_ptr(), contact["offx"].data_ptr(), contact["x"].shape[0], y.data_ptr(), contact["offy"].data_ptr(),
+                                              y.shape[0], contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), contact["ws"].data_ptr(), st))
                 dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
         adam.t += 1
         gR = gT = (None, None, None, 0.0)
@@ -718,7 +719,9 @@ class FitContext:
         idx_h = (bh * V + vh)[oh_s.indices]; idx_o = (bo * N + no)[oo_s.indices]
         offx = torch.zeros(P + 1, dtype=torch.int32, device=dev); offy = torch.zeros(P + 1, dtype=torch.int32, device=dev)
         offx[1:] = torch.cumsum(ch[perm], 0).int(); offy[1:] = torch.cumsum(co[perm], 0).int()
-        return {"P": P, "x": smpl_verts.reshape(-1, 3).index_select(0, idx_h).contiguous(), "offx": offx, "offy": offy, "idx_o": idx_o}
+        x = smpl_verts.reshape(-1, 3).index_select(0, idx_h).contiguous()
+        ws = torch.empty(int(_lib().vt_chamfer_ws_bytes(x.shape[0], idx_o.shape[0], P)), dtype=torch.uint8, device=dev)     # scratch of vt_chamfer_ragged_ws
+        return {"P": P, "x": x, "offx": offx, "offy": offy, "idx_o": idx_o, "ws": ws}
 
 
 class SilSetup:
