@@ -113,7 +113,10 @@ __global__ void sil_face_setup_kernel(const float *__restrict__ proj, const int 
 #ifndef SIL_G
 #define SIL_G 16
 #endif
-#define SIL_BIG (8 * SIL_G)     /* boxes above this many pixels are rasterised by the whole wave (64 lanes), not by the face's lane group */
+#ifndef SIL_GS
+#define SIL_GS SIL_G      /* lanes per face in the scatter kernel (the backward kernel's group is one DPP row: SIL_G) */
+#endif
+#define SIL_BIG 128     /* boxes above this many pixels are rasterised by the whole wave (64 lanes), not by the face's lane group */
 // pixel p of the box (x0, y0, width w) -> image coordinates; p = q w + r without the ~40-instruction integer division: float estimate (p < 2^20 is
 // exact in fp32), corrected by at most one
 __device__ __forceinline__ void sil_box_pixel(int p, int x0, int y0, int w, float rw, int &xi, int &yi)
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
                                                           unsigned long long *__restrict__ zbuf, const int *skip)
 {
     VT_SKIP_RETURN(skip);
-    constexpr int FPW = 64 / SIL_G;
+    constexpr int FPW = 64 / SIL_GS;
     __shared__ unsigned short sQ[4][FPW][SIL_BIG];              // per lane group: the box pixels that passed the inside test
-    const int lane = threadIdx.x & 63, gl = lane % SIL_G, grp = lane / SIL_G, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, gl = lane % SIL_GS, grp = lane / SIL_GS, b = blockIdx.y;
     const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * FPW + grp;
     unsigned long long *zrow = zbuf + (size_t)b * is * is;
     float fc[9]; float den = 0.f; int f2 = 0, x0 = 0, y0 = 0, w = 1, npx = 0;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
     unsigned short *qz = sQ[threadIdx.x >> 6][grp];
     int n_in = 0;
     const int nsmall = big ? 0 : npx;
-    for (int p0 = 0; p0 < nsmall; p0 += SIL_G) {
+    for (int p0 = 0; p0 < nsmall; p0 += SIL_GS) {
         const int p = p0 + gl;
         bool in = false;
         if (p < nsmall) {
@@ -208,12 +211,12 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
             float xp, yp; sil_ndc(xi, yi, is, pow2, ris, xp, yp);
             in = sil_inside(fc, xp, yp);
         }
-        const unsigned bits = (unsigned)(__ballot(in) >> (SIL_G * grp)) & ((1u << SIL_G) - 1u);
+        const unsigned bits = (unsigned)(__ballot(in) >> (SIL_GS * grp)) & (SIL_GS >= 32 ? 0xffffffffu : ((1u << (SIL_GS & 31)) - 1u));
         if (in) qz[n_in + __popc(bits & ((1u << gl) - 1u))] = (unsigned short)p;
         n_in += __popc(bits);
     }
     __syncthreads();
-    for (int i = gl; i < n_in; i += SIL_G) {
+    for (int i = gl; i < n_in; i += SIL_GS) {
         const int p = qz[i];
         int xi, yi; sil_box_pixel(p, x0, y0, w, rw, xi, yi);
         float xp, yp; sil_ndc(xi, yi, is, pow2, ris, xp, yp);
@@ -477,7 +480,7 @@ extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *face
     hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible, skip);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, skip);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_GS) - 1) / (4 * (64 / SIL_GS)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B), dim3(256), 0, st, w.zbuf, NF, size, image, face_index, w.visible, skip);
     VT_LAUNCH_CHECK();
@@ -497,7 +500,7 @@ extern "C" int vt_triplane_render(const float *verts, const float *center, int B
     hipLaunchKernelGGL(sil_face_setup_kernel, dim3((2 * NF + 255) / 256, B3), dim3(256), 0, st, w.proj, faces, NV, NF, size, w.fc, w.fbox, w.visible, nullptr);
     VT_LAUNCH_CHECK();
     VT_HIP(hipMemsetAsync(w.zbuf, 0xff, sizeof(unsigned long long) * (size_t)B3 * size * size, st));
-    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, nullptr);
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_GS) - 1) / (4 * (64 / SIL_GS)), B3), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, nullptr);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_resolve_kernel, dim3((size + 255) / 256, size, B3), dim3(256), 0, st, w.zbuf, NF, size, masks, face_index, w.visible, nullptr);
     VT_LAUNCH_CHECK();
