@@ -154,6 +154,70 @@ def test_object_stage_all_phases_vs_oracle(synth):
         assert v2v < (3e-3 if phase == "sil" else 1e-3), (phase, v2v)
 
 
+def _unpack(a, n):
+    return np.unpackbits(a, axis=2)[:, :, :n].astype(np.float32)
+
+
+def test_objfit_joint_phase_vs_reference(synth):
+    """Phase 'joint' against the REFERENCE's own forward_step / compute_contact_loss / temporal_loss_joint / Adam([obj_t], 0.002) (fixture
+    objfit_joint.npz, tools/gen_golden_joint.py: stand-ins only for pytorch3d's Pointclouds / chamfer_distance): first outer iteration of the phase
+    (it = 45, decay 31 / 3), contacts computed once by the HIP path from its own queries, 10 Adam steps with the recorded decopose_axis noise."""
+    from vistracker_amd import ops, synthetic as syn
+    g = golden("objfit_joint")
+    ctx = make_ctx(synth, g["obj_points"])
+    maps = ops.FeatureMaps.from_nchw(syn.feature_maps(5, int(g["maps_seed"]), res_scale=float(g["res_scale"]), smooth=int(g["smooth"])))
+    R, t, s = cu(g["obj_R0"].copy()), cu(g["obj_t0"].copy()), torch.ones(5, device="cuda")
+    # the contact set the HIP path derives (df < 0.08 on both sides, part labels / argmax of the part logits, pairs present on both sides) is the reference's
+    X0 = ops.rigid_transform(ctx.obj_points, ops.so3_project(R, cu(g["noise"][1])), t, s)
+    c = ctx._contacts_once(maps, cu(g["smpl_verts"]), X0, cu(g["crop_center"]), cu(g["body_center"]))
+    ref_sizes = sorted((int(p[2]), int(p[3])) for p in g["pairs"])
+    got = sorted(zip(np.diff(c["offx"].cpu().numpy()).tolist(), np.diff(c["offy"].cpu().numpy()).tolist()))
+    assert c["P"] == len(ref_sizes)
+    assert sum(abs(a[0] - b[0]) + abs(a[1] - b[1]) for a, b in zip(got, ref_sizes)) <= 2, (got, ref_sizes)      # a point within round-off of the 0.08 threshold
+    it = int(g["it"])
+    res = ctx.optimize_smpl_object(maps, cu(g["smpl_verts"]), R, t, s, cu(g["crop_center"]), cu(g["body_center"]), cu(g["occ"]), noise=cu(g["noise"][1:]),
+                                   it_range=(it, it + 1), early_stop=False)
+    assert res.steps == 10
+    assert rel(res.losses[:10], g["losses"]) < 1e-3, (res.losses[:10], g["losses"])
+    assert torch.equal(R, cu(g["obj_R0"]))                       # the phase optimises obj_t only (recon_fit_trivis_full.py:343-347)
+    assert np.abs(t.cpu().numpy() - g["fin_t"]).max() < 5e-4, np.abs(t.cpu().numpy() - g["fin_t"]).max()
+
+
+def test_objfit_sil_phase_vs_reference(synth):
+    """Phase 'sil' against the REFERENCE's own forward_step / compute_mask_loss / SilLossROI.forward + 'scale' / 'trans' terms / Adam([R, t], 0.006)
+    (fixture objfit_sil.npz; the renderer stand-in is the CPU oracle's rasteriser): it = 15, decay 1, 10 Adam steps.  The HIP rasteriser may
+    differ from the stand-in by <= 3 pixels per frame per call (test_silhouette_per_call_at_bench_size): losses 5e-3, geometry 3e-3 m."""
+    from oracle import oracle as O
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import SilSetup
+    g = golden("objfit_sil")
+    ov, of = syn.object_template()
+    ctx = make_ctx(synth, g["obj_points"], (ov, of))
+    maps = ops.FeatureMaps.from_nchw(syn.feature_maps(5, int(g["maps_seed"]), res_scale=float(g["res_scale"]), smooth=int(g["smooth"])))
+    R, t, s = cu(g["obj_R0"].copy()), cu(g["obj_t0"].copy()), torch.ones(5, device="cuda")
+    sil = SilSetup(cu(g["K"].reshape(5, 9)), cu(_unpack(g["keep_mask"], 256)), cu(_unpack(g["image_ref"], 256)))
+    it = int(g["it"])
+    res = ctx.optimize_smpl_object(maps, None, R, t, s, cu(g["crop_center"]), cu(g["body_center"]), cu(g["occ"]), sil=sil, noise=cu(g["noise"][1:]),
+                                   it_range=(it, it + 1), early_stop=False)
+    assert res.steps == 10
+    assert rel(res.losses[:3], g["losses"][:3]) < 5e-3, (res.losses[:10], g["losses"])
+    sc = np.ones(5, np.float32)
+    X = O.rigid(g["obj_points"], O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc); Xr = O.rigid(g["obj_points"], g["fin_R"], g["fin_t"], sc)
+    v2v = np.linalg.norm(X - Xr, axis=-1).mean()
+    assert v2v < 3e-3, v2v
+
+
+def test_silsetup_on_device_vs_reference():
+    """the per-batch set-up of SilLossROI on the device (bbox -> square x 1.3 -> ROI crops -> keep mask -> ROI intrinsics) against what the reference's
+    own SilLossROI.__init__ produced for the same masks (fixture silsetup.npz)"""
+    from vistracker_amd import synthetic as syn
+    from vistracker_amd.silhouette import SilLossROI
+    g = golden("silsetup"); ov, of = syn.object_template()
+    s = SilLossROI(cu(_unpack(g["person_mask"], 512)), cu(_unpack(g["obj_mask"], 512)), (ov, of), cu(g["crop_center"]), camera_params={}, crop_size=1200, net_input_size=512)
+    assert np.abs(s.K.cpu().numpy() - g["K"]).max() < 1e-6 * np.abs(g["K"]).max()
+    assert np.array_equal(s.keep_mask.cpu().numpy(), _unpack(g["keep_mask"], 256)) and np.array_equal(s.image_ref.cpu().numpy(), _unpack(g["image_ref"], 256))
+
+
 def test_early_stop_on_device(synth):
     """The device-side stop flag freezes the parameters at the step the reference rule fires (no overshoot)."""
     from vistracker_amd import ops, synthetic as syn
