@@ -16,7 +16,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-c_fp = C.POINTER(C.c_float)
+# ``oracle.oracle64`` executes this same file under its own name: every array, scalar argument and C routine is then float64
+# (libvt_oracle64.so = vt_oracle.c built with -DVTO_FP64) -- the reference arithmetic free of fp32 round-off, used by the tests as the
+# arbiter between the HIP path and the fp32 oracle on long Adam trajectories (the reference's own goldens use the same idea: objfit*.npz fin_R64)
+FP64 = __name__.endswith("64")
+REAL = np.float64 if FP64 else np.float32
+c_real = C.c_double if FP64 else C.c_float
+_LIBNAME = "libvt_oracle64.so" if FP64 else "libvt_oracle.so"
+
+c_fp = C.POINTER(c_real)
 c_ip = C.POINTER(C.c_int)
 
 
@@ -27,7 +35,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libvt_oracle.so")
+        path = os.path.join(_HERE, _LIBNAME)
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
@@ -39,7 +47,7 @@ def lib():
 
 
 def _f(a):
-    a = np.ascontiguousarray(a, dtype=np.float32)
+    a = np.ascontiguousarray(a, dtype=REAL)
     return a, a.ctypes.data_as(c_fp)
 
 
@@ -72,7 +80,7 @@ class SmplModel:
     def __init__(self, model: dict):
         self.keep = {}
         for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights"):
-            self.keep[k] = np.ascontiguousarray(model[k], dtype=np.float32)
+            self.keep[k] = np.ascontiguousarray(model[k], dtype=REAL)
         par = np.asarray(model["parents"]).astype(np.int64).copy()
         par[0] = 0
         self.keep["parents"] = np.ascontiguousarray(par, dtype=np.int32)
@@ -88,8 +96,8 @@ class SmplModel:
     def forward(self, pose, betas, trans):
         pose, pp = _f(pose); betas, bp = _f(betas); trans, tp = _f(trans)
         B = pose.shape[0]
-        verts = np.empty((B, self.V, 3), np.float32); jtr = np.empty((B, self.J, 3), np.float32)
-        vposed = np.empty((B, self.V, 3), np.float32)
+        verts = np.empty((B, self.V, 3), REAL); jtr = np.empty((B, self.J, 3), REAL)
+        vposed = np.empty((B, self.V, 3), REAL)
         lib().vto_smplh_forward(C.byref(self.c), pp, bp, tp, B, _fp(verts), _fp(jtr), _fp(vposed))
         return verts, jtr, vposed
 
@@ -100,22 +108,22 @@ class SmplModel:
             djtr, djp = _f(djtr)
         else:
             djp = None
-        dpose = np.zeros((B, self.J * 3), np.float32); dbetas = np.zeros((B, self.NB), np.float32)
-        dtrans = np.zeros((B, 3), np.float32)
+        dpose = np.zeros((B, self.J * 3), REAL); dbetas = np.zeros((B, self.NB), REAL)
+        dtrans = np.zeros((B, 3), REAL)
         lib().vto_smplh_backward(C.byref(self.c), pp, bp, tp, B, dvp, djp, _fp(dpose), _fp(dbetas), _fp(dtrans))
         return dpose, dbetas, dtrans
 
 
 def rodrigues(aa):
     aa, p = _f(aa); n = aa.reshape(-1, 3).shape[0]
-    R = np.empty((n, 9), np.float32)
+    R = np.empty((n, 9), REAL)
     lib().vto_rodrigues(p, n, _fp(R))
     return R
 
 
 def rodrigues_bwd(aa, dR):
     aa, p = _f(aa); dR, q = _f(dR); n = aa.reshape(-1, 3).shape[0]
-    d = np.empty((n, 3), np.float32)
+    d = np.empty((n, 3), REAL)
     lib().vto_rodrigues_bwd(p, n, q, _fp(d))
     return d
 
@@ -129,14 +137,14 @@ class Landmarks:
 
     def forward(self, verts):
         verts, vp = _f(verts); B = verts.shape[0]
-        out = np.empty((B, self.K, 3), np.float32)
+        out = np.empty((B, self.K, 3), REAL)
         lib().vto_landmarks_forward(self.pp, self.ip, self.dp, self.K, vp, B, self.V, _fp(out))
         return out
 
     def backward(self, dout, dverts):
         """accumulates into dverts (B,V,3) float32 contiguous"""
         dout, dp = _f(dout); B = dout.shape[0]
-        assert dverts.dtype == np.float32 and dverts.flags.c_contiguous
+        assert dverts.dtype == REAL and dverts.flags.c_contiguous
         lib().vto_landmarks_backward(self.pp, self.ip, self.dp, self.K, dp, B, self.V, _fp(dverts))
 
 
@@ -144,8 +152,8 @@ def mahalanobis(x, off, mean, prec, dx=None, gscale=0.0):
     """th_Mahalanobis.__call__ (th_smpl_prior.py:30-38) on x[:, off:off+n]; returns (B,) values."""
     x, xp = _f(x); mean, mp = _f(mean); prec, pp = _f(prec)
     B, stride = x.shape; n = mean.shape[0]
-    val = np.empty((B,), np.float32)
-    lib().vto_mahalanobis(xp, B, stride, off, n, mp, pp, _fp(val), _fp(dx), C.c_float(gscale))
+    val = np.empty((B,), REAL)
+    lib().vto_mahalanobis(xp, B, stride, off, n, mp, pp, _fp(val), _fp(dx), c_real(gscale))
     return val
 
 
@@ -153,7 +161,7 @@ MAP_ORDER = ("im_feat", "tmpx", "tri_tmpx0", "tri_tmpx1", "tri_tmpx2", "tri_feat
 HEADS = ("df", "pca", "parts", "centers", "vis")
 HEAD_DIMS = (2, 9, 14, 3, 1)
 # KinectColorCamera defaults (camera.py:26-41) + loadSize 1200 (config/tri-vis-l2.json:40)
-DEFAULT_CAM = np.array([979.7844, 979.840, 1018.952, 779.486, 1200.0], np.float32)
+DEFAULT_CAM = np.array([979.7844, 979.840, 1018.952, 779.486, 1200.0], REAL)
 
 
 class SifNet:
@@ -164,14 +172,14 @@ class SifNet:
         self.dec = _DecC()
         for h, name in enumerate(HEADS):
             for l, (w, b) in enumerate(decoders[name]):
-                w = np.ascontiguousarray(w, np.float32); b = np.ascontiguousarray(b, np.float32)
+                w = np.ascontiguousarray(w, REAL); b = np.ascontiguousarray(b, REAL)
                 self.keep += [w, b]
                 self.dec.w[h][l] = _fp(w); self.dec.b[h][l] = _fp(b)
         self.set_maps(maps)
-        self.cam = np.ascontiguousarray(cam, np.float32)
+        self.cam = np.ascontiguousarray(cam, REAL)
 
     def set_maps(self, maps: dict):
-        self.maps_keep = [np.ascontiguousarray(maps[k], np.float32) for k in MAP_ORDER]
+        self.maps_keep = [np.ascontiguousarray(maps[k], REAL) for k in MAP_ORDER]
         self.maps = (_MapC * 8)()
         for i, m in enumerate(self.maps_keep):
             self.maps[i] = _MapC(_fp(m), m.shape[1], m.shape[2], m.shape[3])
@@ -179,7 +187,7 @@ class SifNet:
     def query(self, pts, crop_center, body_center, head_mask=31):
         pts, pp = _f(pts); cc, cp = _f(crop_center); bc, bp = _f(body_center)
         B, N = pts.shape[:2]
-        outs = [np.zeros((B, d, N), np.float32) for d in HEAD_DIMS]
+        outs = [np.zeros((B, d, N), REAL) for d in HEAD_DIMS]
         lib().vto_query_forward(C.byref(self.dec), self.maps, pp, cp, bp, B, N, _fp(self.cam), head_mask,
                                 *[_fp(o) for o in outs])
         return tuple(outs)
@@ -187,8 +195,8 @@ class SifNet:
     def query_bwd(self, pts, crop_center, body_center, d_df=None, d_pca=None, d_parts=None, d_centers=None, d_vis=None):
         pts, pp = _f(pts); cc, cp = _f(crop_center); bc, bp = _f(body_center)
         B, N = pts.shape[:2]
-        gs = [None if g is None else np.ascontiguousarray(g, np.float32) for g in (d_df, d_pca, d_parts, d_centers, d_vis)]
-        dpts = np.zeros((B, N, 3), np.float32)
+        gs = [None if g is None else np.ascontiguousarray(g, REAL) for g in (d_df, d_pca, d_parts, d_centers, d_vis)]
+        dpts = np.zeros((B, N, 3), REAL)
         lib().vto_query_backward(C.byref(self.dec), self.maps, pp, cp, bp, B, N, _fp(self.cam),
                                  *[_fp(g) for g in gs], _fp(dpts))
         return dpts
@@ -197,27 +205,27 @@ class SifNet:
 def approx_surface(net: "SifNet", samples, num_steps, crop_center, body_center, df_idx, threshold=1.0):
     """Generator.approx_surface (recon/gen/generator.py:72-103): num_steps times  target = clamp(df[:, idx], max = thr);
     g = d sum(target) / d samples;  samples -= g / max(|g|, 1e-12) * target.  Returns (samples, target at the last query)."""
-    x = np.asarray(samples, np.float32).copy()
+    x = np.asarray(samples, REAL).copy()
     tgt = None
     for _ in range(num_steps):
         df = net.query(x, crop_center, body_center, head_mask=1)[0]
-        d = df[:, df_idx].astype(np.float32)
-        tgt = np.minimum(d, np.float32(threshold))
-        d_df = np.zeros_like(df); d_df[:, df_idx] = (d <= threshold).astype(np.float32)
+        d = df[:, df_idx].astype(REAL)
+        tgt = np.minimum(d, REAL(threshold))
+        d_df = np.zeros_like(df); d_df[:, df_idx] = (d <= threshold).astype(REAL)
         g = net.query_bwd(x, crop_center, body_center, d_df=d_df)
-        nrm = np.maximum(np.sqrt((g.astype(np.float32) ** 2).sum(-1, keepdims=True)), np.float32(1e-12))
-        x = (x - g / nrm * tgt[..., None]).astype(np.float32)
+        nrm = np.maximum(np.sqrt((g.astype(REAL) ** 2).sum(-1, keepdims=True)), REAL(1e-12))
+        x = (x - g / nrm * tgt[..., None]).astype(REAL)
     return x, tgt
 
 
 def so3_project(M):
-    M, p = _f(M); B = M.shape[0]; R = np.empty((B, 3, 3), np.float32)
+    M, p = _f(M); B = M.shape[0]; R = np.empty((B, 3, 3), REAL)
     lib().vto_so3_project(p, B, _fp(R))
     return R
 
 
 def so3_project_bwd(M, dR):
-    M, p = _f(M); dR, q = _f(dR); B = M.shape[0]; dM = np.empty((B, 3, 3), np.float32)
+    M, p = _f(M); dR, q = _f(dR); B = M.shape[0]; dM = np.empty((B, 3, 3), REAL)
     lib().vto_so3_project_bwd(p, B, q, _fp(dM))
     return dM
 
@@ -225,7 +233,7 @@ def so3_project_bwd(M, dR):
 def rigid(X0, R, t, s):
     X0, xp = _f(X0); R, rp = _f(R); t, tp = _f(t); s, sp = _f(s)
     B = R.shape[0]; shared = int(X0.ndim == 2); N = X0.shape[-2]
-    X = np.empty((B, N, 3), np.float32)
+    X = np.empty((B, N, 3), REAL)
     lib().vto_rigid_forward(xp, shared, rp, tp, sp, B, N, _fp(X))
     return X
 
@@ -233,7 +241,7 @@ def rigid(X0, R, t, s):
 def rigid_bwd(X0, R, t, s, dX):
     X0, xp = _f(X0); R, rp = _f(R); t, tp = _f(t); s, sp = _f(s); dX, gp = _f(dX)
     B = R.shape[0]; shared = int(X0.ndim == 2); N = X0.shape[-2]
-    dR = np.empty((B, 3, 3), np.float32); dt = np.empty((B, 3), np.float32)
+    dR = np.empty((B, 3, 3), REAL); dt = np.empty((B, 3), REAL)
     lib().vto_rigid_backward(xp, shared, rp, tp, sp, B, N, gp, _fp(dR), _fp(dt))
     return dR, dt
 
@@ -244,12 +252,12 @@ def accel_loss(v, elem_w=None, gscale=0.0, dv=None):
     wp = None
     if elem_w is not None:
         elem_w, wp = _f(elem_w)
-    return lib().vto_accel_loss(vp, B, D, wp, C.c_float(gscale), _fp(dv))
+    return lib().vto_accel_loss(vp, B, D, wp, c_real(gscale), _fp(dv))
 
 
 def velocity_loss(v, gscale=0.0, dv=None):
     v, vp = _f(v); B = v.shape[0]; D = v.size // B
-    return lib().vto_velocity_loss(vp, B, D, C.c_float(gscale), _fp(dv))
+    return lib().vto_velocity_loss(vp, B, D, c_real(gscale), _fp(dv))
 
 
 def chamfer_ragged(xs, ys, gscale=0.0, want_grad=False):
@@ -261,14 +269,14 @@ def chamfer_ragged(xs, ys, gscale=0.0, want_grad=False):
     dx = np.zeros_like(x) if want_grad else None
     dy = np.zeros_like(y) if want_grad else None
     val = lib().vto_chamfer_ragged(xp, offx.ctypes.data_as(c_ip), yp, offy.ctypes.data_as(c_ip), P,
-                                   C.c_float(gscale), _fp(dx), _fp(dy))
+                                   c_real(gscale), _fp(dx), _fp(dy))
     return (val, dx, dy, offx, offy) if want_grad else val
 
 
 def sil_forward(verts, faces, K, size=256):
     verts, vp = _f(verts); faces, fp = _i(faces); K, kp = _f(K)
     B, NV = verts.shape[:2]
-    img = np.empty((B, size, size), np.float32)
+    img = np.empty((B, size, size), REAL)
     lib().vto_sil_forward(vp, B, NV, fp, faces.shape[0], kp, size, _fp(img))
     return img
 
@@ -277,14 +285,14 @@ def triplane_render(verts, faces, center, size=512):
     """TriplaneNrRenderer.render_3views for a batch: (B,NV,3), (NF,3), (B,3) -> (B,3,size,size) masks (right, back, top)"""
     verts, vp = _f(verts); faces, fp = _i(faces); center, cp = _f(center)
     B, NV = verts.shape[:2]
-    out = np.zeros((B, 3, size, size), np.float32)
+    out = np.zeros((B, 3, size, size), REAL)
     lib().vto_triplane_render(vp, cp, B, NV, fp, faces.shape[0], size, _fp(out))
     return out
 
 
 def transform_view(points_center, view, z_offset=10.0):
     """TriplaneNrRenderer.transform_view (render/render_triplane_nr.py:110-139)"""
-    p = np.asarray(points_center, np.float32); o = np.empty_like(p)
+    p = np.asarray(points_center, REAL); o = np.empty_like(p)
     if view == "right":
         o[:, 0], o[:, 1], o[:, 2] = p[:, 2], -p[:, 1], -p[:, 0] + z_offset
     elif view == "back":
@@ -299,8 +307,8 @@ def transform_view(points_center, view, z_offset=10.0):
 def sil_backward(verts, faces, K, d_image, size=256, eps=1e-4):
     verts, vp = _f(verts); faces, fp = _i(faces); K, kp = _f(K); d_image, dp = _f(d_image)
     B, NV = verts.shape[:2]
-    dv = np.zeros((B, NV, 3), np.float32)
-    lib().vto_sil_backward(vp, B, NV, fp, faces.shape[0], kp, size, dp, C.c_float(eps), _fp(dv))
+    dv = np.zeros((B, NV, 3), REAL)
+    lib().vto_sil_backward(vp, B, NV, fp, faces.shape[0], kp, size, dp, c_real(eps), _fp(dv))
     return dv
 
 
@@ -317,10 +325,10 @@ class Adam:
     def step(self, grads):
         self.t += 1
         for p, g, m, v, lr in zip(self.params, grads, self.m, self.v, self.lrs):
-            assert p.dtype == np.float32 and p.flags.c_contiguous
-            g = np.ascontiguousarray(g, np.float32)
-            lib().vto_adam_step(_fp(p), _fp(g), _fp(m), _fp(v), p.size, self.t, C.c_float(lr),
-                                C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps))
+            assert p.dtype == REAL and p.flags.c_contiguous
+            g = np.ascontiguousarray(g, REAL)
+            lib().vto_adam_step(_fp(p), _fp(g), _fp(m), _fp(v), p.size, self.t, c_real(lr),
+                                c_real(self.betas[0]), c_real(self.betas[1]), c_real(self.eps))
 
 
 def num_threads():
@@ -332,7 +340,7 @@ def num_threads():
 # ------------------------------------------------------------------------------------------------
 # joint_weights of compute_Jaccel_loss (fit_SMPLH_30fps.py:26-51)
 JOINT_WEIGHTS_66 = np.repeat(np.array(
-    [1, 10, 10, 10, 5, 5, 10, 1, 1, 10, 1, 1, 5, 5, 5, 5, 5, 5, 1, 1, 1, 1], np.float32), 3)
+    [1, 10, 10, 10, 5, 5, 10, 1, 1, 10, 1, 1, 5, 5, 5, 5, 5, 5, 1, 1, 1, 1], REAL), 3)
 JOINT_WEIGHTS_66[37] = 10.0
 JOINT_WEIGHTS_66[38] = 10.0  # neck row is (5, 10, 10)
 
@@ -353,7 +361,7 @@ def smplt_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, pose, bet
     verts, jtr, _ = smpl.forward(pose, betas, trans)
     J = body25.forward(verts).astype(np.float64)
     terms = {}
-    dverts = np.zeros_like(verts); dpose = np.zeros((B, 156), np.float32)
+    dverts = np.zeros_like(verts); dpose = np.zeros((B, 156), REAL)
     # kpts: err = (proj - kpts_xy)^2 * conf ; mean over B*25*2  (fit_SMPLH_30fps.py:165-168)
     px = J[:, :, 0] * fx / J[:, :, 2] + cx; py = J[:, :, 1] * fy / J[:, :, 2] + cy
     conf = kpts[:, :, 2].astype(np.float64)
@@ -364,11 +372,11 @@ def smplt_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, pose, bet
     dJ = np.zeros((B, 25, 3))
     dJ[:, :, 0] = gpx * fx / J[:, :, 2]; dJ[:, :, 1] = gpy * fy / J[:, :, 2]
     dJ[:, :, 2] = -gpx * fx * J[:, :, 0] / J[:, :, 2] ** 2 - gpy * fy * J[:, :, 1] / J[:, :, 2] ** 2
-    body25.backward(dJ.astype(np.float32), dverts)
+    body25.backward(dJ.astype(REAL), dverts)
     if temporal:
         terms["temp"] = accel_loss(verts, None, w["temp"], dverts)                      # :196-200
         terms["ptemp"] = accel_loss(pose[:, :66].copy(), JOINT_WEIGHTS_66, 0.0, None)    # :189-194
-        g66 = np.zeros((B, 66), np.float32)
+        g66 = np.zeros((B, 66), REAL)
         accel_loss(pose[:, :66].copy(), JOINT_WEIGHTS_66, w["ptemp"], g66)
         dpose[:, :66] += g66
     # priors (fit_SMPLH_30fps.py:182-187): mean over batch
@@ -381,7 +389,7 @@ def smplt_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, pose, bet
     # pinit = mean((pose_init[:, 3:66] - body_pose)^2)  (:178)
     dif = pose[:, 3:66].astype(np.float64) - pose_init[:, 3:66]
     terms["pinit"] = float((dif ** 2).mean())
-    dpose[:, 3:66] += (2 * dif * w["pinit"] / dif.size).astype(np.float32)
+    dpose[:, 3:66] += (2 * dif * w["pinit"] / dif.size).astype(REAL)
     g_pose, g_betas, g_trans = smpl.backward(pose, betas, trans, dverts)
     dpose += g_pose
     total = sum(w[k] * terms[k] for k in terms)
@@ -405,7 +413,7 @@ def smplfit_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, net: Si
     B = pose.shape[0]; V = smpl.V
     verts, _, _ = smpl.forward(pose, betas, trans)
     terms = {}
-    dverts = np.zeros_like(verts); dpose = np.zeros((B, 156), np.float32)
+    dverts = np.zeros_like(verts); dpose = np.zeros((B, 156), REAL)
     # df_h = clamp(df[:,0:1], max=.1).mean() (recon_fit_base.py:640-647); part CE (recon_fit_behave.py:486)
     df, _, parts, _, _ = net.query(verts, crop_center, body_center)
     dfh = df[:, 0].astype(np.float64)
@@ -420,8 +428,8 @@ def smplfit_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, net: Si
     terms["part"] = float(ce.sum(-1).mean())
     sm = np.exp(logp)
     np.put_along_axis(sm, lab[:, None, :], np.take_along_axis(sm, lab[:, None, :], 1) - 1.0, 1)
-    d_parts = (sm * (w["part"] / B)).astype(np.float32)
-    dverts += net.query_bwd(verts, crop_center, body_center, d_df=d_df.astype(np.float32), d_parts=d_parts)
+    d_parts = (sm * (w["part"] / B)).astype(REAL)
+    dverts += net.query_bwd(verts, crop_center, body_center, d_df=d_df.astype(REAL), d_parts=d_parts)
     # priors (recon_fit_base.py:625-638)
     terms["pose"] = float(mahalanobis(pose, 3, pri["body_mean"], pri["body_prec"], dpose, w["pose"] / B).astype(np.float64).mean())
     # HandPrior quirk: the (1,45,45) precision broadcasts the matmul to (1,B,45), cat(axis=1) gives (1,2B,45) and
@@ -432,7 +440,7 @@ def smplfit_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, net: Si
     # pinit = mean_B sum (pose[:, 3:72] - pose_init)^2  (recon_fit_behave.py:493-495)
     dif = pose[:, 3:72].astype(np.float64) - pose_init
     terms["pinit"] = float((dif ** 2).sum(-1).mean())
-    dpose[:, 3:72] += (2 * dif * w["pinit"] / B).astype(np.float32)
+    dpose[:, 3:72] += (2 * dif * w["pinit"] / B).astype(REAL)
     if phase == "kpts":
         # projection_loss (recon_fit_base.py:781-802): crop-space pinhole * 512/1200
         cam = net.cam.astype(np.float64)
@@ -446,7 +454,7 @@ def smplfit_loss_and_grad(smpl: SmplModel, body25: Landmarks, pri: dict, net: Si
         dJ = np.zeros((B, 25, 3))
         dJ[:, :, 0] = gpx * cam[0] / J[:, :, 2]; dJ[:, :, 1] = gpy * cam[1] / J[:, :, 2]
         dJ[:, :, 2] = -gpx * cam[0] * J[:, :, 0] / J[:, :, 2] ** 2 - gpy * cam[1] * J[:, :, 1] / J[:, :, 2] ** 2
-        body25.backward(dJ.astype(np.float32), dverts)
+        body25.backward(dJ.astype(REAL), dverts)
     if B >= 4:
         terms["stemp"] = accel_loss(verts, None, w["stemp"], dverts)   # recon_fit_trivis_full.py:170-177
     g_pose, g_betas, g_trans = smpl.backward(pose, betas, trans, dverts)
@@ -466,13 +474,13 @@ def objfit_loss_and_grad(net: SifNet, obj_points, obj_R, obj_t, obj_s, noise, cr
     """
     w = {k: v / (1 + decay) for k, v in FIT_WEIGHTS.items()}
     B = obj_R.shape[0]
-    M = (obj_R + np.float32(1e-4) * noise).astype(np.float32)
+    M = (obj_R + REAL(1e-4) * noise).astype(REAL)
     R = so3_project(M)
     X = rigid(obj_points, R, obj_t, obj_s)
     N = X.shape[1]
     terms = {}
     dX = np.zeros_like(X)
-    dR = np.zeros((B, 3, 3), np.float32); dt = np.zeros((B, 3), np.float32)
+    dR = np.zeros((B, 3, 3), REAL); dt = np.zeros((B, 3), REAL)
     tw = 10.0 if phase == "joint" else 1.0
     if B >= 4:  # temporal_loss_joint (recon_fit_trivis_full.py:379-391)
         terms["otemp"] = accel_loss(X, None, w["otemp"] * tw, dX) * tw
@@ -484,14 +492,14 @@ def objfit_loss_and_grad(net: SifNet, obj_points, obj_R, obj_t, obj_s, noise, cr
         image = e["keep"] * img
         per = ((image - e["ref"]).astype(np.float64) ** 2).sum((1, 2))      # obj_pose_roi.py:191-198
         terms["mask"] = float((per * occ).mean())                           # recon_fit_trivis_full.py:164-168
-        d_img = (2.0 * (image - e["ref"]) * e["keep"] * (occ[:, None, None] * w["mask"] / B)).astype(np.float32)
+        d_img = (2.0 * (image - e["ref"]) * e["keep"] * (occ[:, None, None] * w["mask"] / B)).astype(REAL)
         dVt = sil_backward(Vt, e["faces"], e["K"], d_img)
         gR, gt = rigid_bwd(e["verts"], R, obj_t, obj_s, dVt)
         dR += gR; dt += gt
         terms["scale"] = float(((obj_s.astype(np.float64) - 1.0) ** 2).mean())
         dtr = obj_t.astype(np.float64) - e["trans_init"]
         terms["trans"] = float((dtr ** 2).mean())
-        dt += (2 * dtr * w["trans"] / dtr.size).astype(np.float32)
+        dt += (2 * dtr * w["trans"] / dtr.size).astype(REAL)
     else:
         df, _, parts, centers, _ = net.query(X, crop_center, body_center)
         dfo = df[:, 1].astype(np.float64)
@@ -503,7 +511,7 @@ def objfit_loss_and_grad(net: SifNet, obj_points, obj_R, obj_t, obj_s, noise, cr
         pred = smpl_center.astype(np.float64) + centers.astype(np.float64).mean(-1)
         act = X.astype(np.float64).mean(1)
         terms["ocent"] = float((((act - pred) ** 2).sum(-1) * occ).mean())
-        dX += net.query_bwd(X, crop_center, body_center, d_df=d_df.astype(np.float32))
+        dX += net.query_bwd(X, crop_center, body_center, d_df=d_df.astype(REAL))
         if phase == "joint" and extra is not None:
             e = extra
             xs, ys, sel = contact_pairs(e["df_hum_o"], e["df_obj_h"], e["parts_obj"], e["part_labels"])
@@ -533,10 +541,10 @@ def collision_loss(smpl_verts, smpl_faces, obj_verts, obj_faces, sigma=0.5, max_
     distance-field penetration of the human-object triangle pairs; returns (value, d value / d obj_t * gscale (B,3), pairs per frame)."""
     sv, svp = _f(smpl_verts); ov, ovp = _f(obj_verts)
     sf = np.ascontiguousarray(smpl_faces, np.int32); of = np.ascontiguousarray(obj_faces, np.int32)
-    B = sv.shape[0]; dt = np.zeros((B, 3), np.float32); npairs = np.zeros(B, np.int32)
+    B = sv.shape[0]; dt = np.zeros((B, 3), REAL); npairs = np.zeros(B, np.int32)
     fn = lib().vto_collision_loss; fn.restype = C.c_double
     val = fn(svp, C.c_int(sv.shape[1]), sf.ctypes.data_as(C.c_void_p), C.c_int(len(sf)), ovp, C.c_int(ov.shape[1]), of.ctypes.data_as(C.c_void_p), C.c_int(len(of)),
-             C.c_int(B), C.c_float(sigma), C.c_int(max_coll), C.c_float(gscale), _fp(dt), npairs.ctypes.data_as(C.c_void_p))
+             C.c_int(B), c_real(sigma), C.c_int(max_coll), c_real(gscale), _fp(dt), npairs.ctypes.data_as(C.c_void_p))
     return float(val), dt, npairs
 
 

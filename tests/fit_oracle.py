@@ -8,11 +8,14 @@ Each loop follows the reference line by line (schedule, optimiser switches, deca
 """
 import numpy as np
 
-from oracle import oracle as O
+from oracle import oracle as O32
+
+# every loop takes the oracle module to step (``O``): oracle.oracle (fp32, the reference's arithmetic) or oracle.oracle64 (the same restatement in
+# float64: the arbiter of what fp32 round-off alone does to a long Adam trajectory)
 
 
-def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_for_global=8, lr_global=0.01, lr_all=0.001):
-    pose, betas, trans = pose0.copy(), betas0.copy(), trans0.copy(); pose_init = pose.copy()
+def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_for_global=8, lr_global=0.01, lr_all=0.001, O=O32):
+    pose, betas, trans = (x.astype(O.REAL) for x in (pose0, betas0, trans0)); pose_init = pose.copy()
     gp, bp, tb, ob = pose[:, :3].copy(), pose[:, 3:66].copy(), betas[:, :2].copy(), betas[:, 2:].copy()
     opt = O.Adam([trans, gp, tb], lr_global); prev = 0.0; losses = []; stopped = False
     for it in range(max_iter):
@@ -35,8 +38,8 @@ def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_
     return pose, betas, trans, np.array(losses), stopped
 
 
-def oracle_optimize_smpl(m, b25, pri, net, labels, pose0, betas0, trans0, cc, bc, kpts, max_iter=100, iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1):
-    pose, betas, trans = pose0.copy(), betas0.copy(), trans0.copy(); pose_init = pose[:, 3:72].copy()
+def oracle_optimize_smpl(m, b25, pri, net, labels, pose0, betas0, trans0, cc, bc, kpts, max_iter=100, iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, O=O32):
+    pose, betas, trans = (x.astype(O.REAL) for x in (pose0, betas0, trans0)); pose_init = pose[:, 3:72].copy()
     gp, bp, tb, ob = pose[:, :3].copy(), pose[:, 3:66].copy(), betas[:, :2].copy(), betas[:, 2:].copy()
     kw = dict(crop_center=cc, body_center=bc, body_kpts=kpts, pose_init=pose_init)
     opt = O.Adam([tb, trans], 0.02); prev = 300.0; losses = []; stopped = False
@@ -63,10 +66,10 @@ def oracle_optimize_smpl(m, b25, pri, net, labels, pose0, betas0, trans0, cc, bc
 
 
 def oracle_optimize_object(net, pts, R0, t0, sc, noise, cc, bc, occ, sverts, labels, sil=None, iter_for_obj=15, iter_for_sil=30, joint_iter=10,
-                           max_iter=100):
+                           max_iter=100, O=O32):
     """``sil``: dict(faces, verts, K, keep, ref) or None when iter_for_sil == 0.  ``noise`` (steps,B,3,3).  Returns R, t, losses, stopped, had_contacts."""
     B = R0.shape[0]
-    Ro, to = R0.copy(), t0.copy()
+    Ro, to = R0.astype(O.REAL), t0.astype(O.REAL); sc = sc.astype(O.REAL)
     losses = []; extra_j = None; stopped = False; prev = 300.0; had_contacts = False
     opt = O.Adam([Ro, to], [0.002, 0.006]); trans_init = None; k = 0
     for it in range(joint_iter + iter_for_obj + max_iter + iter_for_sil):
@@ -88,12 +91,12 @@ def oracle_optimize_object(net, pts, R0, t0, sc, noise, cc, bc, occ, sverts, lab
                 extra = dict(sil); extra["trans_init"] = trans_init
             if phase == "joint":
                 if extra_j is None:        # 'Computing contacts once' (recon_fit_trivis_full.py:242-253)
-                    X = O.rigid(pts, O.so3_project((Ro + np.float32(1e-4) * nz).astype(np.float32)), to, sc)
+                    X = O.rigid(pts, O.so3_project((Ro + O.REAL(1e-4) * nz).astype(O.REAL)), to, sc)
                     df_o, _, parts_o, _, _ = net.query(X, cc, bc)
                     df_h = net.query(sverts, cc, bc)[0]
                     extra_j = {"smpl_verts": sverts, "df_hum_o": df_h[:, 1], "df_obj_h": df_o[:, 0], "parts_obj": parts_o.argmax(1), "part_labels": labels}
                 extra = extra_j
-            total, terms, dM, dt = O.objfit_loss_and_grad(net, pts, Ro, to, sc, nz, cc, bc, occ, np.zeros((B, 3), np.float32), phase, decay, extra)
+            total, terms, dM, dt = O.objfit_loss_and_grad(net, pts, Ro, to, sc, nz, cc, bc, occ, np.zeros((B, 3), O.REAL), phase, decay, extra)
             had_contacts = had_contacts or ("contact" in terms)
             losses.append(total)
             opt.step([dM, dt] if phase != "joint" else [dt])

@@ -1,8 +1,12 @@
 """GPU (-m gpu): FULL-SCHEDULE parity -- the fused fit loops run from their start to the reference's stop rule, against the CPU oracle
 stepped through the same schedule (tests/fit_oracle.py, test infrastructure): step counts, loss histories and the final geometry.
 
-Bar: 1e-3 m (north star) on the final vertices for the SMPL-T pre-fit (466 Adam steps), the SMPL stage of the joint fit (282 steps) and the
-object stage on a slowly varying field without the 'sil' phase; the complete object stage (150 'object only' + 300 'sil' + 'joint' steps to
+Bar: 1e-3 m (north star), STRICT, on the final vertices for the SMPL-T pre-fit (466 Adam steps), the SMPL stage of the joint fit (282 steps) and the
+object stage (150 'object only' + 'joint' steps to the stop rule, contacts + Chamfer live) on the WELL-CONDITIONED analytic-field fixture SURVEY.md 8(d)
+prescribes (synthetic.bowl_decoders: the HIP path started 1e-6 m away ends <= 1e-4 m from itself, asserted); on those cases the float64 build of the
+oracle (oracle/oracle64.py) arbitrates as well: the HIP result must be as close to the fp64 trajectory as the fp32 oracle is, or within the bar.
+The object stage on the random-weight field is chaotic (its own self-distance sits at the bar) and is kept as a REPORTED ENVELOPE, not as the gate;
+the complete object stage (150 'object only' + 300 'sil' + 'joint' steps to
 the stop rule) is held to its own conditioning (measured: HIP vs oracle 3.0e-3 m, HIP vs HIP started 1e-6 m away 4.7e-3 m): the 'sil' objective is piecewise constant in the pose (pixel coverage), Adam turns
 a sign flip of a near-zero gradient component into an lr-sized step, so two correct implementations separate -- the test measures how far
 the HIP path separates from ITSELF under a 1e-6 m perturbation of the initial translation and requires the HIP-oracle distance to stay within
@@ -30,6 +34,20 @@ def rel(a, b):
 def v2v(a, b):
     d = np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=-1)
     return d.mean(), d.max()
+
+
+REPORT = {}      # measured distances of this session, written to gpurun_out/fullsched_parity.json when the tests run on the GPU box (copied to profiles/ by hand)
+
+
+def _report(key, **vals):
+    import json, os
+    REPORT[key] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in vals.items()}
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/fullsched_parity.json", "w") as f:
+            json.dump(REPORT, f, indent=1)
+    except OSError:
+        pass
 
 
 def test_full_schedule_smplt_prefit_vs_oracle(synth):
@@ -62,6 +80,15 @@ def test_full_schedule_smplt_prefit_vs_oracle(synth):
     assert rel(res.losses[:n], losses[:n]) < 1e-5
     mean, mx = v2v(verts_hip, verts_cpu)
     assert mean < 1e-4 and mx < 1e-3, (mean, mx)      # measured 3e-7 / 1e-6 m when the step counts agree
+    # fp64 arbiter: the same schedule on the float64 build of the oracle -- the HIP result is as close to it as the fp32 oracle is (or within the bar)
+    from oracle import oracle64 as O64
+    m64 = O64.SmplModel(model)
+    p64, b64, t64, l64, _ = oracle_fit_smplt(m64, O64.Landmarks(regs["body25"]), pri, pose0, betas0, trans0, kp, O=O64)
+    v64 = m64.forward(p64, b64, t64)[0]
+    h64, o3264 = v2v(verts_hip, v64)[0], v2v(verts_cpu, v64)[0]
+    _report("smplt_prefit", hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, hip_vs_oracle64_mean=h64, oracle32_vs_oracle64_mean=o3264, steps_hip=res.steps,
+            steps_oracle=len(losses), steps_oracle64=len(l64))
+    assert h64 <= max(1e-3, o3264), (h64, o3264)
 
 
 def test_full_schedule_smpl_stage_vs_oracle(synth):
@@ -96,6 +123,14 @@ def test_full_schedule_smpl_stage_vs_oracle(synth):
     mean, mx = v2v(verts_hip, verts_cpu)
     assert mean < 1e-3, (mean, mx)                                   # measured 3.7e-4 m mean, 2e-3 m max (hands of a random-weight field)
     assert mx < 5e-3, (mean, mx)
+    # fp64 arbiter (the float64 build of the oracle on the same schedule)
+    from oracle import oracle64 as O64
+    m64 = O64.SmplModel(model)
+    p64, b64, t64, l64, _ = oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(dec, mp), labels, g["pose"], g["betas"], g["trans"],
+                                                 g["crop_center"], g["body_center"], g["body_kpts"], O=O64)
+    v64 = m64.forward(p64, b64, t64)[0]
+    h64, o3264 = v2v(verts_hip, v64)[0], v2v(verts_cpu, v64)[0]
+    assert h64 <= max(1e-3, o3264), (h64, o3264)
     # ---- attribution of the drift: the same schedule (a) on the strict-fp32 kernels (exact fp32 products: the reference's arithmetic),
     #      (b) on the 512-thread kernel (identical split arithmetic, another summation order of the coordinate gradient = fp32 round-off only).
     #      If the split operands were what separates HIP from the oracle, (a) would sit much closer to the oracle than the split run and (b)
@@ -104,11 +139,16 @@ def test_full_schedule_smpl_stage_vs_oracle(synth):
     r32, v32 = run("fp32"); r512, v512 = run(kernel=512)
     d = {"split vs oracle": mean, "fp32 vs oracle": v2v(v32, verts_cpu)[0], "split vs fp32": v2v(verts_hip, v32)[0], "split 256 vs 512 threads": v2v(verts_hip, v512)[0]}
     print("full-schedule SMPL stage, mean v2v [m]:", {k: f"{x:.2e}" for k, x in d.items()}, "steps", res.steps, r32.steps, r512.steps, len(losses))
+    _report("smpl_stage", hip_vs_oracle64_mean=h64, oracle32_vs_oracle64_mean=o3264, steps_hip=res.steps, steps_oracle=len(losses), steps_oracle64=len(l64),
+            **{k.replace(" ", "_"): x for k, x in d.items()})
     assert all(x < 1e-3 for x in d.values()), d
     assert abs(r32.steps - len(losses)) <= 2 and abs(r512.steps - res.steps) <= 2
 
 
-def _object_case(synth, B, N, seed):
+def _object_case(synth, B, N, seed, field="random"):
+    """``field``: 'random' = the session's random-weight decoders on smoothed random maps (uninformative: chaotic trajectories, Appendix A.11);
+    'bowl' = the analytic well-conditioned distance field of synthetic.bowl_decoders (human bowl at the body, object bowl at the objects' mean
+    position) on the same maps; the start translation is then 0.1 m (sigma per axis) off, so that the fit has a real basin to descend into."""
     from oracle import oracle as O
     from vistracker_amd import synthetic as syn
     rng = np.random.default_rng(seed)
@@ -123,7 +163,12 @@ def _object_case(synth, B, N, seed):
     ref = O.sil_forward(O.rigid(ov, O.so3_project(seq["obj_R"]), seq["obj_t"], sc), of, K, 256)
     keep = np.ones_like(ref); keep[:, 100:140, :90] = 0; ref = ref * keep
     R0 = (seq["obj_R"] + rng.normal(0, 0.02, (B, 3, 3))).astype(np.float32); t0 = (seq["obj_t"] + rng.normal(0, 0.03, (B, 3))).astype(np.float32)
-    return dict(ov=ov, of=of, pts=pts, mp=mp, cc=cc, bc=bc, occ=seq["occ_ratios"].astype(np.float32), sverts=sverts, K=K, keep=keep, ref=ref, R0=R0, t0=t0, sc=sc)
+    dec = synth["decoders"]
+    if field == "bowl":
+        dec = syn.bowl_decoders(seq["obj_t"].mean(0), seq["trans"].mean(0))
+        t0 = (t0 + 0.1 * np.random.default_rng(5).normal(0, 1, (B, 3))).astype(np.float32)
+    return dict(ov=ov, of=of, pts=pts, mp=mp, cc=cc, bc=bc, occ=seq["occ_ratios"].astype(np.float32), sverts=sverts, K=K, keep=keep, ref=ref, R0=R0, t0=t0, sc=sc,
+                dec=dec)
 
 
 def _run_hip_object(ctx, maps, c, noise, t0, **kw):
@@ -135,47 +180,70 @@ def _run_hip_object(ctx, maps, c, noise, t0, **kw):
     return res, R.cpu().numpy(), t.cpu().numpy()
 
 
-@pytest.mark.parametrize("with_sil", [False, True])
-def test_full_schedule_object_stage_vs_oracle(synth, with_sil):
+@pytest.mark.parametrize("field,with_sil", [("bowl", False), ("random", False), ("random", True)])
+def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
     """optimize_smpl_object (recon_fit_trivis_full.py:283-377) to its stop rule: 150 'object only' steps, (300 'sil' steps), then 'joint'
-    (contacts computed once, Chamfer term) until the rule fires."""
-    from oracle import oracle as O
+    (contacts computed once, Chamfer term) until the rule fires.  ('bowl', no 'sil') is the GATE: strict 1e-3 m against the fp32 oracle AND the fp64
+    arbiter on a fixture whose self-distance under a 1e-6 m perturbation is <= 1e-4 m; the two 'random' legs are reported envelopes."""
+    from oracle import oracle as O, oracle64 as O64
     from vistracker_amd import ops
     from vistracker_amd.fitting import FitContext
     B, N = 4, 600
-    c = _object_case(synth, B, N, seed=17)
+    c = _object_case(synth, B, N, seed=17, field=field)
     kw = dict(iter_for_obj=15, iter_for_sil=30 if with_sil else 0, joint_iter=10, max_iter=100)
     nsteps = (kw["iter_for_obj"] + kw["iter_for_sil"] + kw["joint_iter"] + kw["max_iter"]) * 10
     noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
-    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], c["ov"], c["of"], c["pts"])
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], c["dec"], synth["labels"], c["ov"], c["of"], c["pts"])
     ctx_pts = ctx.obj_points.cpu().numpy()          # FitContext stores the surface samples in Morton order: the oracle gets the same array
     maps = ops.FeatureMaps.from_nchw(c["mp"])
     res, R, t = _run_hip_object(ctx, maps, c, noise, c["t0"], **kw)
     # conditioning of the trajectory: the same HIP run from a start translated by 1e-6 m
     res_p, R_p, t_p = _run_hip_object(ctx, maps, c, noise, c["t0"] + np.float32(1e-6), **kw)
-    net = O.SifNet(synth["decoders"], c["mp"])
     sil = dict(faces=c["of"], verts=c["ov"], K=c["K"], keep=c["keep"], ref=c["ref"]) if with_sil else None
-    Ro, to, losses, stopped, had_contacts = oracle_optimize_object(net, ctx_pts, c["R0"], c["t0"], c["sc"], noise, c["cc"], c["bc"], c["occ"], c["sverts"],
-                                                                   synth["labels"], sil=sil, **kw)
+
+    def oracle_run(Om):
+        net = Om.SifNet(c["dec"], c["mp"])
+        Ro, to, losses, stopped, hc = oracle_optimize_object(net, ctx_pts, c["R0"], c["t0"], c["sc"], noise, c["cc"], c["bc"], c["occ"], c["sverts"],
+                                                            synth["labels"], sil=sil, O=Om, **kw)
+        return O.rigid(ctx_pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), c["sc"]), losses, stopped, hc
+    Xo, losses, stopped, had_contacts = oracle_run(O)
     assert had_contacts, "the joint phase of this case must have contacts"
     assert res.stopped_early == stopped
-    X = O.rigid(ctx_pts, O.so3_project(R), t, c["sc"]); Xo = O.rigid(ctx_pts, O.so3_project(Ro), to, c["sc"])
-    Xp = O.rigid(ctx_pts, O.so3_project(R_p), t_p, c["sc"])
+    X = O.rigid(ctx_pts, O.so3_project(R), t, c["sc"]); Xp = O.rigid(ctx_pts, O.so3_project(R_p), t_p, c["sc"])
     mean, mx = v2v(X, Xo); self_mean, _ = v2v(X, Xp)
     n_obj = kw["iter_for_obj"] * 10
-    assert rel(res.losses[:n_obj], losses[:n_obj]) < 3e-3                 # the smooth 'object only' phase tracks step by step (measured 1.0e-3 after 150 steps)
+    assert rel(res.losses[:n_obj], losses[:n_obj]) < 3e-3                 # the smooth 'object only' phase tracks step by step
+    msg = f"[{field}, sil={with_sil}] HIP vs oracle mean {mean:.3e} m (max {mx:.3e}); HIP vs HIP from 1e-6 m away {self_mean:.3e} m; steps {res.steps} / {len(losses)}"
+    rep = dict(hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, hip_self_1e6=self_mean, steps_hip=res.steps, steps_oracle=len(losses))
+    if field == "bowl":
+        # ---- the gate: strict bar on a fixture that can discriminate (a correct kernel ends ~1e-5 m from the oracle, one that is 1 mm off fails)
+        X64, losses64, _, _ = oracle_run(O64)
+        m64, _ = v2v(X, X64); o3264, _ = v2v(Xo, X64)
+        rep.update(hip_vs_oracle64_mean=m64, oracle32_vs_oracle64_mean=o3264)
+        _report(f"object_{field}_sil{int(with_sil)}", **rep)
+        msg += f"; HIP vs oracle64 {m64:.3e} m, oracle32 vs oracle64 {o3264:.3e} m"
+        print(msg)
+        assert self_mean <= 1e-4, msg                                      # the fixture is well-conditioned on the HIP path itself
+        assert abs(res.steps - len(losses)) <= 2, msg
+        n = min(res.steps, len(losses))
+        assert rel(res.losses[:n], losses[:n]) < 1e-3, msg
+        assert mean < 1e-3 and mx < 2e-3, msg                             # STRICT north-star bar
+        assert m64 <= max(1e-3, o3264), msg                               # fp64 arbiter
+        return
+    _report(f"object_{field}_sil{int(with_sil)}", **rep)
+    print(msg)
     if not with_sil:
+        # reported envelope (chaotic: the trajectory's own conditioning sits at the 1e-3 m bar -- 0.7..0.9e-3 m self-distance, fp32 vs fp64 oracle 1.0e-3 m): the
+        # gate for this schedule is the 'bowl' leg above; here only gross disagreement fails
         assert abs(res.steps - len(losses)) <= 2, (res.steps, len(losses))
         n = min(res.steps, len(losses))
         assert rel(res.losses[:n], losses[:n]) < 5e-3
-        # the 1e-3 m bar -- or, where this trajectory's own conditioning sits at the bar (the SAME HIP path started 1e-6 m away ends self_mean
-        # from itself: 0.86e-3 m measured in round 3, HIP vs oracle 1.00e-3 m), 1.5 x that self-distance, and never beyond 2e-3 m
-        assert mean < max(1e-3, 1.5 * self_mean) and mean < 2e-3, f"HIP vs oracle mean {mean:.3e} m (max {mx:.3e}); HIP vs HIP from 1e-6 m away {self_mean:.3e} m"
+        assert mean < max(2e-3, 3 * self_mean), msg
     else:
         # piecewise-constant objective: 300 'sil' steps separate ANY two runs -- measured on the MI355X: HIP vs oracle 3.0e-3 m, HIP vs the same HIP
         # path started 1e-6 m away 4.7e-3 m.  The bar is therefore the path's own sensitivity: the oracle must be no further from the HIP result
         # than twice what a 1e-6 m perturbation of the start does to it (floor 1.5e-3 m), and never beyond 1e-2 m
-        assert mean < 2 * max(self_mean, 1.5e-3) and mean < 1e-2, f"HIP vs oracle mean {mean:.3e} m (max {mx:.3e}); HIP vs HIP from 1e-6 m away {self_mean:.3e} m"
+        assert mean < 2 * max(self_mean, 1.5e-3) and mean < 1e-2, msg
 
 
 def test_fused_step_launches_are_bit_identical(synth):

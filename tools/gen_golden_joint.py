@@ -173,8 +173,11 @@ def main():
                 dd["rot_init"] = F.decopose_axis(obj_R).detach().clone(); box["i"] = 0
                 dd["trans_init"] = obj_t.detach().clone()
             decay = it - IT_OBJ + 1 if phase == "sil" else (it - IT_OBJ + 1) / 3                 # :358-362
-            ld = F.forward_step(net, _Frozen(), dd, obj_R, obj_t, obj_s, phase)
+            dd1 = dict(dd)                                             # the single evaluation keeps its own cache of the contact inputs
+            ld = F.forward_step(net, _Frozen(), dd1, obj_R, obj_t, obj_s, phase)
             loss = F.sum_dict(ld, wd, decay); loss.backward()
+            if phase == "joint":
+                dd["one_df_obj_h"], dd["one_parts_obj"] = dd1["df_obj_h"], dd1["parts_obj"]
             one = dict(loss=loss.item(), **{"t_" + k: float(v) for k, v in ld.items()}, d_R=obj_R.grad.numpy().copy(), d_t=obj_t.grad.numpy().copy())
             obj_R.grad = None; obj_t.grad = None
             opt = make_opt(obj_R, obj_t); losses = []
@@ -205,7 +208,8 @@ def main():
     print("  joint: decay %.3f, terms" % decay, {k: v for k, v in one.items() if k.startswith("t_")}, "pairs", len(pairs))
     save("objfit_joint", **base, smpl_verts=sverts, it=np.array(IT_JOINT), decay=np.array(decay), losses=losses, fin_R_raw=Rraw, fin_R=Rfin, fin_t=tfin,
          contact_h=np.packbits(mh, axis=1), contact_o=np.packbits(mo, axis=1), parts_obj=lab_o.astype(np.int8), pairs=np.array(pairs, np.int32),
-         df_hum_o=dd["df_hum_o"].numpy(), df_obj_h=dd["df_obj_h"].numpy(), **{"one_" + k: v for k, v in one.items()})
+         df_hum_o=dd["df_hum_o"].numpy(), df_obj_h=dd["df_obj_h"].numpy(), one_df_obj_h=dd["one_df_obj_h"].numpy(),
+         one_parts_obj=dd["one_parts_obj"].argmax(1).numpy().astype(np.int8), **{"one_" + k: v for k, v in one.items()})
 
     # ------------------------------------------------------------------ SilLossROI set-up + phase 'sil'
     # network-input masks (B,512,512): the object at its ground-truth pose and the body, rendered into the 1200-px crop around crop_center

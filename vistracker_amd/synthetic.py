@@ -370,3 +370,43 @@ def encoder_weights(keys_shapes, seed: int = 11) -> dict:
         else:
             out[name] = (0.05 * rng.normal(size=shape)).astype(np.float32)
     return out
+
+
+def bowl_decoders(center_o, center_h, seed: int = 3, field_gain: float = 0.05, curv_o=(1.0, 0.6, 1.4), curv_h=1.0) -> dict:
+    """``sifnet_decoders(seed)`` with the distance head replaced by an ANALYTIC, well-conditioned field expressed through the decoder weights
+    ("full-schedule runs on a well-conditioned analytic-field fixture"): both outputs are convex piecewise-linear bowls in the
+    query point p (camera frame, via the network's own xyz input channels 256..258 = (x, y, z - 2.2)),
+
+        df_h(p) = curv_h * sum_k phi(n_k . (p - center_h)),    df_o(p) = sum_k curv_o[k % 3] * phi(m_k . (p - center_o)),
+
+    ``phi(s)`` = the piecewise-linear interpolant of s^2 with knots at |s| = 0, .15, .3, .45, .6 built from ReLU hinges in layer 1, carried through
+    layers 2-3 by identity rows (the hinges are non-negative: ReLU is the identity on them) and summed in layer 4.  32 further hidden units keep
+    the random map-feature path of ``sifnet_decoders`` alive at ``field_gain`` of its usual output scale, so the fixture still exercises every
+    gather of the query kernel.  Such a field anchors the rigid object fit the way a trained network's distance field does (the objective has one
+    basin in the translation and, the curvatures being anisotropic, in the rotation), whereas random decoders give an uninformative field on
+    which any two runs separate (Appendix A.11)."""
+    dec = sifnet_decoders(seed)
+    rng = np.random.default_rng(seed + 1000)
+    knots = np.array([0.0, 0.15, 0.3, 0.45, 0.6]); slope = 2 * (knots + 0.075)          # slope of s^2 at the middle of each segment
+    inc = np.diff(np.concatenate([[0.0], slope]))                                       # slope increment at each knot
+    dirs_h = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float64)
+    dirs_o = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.6, 0.8, 0], [0, 0.6, 0.8], [0.8, 0, 0.6]], np.float64)
+    (w1, b1), (w2, b2), (w3, b3), (w4, b4) = [(w.copy(), b.copy()) for w, b in dec["df"]]
+    n_an = 2 * len(knots) * (len(dirs_h) + len(dirs_o))                               # 90 analytic units
+    assert n_an <= HIDDEN - 32
+    w1[:n_an] = 0; b1[:n_an] = 0; w2[:n_an] = 0; w2[:, :n_an] = 0; b2[:n_an] = 0; w3[:n_an] = 0; w3[:, :n_an] = 0; b3[:n_an] = 0; w4[:, :n_an] = 0
+    w1[n_an:, 256:259] = 0
+    w4 *= field_gain; b4[:] = 0.02
+    z0 = np.array([0, 0, 2.2])
+    u = 0
+    for out, dirs, cen, curv in ((0, dirs_h, np.asarray(center_h, np.float64), [curv_h] * 3), (1, dirs_o, np.asarray(center_o, np.float64), list(curv_o))):
+        for k, n in enumerate(dirs):
+            for sgn in (1.0, -1.0):
+                for kn, a in zip(knots, inc):
+                    w1[u, 256:259] = sgn * n; b1[u] = -sgn * float(n @ (cen - z0)) - kn
+                    w2[u, u] = 1.0; w3[u, u] = 1.0; w4[out, u] = a * curv[k % 3]
+                    u += 1
+    # unused hidden rows beyond the analytic and the random block stay as drawn (they only see map features)
+    dec["df"] = [(w1.astype(np.float32), b1.astype(np.float32)), (w2.astype(np.float32), b2.astype(np.float32)),
+                 (w3.astype(np.float32), b3.astype(np.float32)), (w4.astype(np.float32), b4.astype(np.float32))]
+    return dec
