@@ -42,14 +42,26 @@ FLOP_PER_POINT_HUMAN_MFMA = FLOP_PER_POINT_HUMAN - 4 * 2 * 256 * 128
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_query_human.json")   # rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+# bytes through the vector-memory (texture) path per query point of the SMPL-stage kernel, counted from the launch geometry (weights
+# 19.5 KB -- streamed per 64-point workgroup -- + tap gathers 11.3 KB + rows of the hoisted projection 8.0 KB), and the rate at which a CU's texture
+# path delivers 16-byte-per-lane loads whatever the pattern, from L1 and L2 alike (tools/bench_scripts/gather_patterns.hip: ~36 B / clock / CU)
+TA_BYTES_PER_POINT_HUMAN = 38.8e3
+TA_DELIVERY_PEAK_TBS = 22.0
+
+
+def pmc_file():
+    """the newest committed PMC summary of the SMPL-stage query kernel (profiles/rNN*_pmc_query_human.json: rocprofv3 --pmc passes over this same
+    command, tools/gpu_check.sh + tools/pmc_summary.py)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_query_human.json")))
+    return fs[-1] if fs else None
 
 
 def pmc_traffic_bytes():
     """HBM-side bytes per launch of the human query kernel from the committed PMC summary: FETCH_SIZE and WRITE_SIZE are in KB and
     come from separate passes; FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
     try:
-        d = json.load(open(PMC_FILE))
+        d = json.load(open(pmc_file()))
         return 1024.0 * (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"])
     except Exception:
         return None
@@ -60,7 +72,6 @@ def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0, seq=None):
     (a slice of syn.sequence_params); None = an independent 96-frame trajectory drawn from ``seed``."""
     import torch.nn.functional as F
     from vistracker_amd import ops
-    from vistracker_amd.fitting import SilSetup
     g = torch.Generator(device=dev); g.manual_seed(seed)
     rng = np.random.default_rng(seed)
     if seq is None:
@@ -95,17 +106,28 @@ def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0, seq=None):
     obj_t = (obj_t_gt + 0.05 * torch.randn(B, 3, device=dev, generator=g)).contiguous()
     obj_s = torch.ones(B, device=dev)
     occ = t(seq["occ_ratios"])
-    u0 = cam[0] * obj_t_gt[:, 0] / obj_t_gt[:, 2] + cam[2]; v0 = cam[1] * obj_t_gt[:, 1] / obj_t_gt[:, 2] + cam[3]
-    bb = 1.3 * cam[0] * 1.0 / obj_t_gt[:, 2]
-    K = torch.zeros(B, 9, device=dev)
-    K[:, 0] = cam[0] / bb; K[:, 2] = (cam[2] - (u0 - bb / 2)) / bb; K[:, 4] = cam[1] / bb; K[:, 5] = (cam[3] - (v0 - bb / 2)) / bb; K[:, 8] = 1
+    # network-input masks (channels 3, 4 of the batch's images, data/testdata_triplane.py:42-74): the object at its ground-truth pose and the body,
+    # rendered into the 1200-px crop around crop_center at 512 x 512.  SilLossROI's per-batch set-up (bbox -> square x 1.3 -> ROI crops -> keep mask
+    # -> ROI intrinsics) is built from them INSIDE the timed region (fit_batch), like the reference does (recon_fit_trivis_full.py:289-294)
+    Kc = torch.zeros(B, 9, device=dev)
+    Kc[:, 0] = cam[0] / cam[4]; Kc[:, 2] = (cam[2] - cc[:, 0] + cam[4] / 2) / cam[4]
+    Kc[:, 4] = cam[1] / cam[4]; Kc[:, 5] = (cam[3] - cc[:, 1] + cam[4] / 2) / cam[4]; Kc[:, 8] = 1
     with torch.no_grad():
         Vgt = ops.rigid_transform(ctx.obj_verts, ops.so3_project(obj_R_gt), obj_t_gt, obj_s)
-        ref = ops.silhouette(Vgt, ctx.obj_faces, K, 256)
-    keep = torch.ones_like(ref); keep[:, 96:160, :80] = 0
-    ref = ref * keep
+        mask_o = ops.silhouette(Vgt, ctx.obj_faces, Kc, 512)
+        mask_h = ops.silhouette(verts, ctx.smpl_faces, Kc, 512)
     return dict(pose=pose, betas=betas, trans=trans, cc=cc, bc=body_center, kp=kp, maps=fm, obj_R=obj_R, obj_t=obj_t, obj_s=obj_s,
-                occ=occ, sil=SilSetup(K, keep, ref, 256))
+                occ=occ, mask_h=mask_h, mask_o=mask_o)
+
+
+def sil_setup(ctx, d):
+    """SilLossROI's per-batch set-up from the network-input masks (recon/obj_pose_roi.py:39-75,111-181; called at the top of optimize_smpl_object,
+    recon_fit_trivis_full.py:289-294): part of the timed region"""
+    from vistracker_amd.silhouette import SilLossROI
+    if not hasattr(ctx, "obj_verts_np"):
+        ctx.obj_verts_np, ctx.obj_faces_np = ctx.obj_verts.cpu().numpy(), ctx.obj_faces.cpu().numpy()
+    return SilLossROI(d["mask_h"], d["mask_o"], (ctx.obj_verts_np, ctx.obj_faces_np), d["cc"], device=d["cc"].device, camera_params={}, crop_size=1200,
+                      net_input_size=512).setup()
 
 
 def fit_batch(ctx, torch, d, prof=None, early_stop=True):
@@ -114,7 +136,7 @@ def fit_batch(ctx, torch, d, prof=None, early_stop=True):
     r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof, early_stop=early_stop)
     with torch.no_grad():
         verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
-    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof,
+    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof,
                                   early_stop=early_stop)
     return r1, r2
 
@@ -142,6 +164,61 @@ def solo_kernel_leg(ctx, torch, d, launches=20):
         call(); ev[i + 1].record()
     torch.cuda.synchronize()
     return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
+
+
+def smplt_prefit_leg(ctx, torch, syn, T, bs=512):
+    """The SMPL-T pre-fit (preprocess/fit_SMPLH_30fps.py -bs 512, scripts/demo.sh:13; fit_SMPLH_kpts.py:114-180) of the same synthetic sequence as
+    its own line: batches of 512 consecutive frames, keypoints = projection of the ground-truth body25 joints + 2 px noise, start =
+    noisy ground truth, the reference's schedule and stop rule; batches one after the other on one stream."""
+    from vistracker_amd import ops, sharding
+    hands = np.concatenate([ctx.pri_np["lhand_mean"], ctx.pri_np["rhand_mean"]])
+    sp = syn.sequence_params(T, seed=7, grab_hand_mean=hands)
+    dev = ctx.device; rng = np.random.default_rng(11)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    jobs = []
+    for s_, e_ in sharding.batches_of(T, bs):
+        pose, betas, trans = t(sp["pose"][s_:e_]), t(sp["betas"][s_:e_]), t(sp["trans"][s_:e_])
+        with torch.no_grad():
+            J = ops.landmarks(ctx.b25, ops.smplh_forward(ctx.smpl, pose, betas, trans)[0])
+        cam = ctx.cam
+        kp = torch.stack([cam[0] * J[..., 0] / J[..., 2] + cam[2] + t(rng.normal(0, 2, J.shape[:2])), cam[1] * J[..., 1] / J[..., 2] + cam[3] + t(rng.normal(0, 2, J.shape[:2])),
+                          torch.ones(J.shape[:2], device=dev)], -1).contiguous()
+        p0 = pose.clone(); p0[:, :66] += t(rng.normal(0, 0.08, (e_ - s_, 66)))
+        jobs.append((p0, betas.clone(), (trans + t(rng.normal(0, 0.05, (e_ - s_, 3)))).contiguous(), kp))
+    ctx.fit_smplt(*[x.clone() for x in jobs[-1]], max_iter=2)        # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = [ctx.fit_smplt(*j) for j in jobs]
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return {"workload": f"SMPL-T pre-fit (fit_SMPLH_30fps schedule, stop rule on device) of the {T}-frame sequence in batches of {bs}", "frames_per_s": T / dt,
+            "seconds": dt, "adam_steps_per_batch": [r.steps for r in res], "frame_steps_per_s": sum((e_ - s_) * r.steps for (s_, e_), r in zip(sharding.batches_of(T, bs), res)) / dt}
+
+
+def strict_fp32_leg(ctx, torch, make, n_batches, streams=2):
+    """The headline workload on the STRICT-FP32 route (vt_maps::force_fp32: decoder GEMMs on v_mfma_f32_16x16x4_f32, exact fp32 products = the reference's
+    nn.Conv1d arithmetic; query_f32.hip): the first ``n_batches`` batches of the sequence, ``streams`` in flight, same schedules and stop rules."""
+    import threading
+    ds = [make(i) for i in range(n_batches)]
+    for d in ds:
+        d["maps"].set_force_fp32(True)
+    torch.cuda.synchronize()
+    ss = [torch.cuda.Stream(device=ctx.device) for _ in range(streams)]
+    results = [None] * len(ds)
+
+    def w(k):
+        torch.cuda.set_device(ctx.device)
+        with torch.cuda.stream(ss[k]):
+            for i in range(k, len(ds), streams):
+                results[i] = fit_batch(ctx, torch, ds[i])
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=w, args=(k,)) for k in range(streams)]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    frames = sum(int(d["pose"].shape[0]) for d in ds)
+    fs = sum(int(d["pose"].shape[0]) * (r[0].steps + r[1].steps) for d, r in zip(ds, results))
+    return {"workload": f"the first {n_batches} batches of the headline sequence on the strict-fp32 decoder kernels (exact fp32 products), {streams} in flight",
+            "frames_per_s": frames / dt, "seconds": dt, "frame_steps_per_s": fs / dt,
+            "adam_steps_smpl_stage": float(np.mean([r[0].steps for r in results])), "adam_steps_object_stage": float(np.mean([r[1].steps for r in results]))}
 
 
 def sifnet_inference_leg(torch, syn):
@@ -240,6 +317,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs after the timed region (kernel alone, full schedule, "
                                                               "SIF-Net inference = configs[3], demo pipeline = configs[4])")
     ap.add_argument("--pipeline-frames", type=int, default=1500)
+    ap.add_argument("--fp32-batches", type=int, default=8, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -270,7 +348,7 @@ def main():
     model = syn.smplh_model(0); regs = syn.landmark_regressors(model, 1); pri = syn.priors(2); dec = syn.sifnet_decoders(3)
     labels = syn.part_labels(model); ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, N_OBJ, seed=6)
     ctx = FitContext(model, regs, pri, dec, labels, ov, of, opts, device=dev)
-    ctx.pri_np = pri
+    ctx.pri_np = pri; ctx.obj_verts_np, ctx.obj_faces_np = ov, of
 
     from vistracker_amd import sharding
     strong = args.mode == "strong"
@@ -345,7 +423,7 @@ def main():
                 for i, d in enumerate(batches):
                     ready[i].wait()
                     r1, verts, ev = half[i]; so.wait_event(ev)
-                    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=d["sil"], seed=1, prof=prof)
+                    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof)
                     results[i] = (r1, r2)
                 so.synchronize()
 
@@ -413,6 +491,11 @@ def main():
         leg("full_schedule", full_schedule)
         del full96; batches.clear()
         torch.cuda.empty_cache()
+        if strong:
+            leg("smplt_prefit", lambda: smplt_prefit_leg(ctx, torch, syn, args.sequence))
+            if args.fp32_batches > 0:
+                leg("strict_fp32", lambda: strict_fp32_leg(ctx, torch, run, min(args.fp32_batches, len(seq_batches)), max(1, args.streams)))
+            torch.cuda.empty_cache()
         leg("sifnet_inference", lambda: sifnet_inference_leg(torch, syn))
         torch.cuda.empty_cache()
         leg("demo_pipeline", lambda: pipeline_leg(torch, args.pipeline_frames))
@@ -463,11 +546,11 @@ def main():
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
-                         "traffic": pmc_traffic_bytes(), "traffic_unit": "B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r03_pmc_query_human.json)",
+                         "traffic": pmc_traffic_bytes(), "traffic_unit": f"B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(pmc_file() or 'none')})",
                          "kernel": "query_kernel<2,MODE_HUMAN> (fused gather + df/parts decoders fwd+bwd)",
                          "avg_launch_ms": 1e3 * float(th.mean()), "effective_ms_per_launch": 1e3 * eff, "streams": args.streams,
                          # the kernel alone on the chip (20 back-to-back launches on one stream after the timed region): the number a single-stream
-                         # rocprofv3 kernel trace reports (profiles/r03_kernel_stats_1stream.csv)
+                         # rocprofv3 kernel trace reports (profiles/rNN_kernel_stats_1stream.csv)
                          "solo_launch_ms": None if solo is None else 1e3 * solo,
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
                          "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "
@@ -478,15 +561,17 @@ def main():
                          "hoisting_note": "the im_feat part of layer 1 (42 % of its FLOPs, 30 % of the kernel's) is hoisted out of the Adam loop: applied to "
                                           "the texels once per batch (fp32 MFMA GEMM inside the timed region, 0.2 TFLOP / 2.5 ms per batch) and blended per "
                                           "point on the VALU; frac counts algorithmic FLOPs, frac_mfma_executed only what the MFMA pipe still executes",
-                         # the other roof of this kernel, for information: SURVEY.md 8(d) counts 608 ch x 4 taps x 4 B = 9728 B/pt "touched" in each
-                         # direction (an upper bound: neighbouring points share texels, the caches serve them; "traffic" above is what reaches HBM)
-                         "gather": {"algorithmic_bytes_per_launch": 2 * 9728 * BATCH * 6890, "unit": "TB/s", "peak": 8.0,
-                                    "achieved": ach / FLOP_PER_POINT_HUMAN * 2 * 9728, "frac": ach / FLOP_PER_POINT_HUMAN * 2 * 9728 / 8.0,
-                                    "note": "bytes the gathers request (touched, not unique) / launch time vs the HBM peak; the L2 / MALL serve ~70 % of them"},
+                         # the resource the kernel family is closest to: bytes through the CUs' vector-memory (texture) path -- weights streamed
+                         # per 64-point workgroup + tap gathers + rows of the hoisted projection, counted from the launch geometry -- against the rate at
+                         # which that path delivers 16-byte-per-lane loads from L1 / L2 (measured, gather_patterns.hip); NOT an HBM figure ("traffic" is)
+                         "vector_memory_delivery": {"bytes_per_point": TA_BYTES_PER_POINT_HUMAN, "bytes_per_launch": TA_BYTES_PER_POINT_HUMAN * BATCH * 6890, "unit": "TB/s",
+                                                    "peak": TA_DELIVERY_PEAK_TBS, "achieved": ach / FLOP_PER_POINT_HUMAN * TA_BYTES_PER_POINT_HUMAN,
+                                                    "frac": ach / FLOP_PER_POINT_HUMAN * TA_BYTES_PER_POINT_HUMAN / TA_DELIVERY_PEAK_TBS,
+                                                    "note": "texture-path bytes per launch / launch time vs the measured delivery rate of the path (~36 B / clock / CU)"},
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * N_OBJ * float(fo.sum()) / max(to.sum(), 1e-12) / 1e12},
         }
-        for k in ("full_schedule", "sifnet_inference", "demo_pipeline"):
+        for k in ("full_schedule", "smplt_prefit", "strict_fp32", "sifnet_inference", "demo_pipeline"):
             if k in extras:
                 line[k] = extras[k]
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)

@@ -199,7 +199,7 @@ int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, int in_cstrid
 int vt_conv3x3_tiles(int H, int W);
 /* The 1 x 1 convolutions of the same encoders (conv_last / l / bl / al of a stack, the ConvBlock's down-sampling projection: model/HGFilters.py:150-203,
  * model/net_util.py:364-372) on the same split-f16 kernel (one tap, the 8 x 16 tile as the patch).  weight (Cout, Cin) fp32 host, bias (Cout) or NULL,
- * Cout in {64, 128, 256} (256 runs as two launches of 128), Cin a multiple of 32.  forward: out <- conv(in) + bias [+ res]; gn_stats != NULL applies
+ * Cout in {64, 128, 256} (256 runs as two launches of 128), Cin in {32, 64, 128, 256}.  forward: out <- conv(in) + bias [+ res]; gn_stats != NULL applies
  * max((x - mean) rstd gamma + beta, 0) to the input while it is staged (the GroupNorm -> ReLU in front of l / bl / the projection); stats_ws != NULL
  * leaves the GroupNorm partial sums of conv(in) + bias behind like vt_conv3x3_forward_gn_stats (finalize with C = Cout). */
 typedef struct vt_conv1x1 vt_conv1x1;
@@ -368,6 +368,14 @@ long vt_chamfer_ws_bytes(long total_x, long total_y, int P);
 int vt_chamfer_ragged_ws(const float *x, const int *offx, long total_x, const float *y, const int *offy, long total_y, int P, float gscale,
                          double *term, float *dx, float *dy, void *ws, void *stream);
 
+/* The same with the y clouds taken THROUGH AN INDEX LIST out of one big array (the contact term of phase 'joint', recon_fit_trivis_full.py:393-457: the
+ * object-side contact points are rows idx_y[r] of the transformed surface samples (B * N, 3) of the batch): y row r = y_base[idx_y[r]], and the gradient of
+ * row r is ADDED to dy_base[idx_y[r]] -- the additions of "index_select, vt_chamfer_ragged_ws on the compact list, index_add_" in their order (bit-identical
+ * results), without the three gather / zero / scatter launches around it.  idx_y must not repeat a row (a surface point belongs to one (frame, part) pair).
+ * run_plan = 0 reuses the work-item plan a previous call left in ws for the SAME offx / offy (the contact set is computed once per batch). */
+int vt_chamfer_ragged_idx(const float *x, const int *offx, long total_x, const float *y_base, const int *idx_y, const int *offy, long total_y, int P,
+                          float gscale, double *term, float *dy_base, void *ws, int run_plan, void *stream);
+
 /* Evaluation Chamfer, one direction (recon/eval/chamfer_distance.py:10-52, sklearn NearestNeighbors(k=1, metric='l2')): for each of
  * the nq points of cloud pair p the Euclidean distance to the nearest of the ns points of `search`; query (P,nq,3), search (P,ns,3),
  * dist (P,nq).  The bidirectional Chamfer of the reference is mean(dist(x->y)) + mean(dist(y->x)). */
@@ -445,7 +453,9 @@ int vt_fill(float *p, long n, float value, void *stream);
 /* Device-side early stop.  The fits evaluate their stop rules on the device (the reference breaks out of its inner loop on the host:
  * recon_fit_behave.py:447, recon_fit_trivis_full.py:372, fit_SMPLH_kpts.py:161) and the host reads the flag once per outer iteration of 10 steps; with
  * `flag` registered for `stream` the query and SMPL-H launches queued behind the stopping step return at once when *flag != 0 (the Adam / loss-history
- * launches ignore those steps already).  flag = NULL removes the registration; the owner must remove it before the flag's memory is released. */
+ * launches ignore those steps already).  flag = NULL removes the registration; the owner must remove it before the flag's memory is released.
+ * The registration belongs to the CALLING HOST THREAD: only launches issued by that thread on `stream` see the flag (two fits driven by two threads
+ * through one stream do not interfere); registering a second, different flag for the same stream from the same thread is an error (VT_ERR_ARG). */
 int vt_stream_set_skip_flag(void *stream, const int *flag);
 
 #ifdef __cplusplus

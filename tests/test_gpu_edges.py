@@ -323,6 +323,45 @@ def test_concurrent_fits_through_one_handle_with_an_overflowing_batch(synth):
     assert ctx.net.precision == "split-f16"
 
 
+def test_two_fits_from_two_threads_on_one_stream_keep_their_own_stop_flags(synth):
+    """the device-side skip flag of a fit (vt_stream_set_skip_flag) used to live in a process-global table keyed by (device, stream):
+    two fits driven by two host threads through the SAME stream overwrote / deleted each other's entry, and the one that stopped first made the other's
+    query kernels return at once while its Adam tail kept stepping on stale gradients.  The registration is per host thread now: a fit that stops early
+    (max_iter = 4) and one that runs on, both on the default stream, end bit-identical to the same fits run one after the other."""
+    import threading
+    from conftest import golden
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext
+    g = golden("smplfit")
+    ctx = FitContext(synth["model"], synth["regs"], synth["priors"], synth["decoders"], synth["labels"], np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32),
+                     np.zeros((8, 3), np.float32))
+    mp = syn.feature_maps(4, int(g["maps_seed"]), res_scale=float(g["res_scale"]))
+
+    def fit(max_iter, it_range):
+        maps = ops.FeatureMaps.from_nchw(mp)
+        pose, betas, trans = cu(g["pose"]), cu(g["betas"]), cu(g["trans"])
+        res = ctx.optimize_smpl(maps, pose, betas, trans, cu(g["crop_center"]), cu(g["body_center"]), cu(g["body_kpts"]), max_iter=max_iter, it_range=it_range)
+        return pose, trans, res.steps, res.stopped_early, res.losses.copy()
+    seq = [fit(4, None), fit(100, (0, 9))]
+    assert seq[0][3] and not seq[1][3] and seq[1][2] == 90                  # the first stops early (inside an outer iteration), the second does not
+    out = [None, None]; errs = []
+
+    def worker(k, a):
+        try:
+            torch.cuda.set_device(0)
+            out[k] = fit(*a)                                                # both on the default stream
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(0, (4, None))), threading.Thread(target=worker, args=(1, (100, (0, 9))))]
+    for t_ in th: t_.start()
+    for t_ in th: t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for a, b in zip(seq, out):
+        fa, fb = np.isfinite(a[4]), np.isfinite(b[4])
+        assert a[2] == b[2] and a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(fa, fb) and np.array_equal(a[4][fa], b[4][fb])
+
+
 def _collision_case(synth, B=3, seed=4):
     """an object template pushed half-way into the SMPL body of every frame"""
     from oracle import oracle as O

@@ -347,6 +347,19 @@ def test_chamfer_ragged_split_over_workgroups(hip):
     _, dxa, dya = run(True, want_dx=False); assert not dxa.any() and np.array_equal(dya, dy1)
     _, dxb, dyb = run(True, want_dy=False); assert not dyb.any() and np.array_equal(dxb, dx1)
 
+    # ---- the indexed form (vt_chamfer_ragged_idx): the y clouds are rows idx[r] of one big array, their gradient is ADDED into the big gradient array:
+    #      bit-identical to index_select -> vt_chamfer_ragged_ws -> index_add_ (what a 'joint' step did around the launch before), plan reused by a second call
+    NB = 9000
+    idx = rng.permutation(NB)[: y.shape[0]].astype(np.int32)
+    Ybig = torch.full((NB, 3), 7.0, device="cuda"); Ybig[cu(idx).long()] = y
+    G0 = cu(rng.normal(0, 1e-3, (NB, 3)).astype(np.float32))
+    ref = G0.clone(); ref.index_add_(0, cu(idx).long(), cu(dya))
+    for k in range(2):
+        term = torch.zeros(1, dtype=torch.float64, device="cuda"); G = G0.clone()
+        L.check(lib.vt_chamfer_ragged_idx(x.data_ptr(), ox.data_ptr(), x.shape[0], Ybig.data_ptr(), cu(idx).data_ptr(), oy.data_ptr(), y.shape[0], P, 1.0, term.data_ptr(),
+                                          G.data_ptr(), ws.data_ptr(), int(k == 0), L.stream_ptr()))
+        assert float(term.item()) == v1 and torch.equal(G, ref), (k, float(term.item()), v1, float((G - ref).abs().max()))
+
 
 def _sil_case(B=3, seed=8):
     from vistracker_amd import synthetic as syn

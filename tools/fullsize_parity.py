@@ -80,7 +80,8 @@ def main():
     verts0 = ops.smplh_forward(ctx.smpl, p, b_, t)[0].contiguous()
     v0 = verts0[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
     th = torch.zeros(2, dtype=torch.float64, device="cuda"); dp = torch.empty(B, 6890, 3, device="cuda")
-    L.check(L.lib().vt_query_human_loss(ctx.net.h, C.byref(fm.c), L.dptr(verts0), L.dptr(cu(cc)), L.dptr(cu(bc)), B, 6890, L.dptr(ctx.labels), L.dptr(order), 100.0, 0.0025,
+    cc_d, bc_d = cu(cc), cu(bc)            # (named: a temporary freed inside the argument list hands its block to the next temporary)
+    L.check(L.lib().vt_query_human_loss(ctx.net.h, C.byref(fm.c), L.dptr(verts0), L.dptr(cc_d), L.dptr(bc_d), B, 6890, L.dptr(ctx.labels), L.dptr(order), 100.0, 0.0025,
                                         L.dptr(dp), L.dptr(th), L.stream_ptr()))
     net = O.SifNet(dec, mp)
     vs = verts0.cpu().numpy()

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vt_chamfer_ragged": (ci, [fp, fp, fp, fp, ci, cf, fp, fp, fp, vp]),
     "vt_chamfer_ws_bytes": (C.c_long, [C.c_long, C.c_long, ci]),
     "vt_chamfer_ragged_ws": (ci, [fp, fp, C.c_long, fp, fp, C.c_long, ci, cf, fp, fp, fp, fp, vp]),
+    "vt_chamfer_ragged_idx": (ci, [fp, fp, C.c_long, fp, fp, fp, C.c_long, ci, cf, fp, fp, fp, ci, vp]),
     "vt_collision_workspace_bytes": (cl, [ci, ci]),
     "vt_collision_loss": (ci, [fp, ci, fp, ci, fp, ci, fp, ci, ci, cf, ci, cf, fp, fp, fp, fp, vp]),
     "vt_nn_distance": (ci, [fp, ci, fp, ci, ci, fp, vp]),

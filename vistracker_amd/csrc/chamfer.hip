@@ -150,8 +150,12 @@ __device__ __forceinline__ int chs_find(const int *__restrict__ pre, int P, int 
 __global__ __launch_bounds__(CHS_BLK) void chamfer_nn_kernel(const float *__restrict__ x, const int *__restrict__ offx, const float *__restrict__ y,
                                                              const int *__restrict__ offy, int P, const int *__restrict__ pre1, const int *__restrict__ pre2, float gs,
                                                              double *term, float *dx, float *dy, int *__restrict__ nn1, float *__restrict__ g1,
-                                                             int *__restrict__ nn2, float *__restrict__ g2, double *__restrict__ part, const int *skip)
+                                                             int *__restrict__ nn2, float *__restrict__ g2, double *__restrict__ part, const int *skip,
+                                                             const int *__restrict__ idy)
 {
+    // ``idy`` (vt_chamfer_ragged_idx): row r of the y list is row idy[r] of the array ``y`` points at (the transformed surface samples of the whole batch),
+    // and ``dy`` is a compact scratch list this launch WRITES (row r = the near-side gradient of y row r, zero where it has none); the far launch adds
+    // row r (minus the far-side records) into the big gradient array.  Without it y / dy are the compact lists themselves, dy is accumulated into.
     VT_SKIP_RETURN(skip);
     __shared__ float4 sB4[CH_CHUNK];
     __shared__ double red[CHS_BLK / 64];
@@ -163,19 +167,26 @@ __global__ __launch_bounds__(CHS_BLK) void chamfer_nn_kernel(const float *__rest
     const int p = chs_find(pre, P, it), blk = it - pre[p];
     const int ox = offx[p], nx = offx[p + 1] - ox, oy = offy[p], ny = offy[p + 1] - oy;
     // direction 1: near = x, far = y (records nn1 / g1 indexed by the GLOBAL x row); direction 2: near = y, far = x
-    const float *a = d1 ? x + 3 * (size_t)ox : y + 3 * (size_t)oy, *bp = d1 ? y + 3 * (size_t)oy : x + 3 * (size_t)ox;
     const int na = d1 ? nx : ny, nb = d1 ? ny : nx, arow = (d1 ? ox : oy);
+    // rows of the near (a) and far (bp) cloud: the x list is always compact, the y list goes through idy when given
+    const bool ia = idy && !d1, ib = idy && d1;
+    const int *ida = idy + oy;          // (only dereferenced when ia / ib)
+#define CH_AROW(i_) ((ia ? y + 3 * (size_t)ida[i_] : (d1 ? x + 3 * ((size_t)ox + (i_)) : y + 3 * ((size_t)oy + (i_)))))
+#define CH_BROW(j_) ((ib ? y + 3 * (size_t)ida[j_] : (d1 ? y + 3 * ((size_t)oy + (j_)) : x + 3 * ((size_t)ox + (j_)))))
     float *ga = d1 ? dx : dy; const bool want_far = d1 ? dy != nullptr : dx != nullptr;
     int *nn = d1 ? nn1 : nn2; float *gr = d1 ? g1 : g2;
     const int sub = threadIdx.x & 3, i = blk * CHS_PTS + (threadIdx.x >> 2);       // four adjacent lanes scan a quarter of the far cloud each for point i
     float ax = 0.f, ay = 0.f, az = 0.f;
-    if (i < na) { ax = a[3 * i]; ay = a[3 * i + 1]; az = a[3 * i + 2]; }
+    if (i < na) { const float *a = CH_AROW(i); ax = a[0]; ay = a[1]; az = a[2]; }
     float best = INFINITY; int bj = 0x7fffffff;
     for (int c0 = 0; c0 < nb; c0 += CH_CHUNK) {
         const int cn = min(CH_CHUNK, nb - c0);
         __syncthreads();
-        for (int t = threadIdx.x; t < ((cn + 15) & ~15); t += CHS_BLK)
-            sB4[t] = t < cn ? make_float4(bp[3 * (c0 + t)], bp[3 * (c0 + t) + 1], bp[3 * (c0 + t) + 2], 0.f) : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        for (int t = threadIdx.x; t < ((cn + 15) & ~15); t += CHS_BLK) {
+            float4 v = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            if (t < cn) { const float *bq = CH_BROW(c0 + t); v = make_float4(bq[0], bq[1], bq[2], 0.f); }
+            sB4[t] = v;
+        }
         __syncthreads();
         if (i < na) for (int j = 4 * sub; j < cn; j += 16) {
             float dd[4];
@@ -201,9 +212,12 @@ __global__ __launch_bounds__(CHS_BLK) void chamfer_nn_kernel(const float *__rest
     float g0 = 0.f, g1v = 0.f, g2v = 0.f;
     if (live) {
         acc = (double)best / (double)na;
-        if (ga || want_far) { g0 = 2.f * (ax - bp[3 * bj]) * gs / na; g1v = 2.f * (ay - bp[3 * bj + 1]) * gs / na; g2v = 2.f * (az - bp[3 * bj + 2]) * gs / na; }
-        if (ga) { float *o = ga + 3 * ((size_t)arow + i); o[0] += g0; o[1] += g1v; o[2] += g2v; }
+        if (ga || want_far) { const float *bq = CH_BROW(bj); g0 = 2.f * (ax - bq[0]) * gs / na; g1v = 2.f * (ay - bq[1]) * gs / na; g2v = 2.f * (az - bq[2]) * gs / na; }
+        if (ga && !ia) { float *o = ga + 3 * ((size_t)arow + i); o[0] += g0; o[1] += g1v; o[2] += g2v; }
     }
+    if (ga && ia && own && i < na) { float *o = ga + 3 * ((size_t)arow + i); o[0] = g0; o[1] = g1v; o[2] = g2v; }      // compact scratch row: written, 0 + g == g
+#undef CH_AROW
+#undef CH_BROW
     if (want_far && own && i < na) { nn[arow + i] = live ? bj : -1; float *o = gr + 3 * ((size_t)arow + i); o[0] = g0; o[1] = g1v; o[2] = g2v; }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -216,7 +230,8 @@ __global__ __launch_bounds__(CHS_BLK) void chamfer_nn_kernel(const float *__rest
 __global__ __launch_bounds__(CHS_BLK) void chamfer_far_kernel(const int *__restrict__ offx, const int *__restrict__ offy, int P, const int *__restrict__ pre1,
                                                               const int *__restrict__ pre2, float *dx, float *dy, const int *__restrict__ nn1,
                                                               const float *__restrict__ g1, const int *__restrict__ nn2, const float *__restrict__ g2,
-                                                              const double *__restrict__ part, double *term, const int *skip)
+                                                              const double *__restrict__ part, double *term, const int *skip,
+                                                              const int *__restrict__ idy, float *__restrict__ dy_base)
 {
     VT_SKIP_RETURN(skip);
     __shared__ __attribute__((aligned(16))) int sNN[CH_CHUNK];
@@ -271,35 +286,62 @@ __global__ __launch_bounds__(CHS_BLK) void chamfer_far_kernel(const int *__restr
         s0 += __shfl_xor(s0, o, 64); s1v += __shfl_xor(s1v, o, 64); s2 += __shfl_xor(s2, o, 64);
         any = any | (__shfl_xor((int)any, o, 64) != 0);
     }
+    if (s1 && idy) {
+        // y rows through the index list: the row's near-side gradient g (compact scratch, written by the first launch) minus its far-side records is ADDED
+        // to row idy[r] of the big gradient array: dX + ((0 + g) - s), the additions of "gather, Chamfer on the compact list, index_add_" in their order.
+        // A surface point belongs to one (frame, part) pair: one writer per row.
+        if (sub == 0 && j < nfar) {
+            const float *gq = gb + 3 * ((size_t)frow + j); float *o = dy_base + 3 * (size_t)idy[frow + j];
+            float v0 = gq[0], v1 = gq[1], v2 = gq[2];
+            if (any) { v0 -= s0; v1 -= s1v; v2 -= s2; }
+            o[0] += v0; o[1] += v1; o[2] += v2;
+        }
+        return;
+    }
     if (any && sub == 0 && j < nfar) { float *o = gb + 3 * ((size_t)frow + j); o[0] -= s0; o[1] -= s1v; o[2] -= s2; }
 }
 extern "C" long vt_chamfer_ws_bytes(long total_x, long total_y, int P)
 {
     if (total_x < 0 || total_y < 0 || P <= 0) return 0;
     const long items = total_x / CHS_PTS + total_y / CHS_PTS + 2 * (long)P;        // upper bound of the work items of the first launch
-    return (long)sizeof(int) * 2 * ((long)P + 1) + (long)(sizeof(int) + 3 * sizeof(float)) * (total_x + total_y) + 8 + (long)sizeof(double) * items + 64;
+    return (long)sizeof(int) * 2 * ((long)P + 1) + (long)(sizeof(int) + 3 * sizeof(float)) * (total_x + total_y) + 8 + (long)sizeof(double) * items + 64
+           + (long)(3 * sizeof(float)) * total_y + 16;        // + the compact near-side gradient list of vt_chamfer_ragged_idx
+}
+static int chamfer_ws_launch(const float *x, const int *offx, long total_x, const float *y, const int *idy, const int *offy, long total_y, int P, float gscale,
+                             double *term, float *dx, float *dy, void *ws, int run_plan, hipStream_t st)
+{
+    const int *skip = vt_skip_flag_of(st);
+    int *pre1 = reinterpret_cast<int *>(ws), *pre2 = pre1 + (P + 1);
+    int *nn1 = pre2 + (P + 1), *nn2 = nn1 + total_x;
+    float *g1 = reinterpret_cast<float *>(nn2 + total_y), *g2 = g1 + 3 * total_x;
+    double *part = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(g2 + 3 * total_y) + 7) & ~(uintptr_t)7);
+    const long m1 = total_x / CHS_PTS + P, m2 = total_y / CHS_PTS + P;      // upper bounds of the item counts (the exact ones are pre1[P], pre2[P] on the device)
+    float *dyc = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(part + (m1 + m2)) + 15) & ~(uintptr_t)15);       // compact dy list of the indexed form
+    if (run_plan) {
+        hipLaunchKernelGGL(chamfer_plan_kernel, dim3(1), dim3(1024), 0, st, offx, offy, P, pre1, pre2);
+        VT_LAUNCH_CHECK();
+    }
+    float *dy_list = idy ? (dy ? dyc : nullptr) : dy;
+    hipLaunchKernelGGL(chamfer_nn_kernel, dim3((unsigned)(m1 + m2)), dim3(CHS_BLK), 0, st, x, offx, y, offy, P, pre1, pre2, gscale / (float)P, term, dx, dy_list,
+                       nn1, g1, nn2, g2, part, skip, idy);
+    VT_LAUNCH_CHECK();
+    // far-side gradients (if any are wanted) + one more workgroup that reduces the items' shares of the term
+    hipLaunchKernelGGL(chamfer_far_kernel, dim3((unsigned)((dy ? m2 : 0) + (dx ? m1 : 0) + 1)), dim3(CHS_BLK), 0, st, offx, offy, P, pre1, pre2, dx, dy_list, nn1, g1, nn2, g2,
+                       part, term, skip, idy, dy);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
 }
 extern "C" int vt_chamfer_ragged_ws(const float *x, const int *offx, long total_x, const float *y, const int *offy, long total_y, int P, float gscale,
                                     double *term, float *dx, float *dy, void *ws, void *stream)
 {
     VT_REQUIRE(x && offx && y && offy && ws && P > 0 && P <= 1024 * 1024 && total_x >= 0 && total_y >= 0, "vt_chamfer_ragged_ws: bad argument");
-    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
-    int *pre1 = reinterpret_cast<int *>(ws), *pre2 = pre1 + (P + 1);
-    int *nn1 = pre2 + (P + 1), *nn2 = nn1 + total_x;
-    float *g1 = reinterpret_cast<float *>(nn2 + total_y), *g2 = g1 + 3 * total_x;
-    double *part = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(g2 + 3 * total_y) + 7) & ~(uintptr_t)7);
-    hipLaunchKernelGGL(chamfer_plan_kernel, dim3(1), dim3(1024), 0, st, offx, offy, P, pre1, pre2);
-    VT_LAUNCH_CHECK();
-    // upper bounds of the item counts (the exact ones are pre1[P], pre2[P] on the device): ceil(n / 64) <= n / 64 + 1 per pair
-    const long m1 = total_x / CHS_PTS + P, m2 = total_y / CHS_PTS + P;
-    hipLaunchKernelGGL(chamfer_nn_kernel, dim3((unsigned)(m1 + m2)), dim3(CHS_BLK), 0, st, x, offx, y, offy, P, pre1, pre2, gscale / (float)P, term, dx, dy,
-                       nn1, g1, nn2, g2, part, skip);
-    VT_LAUNCH_CHECK();
-    // far-side gradients (if any are wanted) + one more workgroup that reduces the items' shares of the term
-    hipLaunchKernelGGL(chamfer_far_kernel, dim3((unsigned)((dy ? m2 : 0) + (dx ? m1 : 0) + 1)), dim3(CHS_BLK), 0, st, offx, offy, P, pre1, pre2, dx, dy, nn1, g1, nn2, g2,
-                       part, term, skip);
-    VT_LAUNCH_CHECK();
-    return VT_OK;
+    return chamfer_ws_launch(x, offx, total_x, y, nullptr, offy, total_y, P, gscale, term, dx, dy, ws, 1, vt_stream(stream));
+}
+extern "C" int vt_chamfer_ragged_idx(const float *x, const int *offx, long total_x, const float *y_base, const int *idx_y, const int *offy, long total_y, int P,
+                                     float gscale, double *term, float *dy_base, void *ws, int run_plan, void *stream)
+{
+    VT_REQUIRE(x && offx && y_base && idx_y && offy && ws && P > 0 && P <= 1024 * 1024 && total_x >= 0 && total_y >= 0, "vt_chamfer_ragged_idx: bad argument");
+    return chamfer_ws_launch(x, offx, total_x, y_base, idx_y, offy, total_y, P, gscale, term, nullptr, dy_base, ws, run_plan, vt_stream(stream));
 }
 
 // ---- evaluation Chamfer (recon/eval/chamfer_distance.py:10-52): per point the Euclidean (NOT squared) distance to the nearest

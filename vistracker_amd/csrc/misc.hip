@@ -1000,6 +1000,10 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
     __shared__ float red12[4][12];
     const int b = blockIdx.x, B = gridDim.x;
     const bool stopped = end.stop_flag && *end.stop_flag;          // read before any workgroup can close the step
+    // phase 'joint' optimises obj_t only (recon_fit_trivis_full.py:343-347: optim.Adam([obj_t], lr=0.002)): the rotation half of the rigid VJP (nine of
+    // the twelve sums over the points) and the SO(3) VJP with its second Jacobi SVD feed nothing -- skipped when no rotation slice is optimised
+    // (dR / dM are then left untouched; obj_t takes the same three sums in the same order: bit-identical parameters)
+    const bool rot = aR.p != nullptr;
     const float sc = s[b];
     float tot[12];
 #pragma unroll
@@ -1013,8 +1017,13 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
         for (int e = 0; e < 12; e++) a[e] = 0.f;
         for (int n = threadIdx.x; n < n_; n += 256) {
             const float *x = X0 + (size_t)n * 3, *g = dX + ((size_t)b * n_ + n) * 3;
+            if (rot) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
+                for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) a[9 + c] += g[c] * sc;
+            }
         }
         // the twelve block sums of rigid_bwd_kernel (wave tree, then the four waves in order: the same additions) with ONE barrier pair instead of twelve
 #pragma unroll
@@ -1051,6 +1060,9 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
             for (int c = 0; c < 3; c++) { const float d = tpar[3 * b + c] - t_init[3 * b + c]; acc += (double)(d * d); }
             atomicAdd(term_trans, acc * (double)inv_denom);        // the frame's share of the term
         }
+#pragma unroll
+        for (int c = 0; c < 3; c++) dt[3 * b + c] = g[9 + c];
+        if (rot) {
         // SO(3) VJP (so3_bwd_kernel)
         float M[9], G[9]; Svd3 sv;
 #pragma unroll
@@ -1080,8 +1092,7 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
             for (int c = 0; c < 3; c++) { const float v = UDZ[3 * r] * sv.V[3 * c] + UDZ[3 * r + 1] * sv.V[3 * c + 1] + UDZ[3 * r + 2] * sv.V[3 * c + 2]; dM[9 * b + 3 * r + c] = v; }
 #pragma unroll
         for (int e = 0; e < 9; e++) dR[9 * b + e] = g[e];
-#pragma unroll
-        for (int c = 0; c < 3; c++) dt[3 * b + c] = g[9 + c];
+        }
     }
     __syncthreads();
     if (!stopped) {
@@ -1243,30 +1254,31 @@ extern "C" int vt_kpts_step(const vt_landmarks *h, const float *verts, const flo
 // The stop rules of the fits are evaluated on the device (vt_loss_reduce_and_stop / the step tails) and the host looks at the flag once per outer
 // iteration of 10 steps, so up to 9 steps are already queued behind the step that stopped the fit.  Adam and the loss history ignore them; with the
 // flag registered for the stream the query and SMPL-H kernels of those steps return at their first instruction as well (results unchanged: the
-// reference breaks out of its loop at that step, recon_fit_behave.py:447).  One entry per stream, set / cleared by the fit that owns the flag.
-#include <mutex>
+// reference breaks out of its loop at that step, recon_fit_behave.py:447).  The registry is PER HOST THREAD (thread_local), keyed by (device, stream):
+// a fit registers its flag from the thread that issues its launches and only that thread's launches see it -- two fits driven by two threads
+// through the SAME stream (e.g. both on the default stream) can neither pick up nor delete each other's flag.
 #include <vector>
-static std::mutex g_skip_mu;
 struct SkipEntry { int dev; hipStream_t st; const int *flag; };
-static std::vector<SkipEntry> g_skip_tab;       // keyed by (device, stream): the default stream is the same handle on every device
+static thread_local std::vector<SkipEntry> t_skip_tab;       // (the default stream is the same handle on every device: the device is part of the key)
 static int skip_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 const int *vt_skip_flag_of(hipStream_t st)
 {
-    std::lock_guard<std::mutex> lk(g_skip_mu);
-    if (g_skip_tab.empty()) return nullptr;
+    if (t_skip_tab.empty()) return nullptr;
     const int dev = skip_device();
-    for (const auto &e : g_skip_tab) if (e.st == st && e.dev == dev) return e.flag;
+    for (const auto &e : t_skip_tab) if (e.st == st && e.dev == dev) return e.flag;
     return nullptr;
 }
 extern "C" int vt_stream_set_skip_flag(void *stream, const int *flag)
 {
-    std::lock_guard<std::mutex> lk(g_skip_mu);
     const hipStream_t st = vt_stream(stream); const int dev = skip_device();
-    for (size_t i = 0; i < g_skip_tab.size(); i++)
-        if (g_skip_tab[i].st == st && g_skip_tab[i].dev == dev) {
-            if (flag) g_skip_tab[i].flag = flag; else { g_skip_tab[i] = g_skip_tab.back(); g_skip_tab.pop_back(); }
+    for (size_t i = 0; i < t_skip_tab.size(); i++)
+        if (t_skip_tab[i].st == st && t_skip_tab[i].dev == dev) {
+            // a second fit of THIS thread on the stream while the first one's flag is still registered (nested / leaked registration): refuse instead of
+            // redirecting the first fit's launches to another flag
+            VT_REQUIRE(!flag || t_skip_tab[i].flag == flag, "vt_stream_set_skip_flag: another stop flag is already registered for this stream by this thread");
+            if (!flag) { t_skip_tab[i] = t_skip_tab.back(); t_skip_tab.pop_back(); }
             return VT_OK;
         }
-    if (flag) g_skip_tab.push_back({dev, st, flag});
+    if (flag) t_skip_tab.push_back({dev, st, flag});
     return VT_OK;
 }

@@ -147,7 +147,7 @@ class HGFilterEncoder:
 
     def _hip_conv1x1_ok(self, wname, H, W, cuda):
         cout, cin = self.sd[wname].shape[:2]
-        return self.use_hip_conv and cuda and cout in (64, 128, 256) and cin % 32 == 0 and H % 8 == 0 and W % 16 == 0 and tuple(self.sd[wname].shape[2:]) == (1, 1)
+        return self.use_hip_conv and cuda and cout in (64, 128, 256) and cin in (32, 64, 128, 256) and H % 8 == 0 and W % 16 == 0 and tuple(self.sd[wname].shape[2:]) == (1, 1)
 
     def _conv1x1(self, x, wname, bname=None, gn=None, res=None, want_stats=False):
         """1 x 1 convolution (+ bias) of a channels-last tensor on the split-f16 kernel (vt_conv1x1_forward).  ``gn`` = (stats workspace, norm name):

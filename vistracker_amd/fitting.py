@@ -53,19 +53,21 @@ def _ev_begin(prof):
 
 
 def _flush_events(prof, local, executed):
-    """append a fit's per-launch events to the caller's lists; ``executed`` = the number of steps that ran before the device-side stop (one query launch
-    per step): the launches queued behind it returned at their first instruction and are not query work"""
+    """append a fit's per-launch events to the caller's lists; ``executed`` = the number of Adam steps that ran before the device-side stop: the launches
+    of the steps queued behind it returned at their first instruction and are not query work.  Every event carries the index of the step that launched
+    it (the object stage records no query event in its 'sil' steps, so a count of events says nothing about steps)."""
     if prof is None:
         return
     for k, v in local.items():
-        prof[k].extend(v if executed is None else v[:executed])       # list.extend is atomic under the GIL (two fits in flight share ``prof``)
+        # list.extend is atomic under the GIL (two fits in flight share ``prof``)
+        prof[k].extend((a, b, n) for a, b, n, step in v if executed is None or step < executed)
 
 
-def _ev_end(prof, key, e0, frames):
+def _ev_end(prof, key, e0, frames, step):
     if prof is None:
         return
     e1 = torch.cuda.Event(enable_timing=True); e1.record()
-    prof[key].append((e0, e1, frames))      # frames of the launch: the tail batch of a sequence is smaller
+    prof[key].append((e0, e1, frames, step))      # frames of the launch (the tail batch of a sequence is smaller), Adam step of the fit that launched it
 
 
 class Terms:
@@ -416,7 +418,7 @@ class FitContext:
                                                         self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
                                                         int(phase == "kpts"), float(w[5]), terms.ptr("stemp") if B >= 4 else None, dverts.data_ptr(), terms.ptr("df_h"),
                                                         L.stream_ptr()))
-                        _ev_end(lp, "human", ev, B)
+                        _ev_end(lp, "human", ev, B, res.steps)
                         self.smpl_backward(pose, betas, dverts, vposed, ws, scratch, dpose, dbetas, dtrans)
                         self._smpl_tail(pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, (it - start) * 10 + i, ticket, int(early_stop and it > arm_after))
                         res.steps += 1
@@ -425,7 +427,7 @@ class FitContext:
                     _chk(_lib().vt_query_human_loss(self.net.h, C.byref(maps.c), verts.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, V,
                                                     self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
                                                     dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
-                    _ev_end(lp, "human", ev, B)
+                    _ev_end(lp, "human", ev, B, res.steps)
                     if phase == "kpts":
                         _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
                         _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
@@ -548,7 +550,7 @@ class FitContext:
                         ev = _ev_begin(lp)
                         _chk(_lib().vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
                                                          occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), L.stream_ptr()))
-                        _ev_end(lp, "object", ev, B)
+                        _ev_end(lp, "object", ev, B, res.steps)
                     if B >= 4:
                         _chk(_lib().vt_accel_loss(X.data_ptr(), B, N * 3, None, float(w[1]), terms.ptr("otemp"), dX.data_ptr(), L.stream_ptr()))
                         _chk(_lib().vt_velocity_loss(X.data_ptr(), B, N * 3, float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), L.stream_ptr()))
@@ -568,12 +570,7 @@ class FitContext:
                             contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
                         contact = contact_box[0]
                         if contact["P"] > 0:
-                            y = X.view(-1, 3).index_select(0, contact["idx_o"])
-                            dy = torch.zeros_like(y)
-                            _chk(_lib().vt_chamfer_ragged_ws(contact["x"].data_ptr(), contact["offx"].data_ptr(), contact["x"].shape[0], y.data_ptr(),
-                                                             contact["offy"].data_ptr(), y.shape[0], contact["P"], float(w[5]), terms.ptr("contact"), None,
-                                                             dy.data_ptr(), contact["ws"].data_ptr(), L.stream_ptr()))
-                            dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
+                            self._contact_term(contact, X, dX, float(w[5]), terms)
                     _chk(_lib().vt_rigid_backward(self.obj_points.data_ptr(), 1, obj_s.data_ptr(), B, N, dX.data_ptr(), dR.data_ptr(), dt.data_ptr(), acc, L.stream_ptr()))
                     if phase == "joint" and self.collision_loss:
                         # prevent interpenetration (recon_fit_trivis_full.py:260-264): SMPL mesh vs the transformed object template
@@ -620,7 +617,10 @@ class FitContext:
             yield
             return
         sp = L.stream_ptr()
-        _chk(_lib().vt_stream_set_skip_flag(sp, stop.data_ptr()))
+        if _lib().vt_stream_set_skip_flag(sp, stop.data_ptr()) != 0:
+            # this thread already has another fit's flag registered for the stream (nested fits): run without the device-side skip
+            yield
+            return
         try:
             yield
         finally:
@@ -653,7 +653,7 @@ class FitContext:
             ev = _ev_begin(prof)
             _chk(lib.vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
                                           occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), st))
-            _ev_end(prof, "object", ev, B)
+            _ev_end(prof, "object", ev, B, k)
         if B >= 4:
             _chk(lib.vt_temporal_loss2(X.data_ptr(), B, N * 3, float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), int(is_sil), st))
         elif is_sil:
@@ -670,11 +670,7 @@ class FitContext:
                 contact_box[0] = self._contacts_once(maps, smpl_verts, X, crop_center, body_center)
             contact = contact_box[0]
             if contact["P"] > 0:
-                y = X.view(-1, 3).index_select(0, contact["idx_o"])
-                dy = torch.zeros_like(y)
-                _chk(lib.vt_chamfer_ragged_ws(contact["x"].data_ptr(), contact["offx"].data_ptr(), contact["x"].shape[0], y.data_ptr(), contact["offy"].data_ptr(),
-                                              y.shape[0], contact["P"], float(w[5]), terms.ptr("contact"), None, dy.data_ptr(), contact["ws"].data_ptr(), st))
-                dX.view(-1, 3).index_add_(0, contact["idx_o"], dy)
+                self._contact_term(contact, X, dX, float(w[5]), terms)
         adam.t += 1
         gR = gT = (None, None, None, 0.0)
         for (p_, n_, g_, lr_), m_, v_ in zip(adam.slices, adam.m, adam.v):
@@ -686,6 +682,15 @@ class FitContext:
                                  obj_s.data_ptr(), B, obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), trans_init.data_ptr() if is_sil else None, float(w[4]),
                                  terms.ptr("trans"), dR.data_ptr(), dt.data_ptr(), dM.data_ptr(), *gR, *gT, adam.t, 0.9, 0.999, 1e-8,
                                  terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, st))
+
+    def _contact_term(self, contact, X, dX, w, terms):
+        """the contact Chamfer term of a 'joint' step (recon_fit_trivis_full.py:449-457): the object-side contact points are read out of X and their gradient
+        added into dX through the index list inside the launch (vt_chamfer_ragged_idx: the additions of index_select -> Chamfer -> index_add_ in their
+        order, without those three launches); the work-item plan of the -- per batch constant -- contact set is built by the first call only"""
+        _chk(_lib().vt_chamfer_ragged_idx(contact["x"].data_ptr(), contact["offx"].data_ptr(), contact["x"].shape[0], X.data_ptr(), contact["idx_o32"].data_ptr(),
+                                          contact["offy"].data_ptr(), contact["idx_o32"].shape[0], contact["P"], w, terms.ptr("contact"), dX.data_ptr(),
+                                          contact["ws"].data_ptr(), int(not contact["planned"]), L.stream_ptr()))
+        contact["planned"] = True
 
     def _contacts_once(self, maps, smpl_verts, X, crop_center, body_center, thres=0.08):
         """'Computing contacts once' (recon_fit_trivis_full.py:242-253) + the pairing of compute_contact_loss (:393-457):
@@ -721,7 +726,7 @@ class FitContext:
         offx[1:] = torch.cumsum(ch[perm], 0).int(); offy[1:] = torch.cumsum(co[perm], 0).int()
         x = smpl_verts.reshape(-1, 3).index_select(0, idx_h).contiguous()
         ws = torch.empty(int(_lib().vt_chamfer_ws_bytes(x.shape[0], idx_o.shape[0], P)), dtype=torch.uint8, device=dev)     # scratch of vt_chamfer_ragged_ws
-        return {"P": P, "x": x, "offx": offx, "offy": offy, "idx_o": idx_o, "ws": ws}
+        return {"P": P, "x": x, "offx": offx, "offy": offy, "idx_o": idx_o, "idx_o32": idx_o.int().contiguous(), "ws": ws, "planned": False}
 
 
 class SilSetup:

@@ -168,13 +168,15 @@ class SequencePipeline:
         if overlap:
             import threading
             enc_stream = torch.cuda.Stream(device=self.device); enc_stream.wait_stream(torch.cuda.current_stream())
-            enc_done = [threading.Event() for _ in nb4]; enc_ev = [torch.cuda.Event() for _ in nb4]; enc_err = []
+            enc_done = [threading.Event() for _ in nb4]; enc_ev = [torch.cuda.Event() for _ in nb4]; enc_err = []; enc_cancel = threading.Event()
 
             def encode_all():
                 try:
                     torch.cuda.set_device(self.device)
                     with torch.cuda.stream(enc_stream):
                         for i, (s, e) in enumerate(nb4):
+                            if enc_cancel.is_set():
+                                break
                             enc_maps[i] = self.net.encoder(images[s:e], out={k: t[s - lo:e - lo] for k, t in big.items()})
                             self.net.frames_encoded = getattr(self.net, "frames_encoded", 0) + (e - s)
                             enc_ev[i].record(enc_stream); enc_done[i].set()
@@ -183,27 +185,33 @@ class SequencePipeline:
                     for d_ in enc_done:
                         d_.set()
             enc_thread = threading.Thread(target=encode_all); enc_thread.start()
-        for i, (s, e) in enumerate(nb4):
-            batch = {k: v[s:e] for k, v in data.items()}
-            self.generator.reseed(s)            # random stream keyed by the batch's first frame: the same samples on any rank
-            bm = None
+        try:
+            for i, (s, e) in enumerate(nb4):
+                batch = {k: v[s:e] for k, v in data.items()}
+                self.generator.reseed(s)            # random stream keyed by the batch's first frame: the same samples on any rank
+                bm = None
+                if overlap:
+                    enc_done[i].wait()
+                    if enc_err:
+                        enc_thread.join(); raise enc_err[0]
+                    torch.cuda.current_stream().wait_event(enc_ev[i])
+                    bm = enc_maps[i]
+                elif resident:
+                    self.net.filter(batch["images"], out={k: t[s - lo:e - lo] for k, t in big.items()})
+                    bm = self.net.maps
+                # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
+                # neural-only pass is written to disk and never read again by steps 5-6 (work whose result is unused)
+                pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm, targets=("object",))
+                o = pc["object"]
+                rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
+        finally:
+            # also on an exception of the loop above: stop the encoder thread, join it, and order this stream behind everything it queued -- it must
+            # not keep writing into the resident maps while the exception propagates
             if overlap:
-                enc_done[i].wait()
-                if enc_err:
-                    enc_thread.join(); raise enc_err[0]
-                torch.cuda.current_stream().wait_event(enc_ev[i])
-                bm = enc_maps[i]
-            elif resident:
-                self.net.filter(batch["images"], out={k: t[s - lo:e - lo] for k, t in big.items()})
-                bm = self.net.maps
-            # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
-            # neural-only pass is written to disk and never read again by steps 5-6 (work whose result is unused)
-            pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm, targets=("object",))
-            o = pc["object"]
-            rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
-        if overlap:
-            enc_thread.join()
-            torch.cuda.current_stream().wait_stream(enc_stream)
+                enc_cancel.set(); enc_thread.join()
+                torch.cuda.current_stream().wait_stream(enc_stream)
+        if overlap and enc_err:
+            raise enc_err[0]
         local = torch.cat(rows, 0) if rows else torch.zeros(0, 16, device=self.device)
         neural = self._gather(local, T, unit).cpu().numpy()
         neural_dict = {"pca_axis": neural[:, :9].reshape(T, 3, 3), "centers": neural[:, 9:15], "visibility": neural[:, 15:16]}

@@ -249,9 +249,12 @@ class ReconFitterTriVisFull(ReconFitterBase):
             paths = data.get("path")
             neural_only = bool(getattr(args, "neural_only", False))
             if hasattr(source, "is_done") and not getattr(args, "redo", False):
-                try:            # recon_fit_triplane.py:50: is_done(paths, neural_only) -- a neural-only pass resumes on its own outputs (k1_densepc.npz)
+                # recon_fit_triplane.py:50: is_done(paths, neural_only) -- a neural-only pass resumes on its own outputs (k1_densepc.npz); sources written for
+                # the older one-argument form are called that way (decided on the signature: a TypeError raised INSIDE is_done must not be swallowed)
+                import inspect
+                if "neural_only" in inspect.signature(source.is_done).parameters:
                     finished = source.is_done(paths, neural_only=neural_only)
-                except TypeError:
+                else:
                     finished = source.is_done(paths)
                 if finished:
                     continue

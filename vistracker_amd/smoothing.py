@@ -185,11 +185,13 @@ class SMPLTSmoother:
         data_seq = np.concatenate([pose_6d, raw_data["betas"], raw_data["trans"]], 1)
         # the sequence goes to the device ONCE; the ~1400 clips are cut there (a 1437 x 64 x 157 host tensor took longer to build and copy than
         # the network takes to run)
-        input_data, paths = self.seq2batches(torch.as_tensor(data_seq).float().to(self.device), raw_data)
+        # (the subtraction runs in the dtype of the packed data -- float64 for packed pkls -- and the cast to float32 follows it, like the reference,
+        # smoothnet/smooth_smplt.py:90-96: subtracting float32-rounded translations differs from it by 1e-7 relative)
+        input_data, paths = self.seq2batches(torch.as_tensor(data_seq).to(self.device), raw_data)
         s0 = 24 * 6 + 10
         init = input_data[:, 0:1, s0:s0 + 3].clone()                      # translation relative to the first frame of each clip
         input_data[:, :, s0:s0 + 3] = input_data[:, :, s0:s0 + 3] - init
-        return {"input_data": input_data, "smplt_start": s0, "smplt_init": init, "paths": paths}
+        return {"input_data": input_data.float(), "smplt_start": s0, "smplt_init": init.float(), "paths": paths}
 
     @staticmethod
     def merge_paths(paths):
