@@ -36,6 +36,14 @@ def v2v(a, b):
     return d.mean(), d.max()
 
 
+def both(f32, f64):
+    """run the fp32 oracle and its fp64 arbiter side by side (ctypes releases the GIL; the OpenMP teams share the host cores)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:
+        a, b = ex.submit(f32), ex.submit(f64)
+        return a.result(), b.result()
+
+
 REPORT = {}      # measured distances of this session, written to gpurun_out/fullsched_parity.json when the tests run on the GPU box (copied to profiles/ by hand)
 
 
@@ -72,7 +80,11 @@ def test_full_schedule_smplt_prefit_vs_oracle(synth):
     p, b_, t = cu(pose0.copy()), cu(betas0.copy()), cu(trans0.copy())
     res = ctx.fit_smplt(p, b_, t, cu(kp))
     verts_hip = ops.smplh_forward(ctx.smpl, p, b_, t)[0].cpu().numpy()
-    pose, betas, trans, losses, stopped = oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp)
+    from oracle import oracle64 as O64
+    m64 = O64.SmplModel(model)
+    (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(
+        lambda: oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp),
+        lambda: oracle_fit_smplt(m64, O64.Landmarks(regs["body25"]), pri, pose0, betas0, trans0, kp, O=O64))
     verts_cpu, _, _ = m.forward(pose, betas, trans)
     assert res.stopped_early and stopped and res.steps > 310          # armed at it > 30: both ran at least 31 outer iterations
     assert abs(res.steps - len(losses)) <= 2, (res.steps, len(losses))   # the rule compares two nearly equal numbers: may fire a step apart
@@ -81,9 +93,6 @@ def test_full_schedule_smplt_prefit_vs_oracle(synth):
     mean, mx = v2v(verts_hip, verts_cpu)
     assert mean < 1e-4 and mx < 1e-3, (mean, mx)      # measured 3e-7 / 1e-6 m when the step counts agree
     # fp64 arbiter: the same schedule on the float64 build of the oracle -- the HIP result is as close to it as the fp32 oracle is (or within the bar)
-    from oracle import oracle64 as O64
-    m64 = O64.SmplModel(model)
-    p64, b64, t64, l64, _ = oracle_fit_smplt(m64, O64.Landmarks(regs["body25"]), pri, pose0, betas0, trans0, kp, O=O64)
     v64 = m64.forward(p64, b64, t64)[0]
     h64, o3264 = v2v(verts_hip, v64)[0], v2v(verts_cpu, v64)[0]
     _report("smplt_prefit", hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, hip_vs_oracle64_mean=h64, oracle32_vs_oracle64_mean=o3264, steps_hip=res.steps,
@@ -112,9 +121,12 @@ def test_full_schedule_smpl_stage_vs_oracle(synth):
         finally:
             ctx.net.set_precision("split-f16"); L.check(L.lib().vt_query_set_human_kernel(256))
     res, verts_hip = run()
-    m = O.SmplModel(model); b25 = O.Landmarks(regs["body25"]); net = O.SifNet(dec, mp)
-    pose, betas, trans, losses, stopped = oracle_optimize_smpl(m, b25, pri, net, labels, g["pose"], g["betas"], g["trans"], g["crop_center"],
-                                                              g["body_center"], g["body_kpts"])
+    from oracle import oracle64 as O64
+    m = O.SmplModel(model); b25 = O.Landmarks(regs["body25"]); net = O.SifNet(dec, mp); m64 = O64.SmplModel(model)
+    (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(
+        lambda: oracle_optimize_smpl(m, b25, pri, net, labels, g["pose"], g["betas"], g["trans"], g["crop_center"], g["body_center"], g["body_kpts"]),
+        lambda: oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(dec, mp), labels, g["pose"], g["betas"], g["trans"],
+                                     g["crop_center"], g["body_center"], g["body_kpts"], O=O64))
     verts_cpu, _, _ = m.forward(pose, betas, trans)
     assert res.stopped_early and stopped
     assert abs(res.steps - len(losses)) <= 2, (res.steps, len(losses))
@@ -124,10 +136,6 @@ def test_full_schedule_smpl_stage_vs_oracle(synth):
     assert mean < 1e-3, (mean, mx)                                   # measured 3.7e-4 m mean, 2e-3 m max (hands of a random-weight field)
     assert mx < 5e-3, (mean, mx)
     # fp64 arbiter (the float64 build of the oracle on the same schedule)
-    from oracle import oracle64 as O64
-    m64 = O64.SmplModel(model)
-    p64, b64, t64, l64, _ = oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(dec, mp), labels, g["pose"], g["betas"], g["trans"],
-                                                 g["crop_center"], g["body_center"], g["body_kpts"], O=O64)
     v64 = m64.forward(p64, b64, t64)[0]
     h64, o3264 = v2v(verts_hip, v64)[0], v2v(verts_cpu, v64)[0]
     assert h64 <= max(1e-3, o3264), (h64, o3264)
