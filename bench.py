@@ -110,8 +110,9 @@ def make_batch(ctx, syn, torch, seed, dev, res_scale=1.0, seq=None):
     # rendered into the 1200-px crop around crop_center at 512 x 512.  SilLossROI's per-batch set-up (bbox -> square x 1.3 -> ROI crops -> keep mask
     # -> ROI intrinsics) is built from them INSIDE the timed region (fit_batch), like the reference does (recon_fit_trivis_full.py:289-294)
     Kc = torch.zeros(B, 9, device=dev)
-    Kc[:, 0] = cam[0] / cam[4]; Kc[:, 2] = (cam[2] - cc[:, 0] + cam[4] / 2) / cam[4]
-    Kc[:, 4] = cam[1] / cam[4]; Kc[:, 5] = (cam[3] - cc[:, 1] + cam[4] / 2) / cam[4]; Kc[:, 8] = 1
+    fx_, fy_, cx_, cy_, crop_ = (float(v) for v in cam[:5])
+    Kc[:, 0] = fx_ / crop_; Kc[:, 2] = (cx_ - cc[:, 0] + crop_ / 2) / crop_
+    Kc[:, 4] = fy_ / crop_; Kc[:, 5] = (cy_ - cc[:, 1] + crop_ / 2) / crop_; Kc[:, 8] = 1
     with torch.no_grad():
         Vgt = ops.rigid_transform(ctx.obj_verts, ops.so3_project(obj_R_gt), obj_t_gt, obj_s)
         mask_o = ops.silhouette(Vgt, ctx.obj_faces, Kc, 512)

@@ -1,5 +1,6 @@
-"""A/B of the two kernels behind vt_query_human_loss at the bench shape (B=96, SMPL vertices, 2-D Morton order, hoisted projection):
-time per launch and agreement of terms / coordinate gradients.  usage: qab.py [reps=20] [B=96]"""
+"""A/B of the kernels behind vt_query_human_loss at the bench shape (B=96, SMPL vertices, 2-D Morton order, hoisted projection): 256 (default), 512 (thin
+waves), 128 (producer / consumer waves, 128 points per workgroup): time per launch and agreement of terms / coordinate gradients with the default.
+usage: qab.py [reps=20] [B=96] [variants=256,512,128]"""
 import sys, ctypes as C; sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import torch.nn.functional as F
@@ -19,8 +20,9 @@ verts, _, _ = ops.smplh_forward(ops.SmplhHandle(model), t(sp["pose"]), t(sp["bet
 pts = verts.detach().contiguous(); bc = t(sp["trans"]); cc = torch.tensor([[1018.952, 779.486]] * B, device=dev)
 labels = torch.as_tensor(syn.part_labels(model).astype(np.int32), device=dev)
 v0 = pts[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
+variants = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else '256,512,128').split(',')]
 res = {}
-for thr in (256, 512):
+for thr in variants:
     L.check(L.lib().vt_query_set_human_kernel(thr))   # 256 = default
     dp = torch.full((B, N, 3), float("nan"), device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
     def run():
@@ -34,10 +36,14 @@ for thr in (256, 512):
     ms = e0.elapsed_time(e1) / reps
     dp2 = torch.empty_like(dp); t2 = torch.zeros_like(terms)
     dp.fill_(float("nan")); terms.zero_(); run(); torch.cuda.synchronize()
-    print(f"{thr}-thread kernel: {ms:.3f} ms/launch = {0.59265024 / ms * 1e3:.0f} TFLOP/s algorithmic = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; "
+    print(f"variant {thr}: {ms:.3f} ms/launch = {0.59265024 / ms * 1e3:.0f} TFLOP/s algorithmic = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; "
           f"finite {bool(torch.isfinite(dp).all())}; rerun bit-identical {bool(torch.equal(dp, first[0]))} terms {bool(torch.equal(terms, first[1]))}")
     res[thr] = (first[0].cpu().numpy(), first[1].cpu().numpy())
-a, b = res[256], res[512]
-err = np.abs(a[0] - b[0]).max(-1) / np.abs(a[0]).max()
-print("terms 256:", a[1], "512:", b[1], "rel diff", np.abs(a[1] - b[1]) / np.abs(a[1]))
-print("gradient: max |diff| / max |g| =", err.max(), " quantiles 50/99/99.9/99.99 %:", [float(np.quantile(err, q)) for q in (0.5, 0.99, 0.999, 0.9999)], " points > 1e-5:", int((err > 1e-5).sum()))
+L.check(L.lib().vt_query_set_human_kernel(256))
+a = res[variants[0]]
+for v in variants[1:]:
+    b = res[v]
+    err = np.abs(a[0] - b[0]).max(-1) / np.abs(a[0]).max()
+    print(f"terms {variants[0]}:", a[1], f"{v}:", b[1], "rel diff", np.abs(a[1] - b[1]) / np.abs(a[1]))
+    print(f"gradient {variants[0]} vs {v}: max |diff| / max |g| =", err.max(), " quantiles 50/99/99.9/99.99 %:", [float(np.quantile(err, q)) for q in (0.5, 0.99, 0.999, 0.9999)],
+          " points > 1e-5:", int((err > 1e-5).sum()))

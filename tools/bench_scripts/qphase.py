@@ -22,7 +22,11 @@ if real:
     rng = np.random.default_rng(3); R = syn.random_rotations(B, rng)
     opts = t(np.einsum("nc,bcd->bnd", op, R) + sp["trans"][:, None] + rng.uniform(-0.3, 0.3, (B, 1, 3)))
     bc = t(sp["trans"])
-for mode, n in (("human", N), ("object", 3000)):
+pc = "pc" in sys.argv       # the producer / consumer kernel (vt_query_set_human_kernel(128)): phases of a consumer | a producer, slot 7 = clocks at the loop barriers
+if pc:
+    L.check(lib.vt_query_set_human_kernel(128))
+    names = ["proj fwd", "L1 fwd loop (+ relu/pack)", "hidden + objective", "loss reduce + proj bwd (+ dh)", "L1 bwd loop", "tail", "-", "of which: waiting at the loop barriers"]
+for mode, n in ((("human", N),) if pc else (("human", N), ("object", 3000))):
     pts = (torch.randn(B, n, 3, device=dev, generator=g) * 0.3 + torch.tensor([0, 0, 2.2], device=dev)).contiguous()
     if real:
         pts = (verts.detach() if mode == "human" else opts).contiguous()
@@ -50,5 +54,12 @@ for mode, n in (("human", N), ("object", 3000)):
     lib.vt_phase_clk(None, 1)
     for _ in range(5): run()
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 8)(); lib.vt_phase_clk(out, 1)
+    out = (C.c_ulonglong * 32)(); lib.vt_phase_clk(out, 1)
+    if pc:
+        wgs = 5 * B * (((n + 63) // 64 + 1) // 2)
+        for role, o in (("consumer (thread 0)", 0), ("producer (thread 256)", 8)):
+            v = np.array(list(out)[o:o + 8], np.float64)
+            print(role, "clocks per workgroup (two tiles):", {k: int(x / wgs) for k, x in zip(names, v) if k != "-"}, "total", int(v[:6].sum() / wgs))
+            print("   fine timers of the L1 fwd loop, clocks per workgroup:", [int(x / wgs) for x in list(out)[16 + o:16 + o + 8]])
+        continue
     v = np.array(list(out)[:5], np.float64); print(mode, "share per phase:", {k: f"{100 * x / v.sum():.1f}%" for k, x in zip(names, v)}, "clocks per WG:", int(v.sum() / 5 / (B * ((n + 63) // 64))))

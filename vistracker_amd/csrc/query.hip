@@ -519,7 +519,7 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
 #endif
 // per-phase shader-clock breakdown (debug builds with -DPHASE_CLK only; tools/bench_scripts/qphase.py)
 #ifdef PHASE_CLK
-__device__ unsigned long long g_phase[16];
+__device__ unsigned long long g_phase[32];
 #define PCLK(i_) do { if (tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_phase[i_], t_ - tprev_); tprev_ = t_; } } while (0)
 #else
 #define PCLK(i_)
@@ -1820,6 +1820,8 @@ static int launch_human8(const QArgs &a, hipStream_t st)
     return VT_OK;
 }
 
+#include "query_pc.h"       // producer / consumer variant: one 512-thread workgroup per two tiles (vt_query_set_human_kernel(128))
+
 // ---------------------------------------------------------------------------------------------------
 // MFMA operand-layout self test (f32-input 16x16x4, A = 16x4, B = 4x16 asymmetric): out = A.B, row-major 16x16
 // ---------------------------------------------------------------------------------------------------
@@ -2026,7 +2028,7 @@ __global__ __launch_bounds__(256) void proj_gemm_kernel(const float *__restrict_
 extern "C" int vt_phase_clk(unsigned long long *out, int reset)
 {
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase));
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
     return 0;
 }
 #endif
@@ -2126,10 +2128,10 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
 }
 
 // which kernel serves vt_query_human_loss when the maps carry a projection: 256 (default, the faster one: DESIGN.md 4.1b) or 512 threads per workgroup
-static std::atomic<int> g_human_kernel_threads{[]() { const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); return (e && atoi(e) == 512) ? 512 : 256; }()};
+static std::atomic<int> g_human_kernel_threads{[]() { const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); const int v = e ? atoi(e) : 0; return (v == 512 || v == 128) ? v : 256; }()};
 extern "C" int vt_query_set_human_kernel(int threads)
 {
-    VT_REQUIRE(threads == 256 || threads == 512, "vt_query_set_human_kernel: threads must be 256 or 512");
+    VT_REQUIRE(threads == 256 || threads == 512 || threads == 128, "vt_query_set_human_kernel: 256, 512 (threads per 64-point workgroup) or 128 (points per 512-thread producer / consumer workgroup)");
     g_human_kernel_threads.store(threads, std::memory_order_relaxed);
     return VT_OK;
 }
@@ -2143,9 +2145,11 @@ extern "C" int vt_query_human_loss(const vt_sifnet *h, const vt_maps *maps, cons
     a.hw[0] = head_at(h, 0, maps->act_level); a.hw[1] = head_at(h, 2, maps->act_level); a.labels = labels; a.order = order; a.w0 = w_dfh; a.w1 = w_part; a.dpts = dpts; a.terms = terms;
     // vt_query_set_human_kernel(512) / VT_QUERY_HUMAN_KERNEL=512 select the 512-thread kernel (one workgroup per CU, deep tap prefetch): an
     // experiment kept for A/B measurements and as an independent cross-check of the 256-thread kernel (measured slower)
-    const bool use8 = g_human_kernel_threads.load(std::memory_order_relaxed) == 512;
+    const int variant = g_human_kernel_threads.load(std::memory_order_relaxed);
+    const bool use8 = variant == 512;
     const bool usep = a.proj != nullptr && a.pw == PROJ_COLS && (long)a.res[0] * a.res[0] * PROJ_COLS < (1L << 32);
     if (use8 && usep) return launch_human8(a, vt_stream(stream));
+    if (variant == 128 && usep) return launch_human_pc(a, vt_stream(stream));
     return launch<2, MODE_HUMAN>(a, vt_stream(stream));
 }
 
