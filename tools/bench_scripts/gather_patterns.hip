@@ -4,6 +4,7 @@
 //   0: lane = (point, 32-byte piece): two instructions, each touching HALF of 16 rows per wave          (the query kernel's tap gathers today)
 //   1: lane = (point-of-8, 16-byte piece): each instruction reads 8 FULL rows per wave, two point groups per thread
 //   4: lane-linear: a wave reads 1 KB contiguous (the weight-fragment loads)
+//   5: lane-linear 1 KB per wave like 4, but delivered to LDS by the asynchronous DMA (global_load_lds, 16 B per lane) instead of to registers
 //   2: lane = (point, 64-byte half): four instructions each touching 16 B of ... (the P-row pattern: 4 lanes x 16 B = 64 contiguous bytes per point)
 // build: hipcc -O3 --offload-arch=gfx950 gather_patterns.hip -o gather_patterns ; run: ./gather_patterns [table MB]
 #include <hip/hip_runtime.h>
@@ -15,8 +16,17 @@ template <int PAT> __global__ __launch_bounds__(256) void gather(const float4 *_
 {
     const int tid = threadIdx.x;
     float4 acc = make_float4(0, 0, 0, 0);
+    __shared__ float4 sbuf[8][512];
     for (int it = 0; it < iters; it++) {
         const int *r = rows + ((size_t)blockIdx.x * iters + it) * 64;
+        if (PAT == 5) {
+            const int lane = tid & 63, w = tid >> 6;
+            const float4 *p = tab + ((size_t)r[w * 16] * 8 & ~(size_t)127) + lane;
+            float4 *dst = &sbuf[it & 7][w * 128];
+            __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(p + 64, (__attribute__((address_space(3))) void *)(dst + 64), 16, 0, 0);
+            if ((it & 7) == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        } else
         if (PAT == 0) {
             const int pt = tid >> 2, piece = tid & 3;                       // 4 lanes per point, 32 B each = 2 loads
             const float4 *p = tab + (size_t)r[pt] * 8 + piece * 2;
@@ -47,6 +57,7 @@ template <int PAT> __global__ __launch_bounds__(256) void gather(const float4 *_
             acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
         }
     }
+    if (PAT == 5) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); acc = sbuf[tid & 7][tid]; }
     out[(size_t)blockIdx.x * 256 + tid] = acc;
 }
 template <int PAT> float run(const float4 *tab, const int *rows, int blocks, int iters, float4 *out)
@@ -74,8 +85,8 @@ int main(int argc, char **argv)
     }
     CK(hipMalloc(&rows, h.size() * 4)); CK(hipMemcpy(rows, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     const double bytes = (double)blocks * iters * 64 * 128;
-    float t0 = run<0>(tab, rows, blocks, iters, out), t1 = run<1>(tab, rows, blocks, iters, out), t2 = run<2>(tab, rows, blocks, iters, out), t3 = run<3>(tab, rows, blocks, iters, out), t4 = run<4>(tab, rows, blocks, iters, out);
-    printf("table %zu MB, window %d rows: half-row x2 (today) %.3f ms = %.2f TB/s | full rows %.3f ms = %.2f TB/s | D-fragment 16 B strided lanes %.3f ms = %.2f TB/s | 64 B adjacent lanes %.3f ms = %.2f TB/s | lane-linear 1 KB per wave %.3f ms = %.2f TB/s\n",
-           mb, local, t0, bytes / t0 * 1e-9, t1, bytes / t1 * 1e-9, t2, bytes / t2 * 1e-9, t3, bytes / t3 * 1e-9, t4, bytes / t4 * 1e-9);
+    float t0 = run<0>(tab, rows, blocks, iters, out), t1 = run<1>(tab, rows, blocks, iters, out), t2 = run<2>(tab, rows, blocks, iters, out), t3 = run<3>(tab, rows, blocks, iters, out), t4 = run<4>(tab, rows, blocks, iters, out), t5 = run<5>(tab, rows, blocks, iters, out);
+    printf("table %zu MB, window %d rows: half-row x2 (today) %.3f ms = %.2f TB/s | full rows %.3f ms = %.2f TB/s | D-fragment 16 B strided lanes %.3f ms = %.2f TB/s | 64 B adjacent lanes %.3f ms = %.2f TB/s | lane-linear 1 KB per wave %.3f ms = %.2f TB/s | the same through the LDS DMA %.3f ms = %.2f TB/s\n",
+           mb, local, t0, bytes / t0 * 1e-9, t1, bytes / t1 * 1e-9, t2, bytes / t2 * 1e-9, t3, bytes / t3 * 1e-9, t4, bytes / t4 * 1e-9, t5, bytes / t5 * 1e-9);
     return 0;
 }

@@ -993,7 +993,24 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++)                                                                     \
             __builtin_amdgcn_global_load_lds(a.hw[g_].w1c + (size_t)(ci_) * 1024 + 256 * i_ + tid,                          \
                                              (__attribute__((address_space(3))) void *)(Sl + g_ * 1024 + 256 * i_ + wave * 64), 16, 0, 0);
-    SLAB_DMA(C0)
+    // SLAB_VIA_REGS (default 1): the slab through registers (8 buffer loads of 16 B per thread, 8 ds_write_b128) instead of the LDS DMA.  Measured
+    // (tools/bench_scripts/gather_patterns.hip, pattern 5): the DMA path delivers 16-byte-per-lane loads at HALF the rate of the path to the
+    // registers (10.5-11.2 vs 20-21.4 TB/s for the same lane-linear 1 KB per wave from L2) -- and this kernel is bound by that delivery.
+#ifndef SLAB_VIA_REGS
+#define SLAB_VIA_REGS 1
+#endif
+    // (the one-head kernels -- 168 VGPRs, three workgroups per CU -- have no room for the eight fragments in flight and keep the DMA)
+    constexpr bool SLABR = (G == 2) && SLAB_VIA_REGS;
+    uint4 slabr[G][4];
+#define SLAB_LOAD(ci_)                                                                                                       \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++) {                                                                       \
+        const rsrc_t sr_ = make_rsrc(a.hw[g_].w1c, 0x40000000u);                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) slabr[g_][i_] = bload_u4(sr_, (unsigned)(256 * i_ + tid) * 16u, (unsigned)(ci_) * 16384u); \
+    }
+#define SLAB_STORE()                                                                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; g_++)                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) Sl[g_ * 1024 + 256 * i_ + tid] = slabr[g_][i_];
+    if (SLABR) { SLAB_LOAD(C0) SLAB_STORE() } else { SLAB_DMA(C0) }
     TapGeom<2> tgb;
     { int mi, co; chunk_info(C0, mi, co); if (SHGEO) geom_fetch<2>(mi, sGeo, tid, tgb); else taps_geom(a, mi, sUV, tid, tgb); taps_issue(a, b, mi, co, tgb, tp); }
     __syncthreads();
@@ -1044,7 +1061,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) d4[pass] = *reinterpret_cast<const float4 *>(sD + (gpp + 32 * pass) * TS + 4 * gsub);
 #if !(defined(TA_ABL) && (TA_ABL & 2))
-        if (ci + 1 < NCHUNK) { SLAB_DMA(ci + 1) asm volatile("" ::: "memory"); }
+        if (ci + 1 < NCHUNK) { if (SLABR) { SLAB_LOAD(ci + 1) } else { SLAB_DMA(ci + 1) asm volatile("" ::: "memory"); } }
 #endif
 #pragma unroll
         for (int pass = 0; pass < 2; pass++)
@@ -1088,15 +1105,24 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
             taps_issue(a, b, m2i, c2o, tgb, tp);
-            // slab(ci+1) landed, the d feat rows free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
-            // 8 tap loads just issued; the DMA pieces are older than those, so "at most 8 outstanding" means the slab is in LDS.
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if (SLABR) {
+                // the slab pieces (older than the 8 tap loads just issued: the compiler's own vmcnt for them leaves the taps in flight) go to LDS; everybody
+                // read the old slab before the barrier in the middle of the iteration
+                SLAB_STORE()
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                // slab(ci+1) landed, the d feat rows free again.  NOT __syncthreads(): its fence is a vmcnt(0), which would also wait for the
+                // 8 tap loads just issued; the DMA pieces are older than those, so "at most 8 outstanding" means the slab is in LDS.
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            }
 #endif
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     }
 #undef SLAB_DMA
+#undef SLAB_LOAD
+#undef SLAB_STORE
     PCLK(4);
     // the gathered-map part: perspective Jacobian (kx/z, ky/z, -kx x/z^2, -ky y/z^2), sum over the 8 pieces of a tap row (xor 1, xor 2 inside the quad,
     // then the half-row mirror), hand-over from the gather layout (piece 0 of points gpp, gpp + 32) to the owner lanes (q == 0: point mypt)
