@@ -318,6 +318,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational legs after the timed region (kernel alone, full schedule, "
                                                               "SIF-Net inference = configs[3], demo pipeline = configs[4])")
     ap.add_argument("--pipeline-frames", type=int, default=1500)
+    ap.add_argument("--handout", choices=("auto", "static", "dynamic"), default="auto",
+                    help="strong mode with N > 1 ranks: static = contiguous runs of whole batches per rank (the reference's --start/--end contract); dynamic = "
+                         "every rank holds all batches' inputs and pulls the next batch index at run time from one shared counter, longest batch first "
+                         "(vistracker_amd.sharding.WorkQueue); auto = dynamic when N > 1")
     ap.add_argument("--fp32-batches", type=int, default=8, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
     args = ap.parse_args()
 
@@ -368,14 +372,25 @@ def main():
         torch.cuda.synchronize()
         return d
 
-    # this rank's jobs: a contiguous run of the K batches (first K % world ranks take one more), or K of its own in weak mode
+    # this rank's jobs: a contiguous run of the K batches (first K % world ranks take one more), or K of its own in weak mode -- or, with the
+    # run-time hand-out, ALL K batches resident on every rank and pulled one by one from a shared counter inside the timed region
+    job_frames = [(lambda se: se[1] - se[0])(seq_batches[j % len(seq_batches)]) for j in range(args.steps)] if strong else [BATCH] * args.steps
+    queue = None
+    if strong and use_dist and world > 1 and args.handout in ("auto", "dynamic"):
+        order = sorted(range(args.steps), key=lambda j: -job_frames[j])        # longest first (stable): the 60-frame tail batch goes last
+        queue = sharding.WorkQueue(args.steps, order)
+        if not queue.shared:
+            queue = None
+    dynamic = queue is not None
     if strong:
         base_, extra_ = divmod(args.steps, world)
         lo_ = rank * base_ + min(rank, extra_)
-        my_jobs = list(range(lo_, lo_ + base_ + (1 if rank < extra_ else 0)))
-        total_frames = sum(e_ - s_ for s_, e_ in (seq_batches[j % len(seq_batches)] for j in range(args.steps)))
+        my_jobs = list(range(args.steps)) if dynamic else list(range(lo_, lo_ + base_ + (1 if rank < extra_ else 0)))
+        total_frames = sum(job_frames)
     else:
         my_jobs = list(range(args.steps)); total_frames = world * args.steps * BATCH
+    # test hook: this job index runs the reference's maximum schedule (stop rules off) -- a batch 3.5 x as expensive as its neighbours
+    heavy = int(os.environ.get("VT_BENCH_FULL_SCHEDULE_BATCH", "-1"))
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
         fit_batch(ctx, torch, d); del d
@@ -386,8 +401,31 @@ def main():
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
-    if args.streams <= 1:
-        results = [fit_batch(ctx, torch, d, prof) for d in batches]
+    fitted = list(range(len(batches)))          # positions in ``batches`` this rank fitted (static: all of them)
+    if dynamic:
+        import threading
+        results = [None] * len(batches); fitted = []
+        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+
+        def pull_worker(k):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[k]):
+                while True:
+                    i = queue.next()
+                    if i is None:
+                        break
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy)); fitted.append(i)
+                streams[k].synchronize()
+        th_ = [threading.Thread(target=pull_worker, args=(k,)) for k in range(len(streams))]
+        for t_ in th_: t_.start()
+        for t_ in th_: t_.join()
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        fitted.sort()
+    elif args.streams <= 1:
+        results = [fit_batch(ctx, torch, d, prof, early_stop=(j != heavy)) for j, d in zip(my_jobs, batches)]
     else:
         # independent batches (the unit the path shards by) on separate HIP streams: the launch-latency-bound small kernels of one
         # batch overlap with the chip-filling query kernels of another
@@ -401,7 +439,7 @@ def main():
             torch.cuda.set_device(dev)
             with torch.cuda.stream(streams[k]):
                 for i in range(k, len(batches), args.streams):
-                    results[i] = fit_batch(ctx, torch, batches[i], prof)
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy))
 
         ready = [threading.Event() for _ in batches]; half = [None] * len(batches)
 
@@ -436,21 +474,49 @@ def main():
         for t_ in th_: t_.join()
         for s_ in streams:
             torch.cuda.current_stream().wait_stream(s_)
-    if use_dist:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch), padded to the largest shard
+    torch.cuda.synchronize(); my_seconds = time.perf_counter() - t0      # this rank's own work (before it waits for the others)
+    rows_of = lambda d: torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(-1, 9), d["obj_t"], d["obj_s"][:, None]], 1)
+    job_rows = None
+    if use_dist and dynamic:
+        # final exchange of the fitted parameters: every rank fills the rows of the batches IT fitted in a job-sized table (1500 x 182 floats), zeros
+        # elsewhere; one all-reduce (the rows are disjoint) leaves the whole table on every rank
+        offs = np.concatenate([[0], np.cumsum(job_frames)]).astype(int)
+        packed = torch.zeros(int(offs[-1]), 182, device=dev)
+        for i in fitted:
+            packed[offs[i]:offs[i + 1]] = rows_of(batches[i])
+        packed = packed.to(cdev)
+        dist.all_reduce(packed)
+        job_rows = packed
+    elif use_dist:   # final gather of the fitted parameters (the pipeline barrier of scripts/demo.sh; ~70 KB per batch), padded to the largest shard
         rows_max = (args.steps + world - 1) // world * BATCH if strong else args.steps * BATCH
         packed = torch.zeros(rows_max, 182, device=dev)
         if batches:
-            mine = torch.cat([torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(-1, 9), d["obj_t"], d["obj_s"][:, None]], 1) for d in batches])
+            mine = torch.cat([rows_of(d) for d in batches])
             packed[: mine.shape[0]] = mine
         packed = packed.to(cdev)
         out = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(out, packed)
+        if strong:
+            counts = [(args.steps // world + (1 if r_ < args.steps % world else 0)) for r_ in range(world)]
+            pos = 0; parts = []
+            for r_, c_ in enumerate(counts):
+                n_ = sum(job_frames[pos:pos + c_]); parts.append(out[r_][:n_]); pos += c_
+            job_rows = torch.cat(parts)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_wait = float(ctx.host_wait_s) - host_wait0
-    batch_frames = [int(d_["pose"].shape[0]) for d_ in batches]        # (the informational legs below release the batches)
+    rank_seconds = [my_seconds]
+    if use_dist:
+        rs_ = [None] * world; dist.all_gather_object(rs_, (my_seconds, [int(i) for i in (fitted if dynamic else my_jobs)])); rank_seconds = [x[0] for x in rs_]
+        rank_jobs = [x[1] for x in rs_]
+    else:
+        rank_jobs = [list(my_jobs)]
+    if os.environ.get("VT_BENCH_DUMP_ROWS") and rank == 0:
+        np.save(os.environ["VT_BENCH_DUMP_ROWS"], (job_rows if job_rows is not None else torch.cat([rows_of(d) for d in batches])).cpu().numpy())
+    results = [results[i] for i in fitted]; batches_fitted = [batches[i] for i in fitted]
+    batch_frames = [int(d_["pose"].shape[0]) for d_ in batches_fitted]        # (the informational legs below release the batches)
     if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
@@ -502,7 +568,7 @@ def main():
         leg("demo_pipeline", lambda: pipeline_leg(torch, args.pipeline_frames))
     if rank == 0:
         frames = total_frames
-        smpl_steps = float(np.mean([r[0].steps for r in results])); obj_steps = float(np.mean([r[1].steps for r in results]))
+        smpl_steps = float(np.mean([r[0].steps for r in results])) if results else 0.0; obj_steps = float(np.mean([r[1].steps for r in results])) if results else 0.0
         # frames x executed Adam steps of THIS rank's batches (the tail batch has fewer frames), scaled to the job
         my_frames = sum(batch_frames)
         frame_steps = sum(n_ * (r[0].steps + r[1].steps) for n_, r in zip(batch_frames, results)) * (frames / max(my_frames, 1))
@@ -543,8 +609,10 @@ def main():
                        # slack of the launching threads: seconds (summed over the host threads of rank 0) blocked on the device-side stop flag / wall-clock x threads;
                        # near 1 = the GPU is the bottleneck, near 0 = the host cannot queue launches as fast as the GPU retires them
                        "host_wait_frac": host_wait / (elapsed * max(1, args.streams + (1 if args.schedule == "staged" else 0))),
-                       "sharding": (f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)" if strong
-                                    else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU"},
+                       "sharding": ((f"{args.steps} batches handed out at run time from one shared counter (longest first) to {world} rank(s), every rank holding all inputs" if dynamic else
+                                     f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)") if strong
+                                    else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU",
+                       "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
                          "traffic": pmc_traffic_bytes(), "traffic_unit": f"B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(pmc_file() or 'none')})",

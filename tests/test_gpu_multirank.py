@@ -32,6 +32,38 @@ def test_bench_two_ranks_on_one_gpu(mode):
     assert line["config"]["adam_steps_smpl_stage"] >= 280 and line["roofline"]["launches"] >= 280
 
 
+def test_dynamic_handout_two_ranks_balances_a_heavy_batch(tmp_path):
+    """Run-time batch hand-out (sharding.WorkQueue; bench.py --handout dynamic, the default for N > 1): six batches of a 540-frame sequence, batch 0 forced to the
+    reference's MAXIMUM schedule (stop rules off: ~3.5 x the cost of its neighbours), two ranks on the one GPU of the test box.  Every batch is fitted exactly
+    once, the fitted rows are bit-identical to a one-rank run (a batch is an independent unit with its own random stream: who fits it cannot matter), and the
+    two ranks finish within 25 % of each other -- the contiguous static split of the same job leaves one rank with the heavy batch AND a full neighbour."""
+    import numpy as np
+    base = [os.path.join(ROOT, "bench.py"), "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1", "--steps", "6", "--sequence", "540", "--res-scale", "0.5"]
+    out_lines = {}
+    for tag, n, handout, port in (("one", 1, "static", 29571), ("dyn", 2, "dynamic", 29572), ("sta", 2, "static", 29573)):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", VT_BENCH_FULL_SCHEDULE_BATCH="0", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"))
+        if n > 1:
+            env["VT_BENCH_TEST_SHARED_GPU"] = "1"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + \
+                  ["--gpus", str(n), "--handout", handout]
+        else:
+            cmd = [sys.executable] + base + ["--gpus", "1"]
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+        out_lines[tag] = json.loads(lines[0])
+    dyn, sta = out_lines["dyn"]["config"], out_lines["sta"]["config"]
+    assert dyn["handout"] == "dynamic" and sta["handout"] == "static" and dyn["frames_timed"] == 540
+    assert sorted(sum(dyn["rank_jobs"], [])) == list(range(6)) and all(len(j) >= 1 for j in dyn["rank_jobs"])
+    rows = {k: np.load(tmp_path / f"{k}.npy") for k in ("one", "dyn", "sta")}
+    assert rows["one"].shape == (540, 182) and np.array_equal(rows["one"], rows["dyn"]) and np.array_equal(rows["one"], rows["sta"])
+    bal = lambda c: min(c["rank_seconds"]) / max(c["rank_seconds"])
+    print(f"rank seconds: dynamic {dyn['rank_seconds']} (jobs {dyn['rank_jobs']}), static {sta['rank_seconds']} (jobs {sta['rank_jobs']}); "
+          f"whole job {out_lines['dyn']['ms_per_step'] * 6e-3:.2f} s dynamic vs {out_lines['sta']['ms_per_step'] * 6e-3:.2f} s static")
+    assert bal(dyn) >= 0.75, (dyn["rank_seconds"], dyn["rank_jobs"])
+    assert bal(dyn) > bal(sta), (dyn["rank_seconds"], sta["rank_seconds"])
+
+
 def test_pipeline_two_ranks_equal_one_rank(tmp_path):
     """The demo pipeline sharded over two ranks (batch-aligned shards, one all-gather per barrier) returns what the single-rank run returns:
     frames shard by whole batches, every batch's random stream is keyed by its first frame, and no step depends on the rank.  The SMPL-T stages

@@ -55,6 +55,44 @@ def test_gather_params_world2_gloo(tmp_path):
     assert "GATHER_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_work_queue_world2_gloo(tmp_path):
+    """Run-time hand-out (sharding.WorkQueue): two CPU processes with two threads each pull items from one shared counter -- every item is served exactly
+    once, in the queue's order (longest first), and a slow rank simply takes fewer items; without a process group the counter is local."""
+    from vistracker_amd.sharding import WorkQueue
+    q = WorkQueue(5, order=[4, 0, 1, 2, 3])
+    assert not q.shared and [q.next() for _ in range(7)] == [4, 0, 1, 2, 3, None, None]
+    script = tmp_path / "q.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time, threading, torch, torch.distributed as dist
+        sys.path.insert(0, {ROOT!r})
+        from vistracker_amd.sharding import WorkQueue
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        n = 23
+        q = WorkQueue(n, order=list(range(n - 1, -1, -1)))
+        assert q.shared
+        mine = []
+        def worker():
+            while True:
+                i = q.next()
+                if i is None: break
+                mine.append(i); time.sleep(0.03 if r == 0 else 0.01)      # rank 0 is three times slower
+        th = [threading.Thread(target=worker) for _ in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        got = [None] * w; dist.all_gather_object(got, mine)
+        if r == 0:
+            allv = sorted(got[0] + got[1])
+            assert allv == list(range(n)), allv
+            assert len(got[1]) > len(got[0]) >= 1, (len(got[0]), len(got[1]))       # the faster rank took more
+            print("QUEUE_OK", len(got[0]), len(got[1]))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29535", str(script)], capture_output=True, text=True, env=env, timeout=240)
+    assert "QUEUE_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_config_loader_reads_reference_style_json(tmp_path):
     from vistracker_amd.config import load_configs, get_parser, merge_configs
     (tmp_path / "x.json").write_text('{\n "exp_name": "x", // comment\n "loadSize": 1200, "net_img_size": [512, 512], "z_feat": "smpl-triplane"\n}\n')

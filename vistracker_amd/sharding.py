@@ -62,3 +62,45 @@ def gather_params(local, num_frames: int, bs: int, start: int = 0, end: int | No
     dist.all_gather(outs, send)
     full = torch.cat([o[:c] for o, c in zip(outs, counts)], 0)
     return full.to(local.device) if via_host else full
+
+
+class WorkQueue:
+    """Run-time hand-out of work items (batch indices) to whichever rank / stream asks next.
+
+    The reference leaves the split of a sequence to the user (``--start/--end`` per process, README.md:50-52, recon/recon_fit_base.py:411-419): contiguous
+    equal-count shards leave the rank with the 60-frame tail batch idle for 38 % of a batch, and the stop rules make batches cost 734 .. 2580 Adam steps.
+    Here every rank (and every stream of a rank) pulls the next index from ONE atomic counter in the process group's key-value store (``store.add``: no
+    collective, no extra thread); items are served in ``order`` (e.g. longest first).  Results cannot depend on who fits what: a batch is an independent
+    unit with its own random stream.  Without a process group (or with one rank) the counter is local.  Every rank must construct its queues in the same
+    order (the key is numbered per process)."""
+    _serial = 0
+
+    def __init__(self, n_items: int, order=None, name: str = "vt_workqueue"):
+        import threading
+        self.n = int(n_items)
+        self.order = list(order) if order is not None else list(range(self.n))
+        assert sorted(self.order) == list(range(self.n)), "order must be a permutation of the items"
+        self._lock = threading.Lock(); self._next = 0
+        self.store = None
+        WorkQueue._serial += 1
+        self.key = f"{name}/{WorkQueue._serial}"
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from torch.distributed import distributed_c10d as c10d
+                self.store = c10d._get_default_store()
+        except Exception:          # noqa: BLE001 -- no store: every rank would serve itself the whole list; the caller must fall back to static shards
+            self.store = None
+
+    @property
+    def shared(self) -> bool:
+        return self.store is not None
+
+    def next(self):
+        """the next item, or None when all have been handed out"""
+        if self.store is None:
+            with self._lock:
+                k = self._next; self._next += 1
+        else:
+            k = int(self.store.add(self.key, 1)) - 1
+        return self.order[k] if k < self.n else None
