@@ -3,6 +3,9 @@ rocprofv3 --kernel-trace --stats"""
 import sys, time; sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from vistracker_amd import demo_inputs
+from vistracker_amd import generator as G
+for a in sys.argv[1:]:           # e.g. kept_heads_only=0 skip_done_frames=0 adaptive_sit_out=0 : class switches of the generator, for A/B runs
+    k, v = a.split("="); setattr(G.Generator, k, bool(int(v)))
 pipe, assets = demo_inputs.pipeline()
 T = 64
 seq = demo_inputs.sequence(T, assets)

@@ -13,6 +13,8 @@ The image encoder (``filter``) is not part of this module: feed encoder outputs 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -29,6 +31,12 @@ class Generator:
     # would draw them -- more rounds for that frame and another sample distribution: a deviation confined to that (rare: a frame 1.5 x ahead being
     # overtaken by the common count) case.  Set False for the reference's every-frame-every-round behaviour.
     skip_done_frames = True
+    # the sit-out level follows the rounds: the common count ends below num_points + (minimum of the LAST round), so a frame holding
+    # num_points + 2 x (the largest round minimum seen so far) points cannot be overtaken unless the slowest frame's yield more than doubles (measured: the
+    # round minima of a batch stay within +-15 % of each other after round 3; a frame that is overtaken anyway is re-activated, see above) -- instead of the
+    # fixed 1.5 x num_points.  Frames leave the launches one to two rounds earlier (-15 % frame-rounds).  False: the fixed level.
+    adaptive_sit_out = True
+    kept_heads_only = True      # see gen_pc_batch: the four heads other than the distance field are evaluated at the kept points only
 
     def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,
                  filter_val=0.03, seed=0, **kwargs):
@@ -126,14 +134,21 @@ class Generator:
         samples = samples_init.clone()
         active = np.ones(B, bool)                       # host copy: which frames still take part in the rounds
         stop_at = num_points + num_points // 2
+        max_min = 0
         full_maps, sub_maps, sub_key = getattr(model, "maps", None), None, None
         refill = False                                  # True: the common count is final, only frames it has overtaken are sampled further
 
-        def project(samples):
-            """approx_surface on the active frames only; results scattered back to batch-sized tensors (zeros for the frames that sit out)"""
+        # heads other than the distance field at the kept points only: the reference evaluates all five decoders on every sample of the last query and then
+        # reads them at the kept ones (generator.py:160-190); a decoder is a per-point function, so evaluating pca / parts / centres / visibility on the
+        # compacted kept points (a few thousand of the 20 000 samples of a frame) gives the same values for 1/5 .. 1/10 of the work.  False: the round's
+        # last step is followed by the five-head forward of ``approx_surface`` on all samples (round 3's path; A/B, tests).
+        kept_only = bool(self.kept_heads_only)
+
+        def active_view():
+            """(frame indices, query input, maps) of the frames still taking part"""
             nonlocal sub_maps, sub_key
             if active.all():
-                return self.approx_surface(model, samples, num_steps, query_input, df_type=df_type)
+                return None, query_input, full_maps
             idx = torch.as_tensor(np.nonzero(active)[0], device=dev)
             key = active.tobytes()
             if key != sub_key and full_maps is not None:
@@ -141,24 +156,56 @@ class Generator:
                     full_maps.build_projection(model.handle)
                 sub_maps, sub_key = full_maps.select(idx), key
             qi = {k: (v.index_select(0, idx) if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in query_input.items()}
+            return idx, qi, sub_maps
+
+        def scatter_frames(t, idx):
+            if idx is None:
+                return t
+            f = torch.zeros((B,) + tuple(t.shape[1:]), device=dev, dtype=t.dtype); f.index_copy_(0, idx, t)
+            return f
+
+        def project(samples):
+            """approx_surface on the active frames only; results scattered back to batch-sized tensors (zeros for the frames that sit out).
+            -> (surface samples, predictions of the last query or None, clamped distance at the last query, positions of the last query)"""
+            idx, qi, mp = active_view()
+            ss_in = samples if idx is None else samples.index_select(0, idx)
             if full_maps is not None:
-                model.maps = sub_maps
+                model.maps = mp
             try:
-                ss, pr = self.approx_surface(model, samples.index_select(0, idx), num_steps, qi, df_type=df_type)
+                if not kept_only:
+                    ss, pr = self.approx_surface(model, ss_in, num_steps, qi, df_type=df_type)
+                    pr = [scatter_frames(t, idx) for t in pr]
+                    return scatter_frames(ss, idx), pr, torch.clamp(pr[0][:, df_idx, :], max=self.threshold), None
+                if self.use_projection and model.maps.proj is None:
+                    model.maps.build_projection(model.handle)
+                ss = ss_in.detach().contiguous().clone(); pre = None; dft = None
+                for j in range(num_steps):
+                    qi = self.update_query_dict(ss, qi)
+                    last = j == num_steps - 1
+                    if last:
+                        pre = ss.clone()            # where the reference's last query (the one whose predictions it keeps) is evaluated
+                    _, d_ = ops.sifnet_project_step(model.handle, model.maps, ss, qi["crop_center"], qi["body_center"], df_idx, self.threshold, out=ss, want_target=last)
+                    dft = d_ if last else dft
+                return scatter_frames(ss, idx), None, scatter_frames(dft, idx), scatter_frames(pre, idx)
             finally:
                 if full_maps is not None:
                     model.maps = full_maps
-            ss_full = torch.zeros_like(samples); ss_full.index_copy_(0, idx, ss)
-            pr_full = []
-            for t in pr:
-                f = torch.zeros((B,) + tuple(t.shape[1:]), device=dev, dtype=t.dtype); f.index_copy_(0, idx, t); pr_full.append(f)
-            return ss_full, pr_full
 
+        def heads_at(points, kmax):
+            """pca, parts, centres (, visibility) at ``points`` (B, kmax, 3) of the active frames -> list of (B, C, kmax)"""
+            idx, qi, mp = active_view()
+            pts = (points if idx is None else points.index_select(0, idx)).contiguous()
+            with torch.no_grad():
+                _, pca, parts, centers, vis = ops.sifnet_query(model.handle, mp if mp is not None else model.maps, pts, qi["crop_center"], qi["body_center"],
+                                                               0b11110 if "visibility" in out_names else 0b01110)
+            outs = {"pca_axis": pca, "parts": parts, "centers": centers, "visibility": vis}
+            return [scatter_frames(outs[n], idx) for n in out_names[1:]]
+
+        stats = [] if os.environ.get("VT_GEN_STATS") else None
         while samples_count < num_points or refill:
-            samples_surface, preds = project(samples)
+            samples_surface, preds, df_target, pre = project(samples)
             S = samples.shape[1]
             act = torch.as_tensor(active, device=dev)
-            df_target = torch.clamp(preds[0][:, df_idx, :], max=self.threshold)
             mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0) & act[:, None]
             cnt = mask.sum(1)                                                  # (B,) kept points per frame
             order = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)  # kept sample indices first, in sample order
@@ -168,12 +215,25 @@ class Generator:
                 valid = (ar < cnt[:, None]) & (dest < cap)
                 dest = torch.where(valid, dest, torch.full_like(dest, cap))    # everything else lands in the trash row
                 buf["points"].scatter_(1, dest[..., None].expand(B, S, 3), samples_surface.gather(1, order[..., None].expand(B, S, 3)))
-                for name, pred in zip(out_names[1:], preds[1:]):
-                    pr = pred.reshape(B, -1, S).transpose(1, 2)                # (B, S, C)
-                    Cc = pr.shape[2]
-                    if name not in buf:
-                        buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
-                    buf[name].scatter_(1, dest[..., None].expand(B, S, Cc), pr.gather(1, order[..., None].expand(B, S, Cc)))
+                if preds is None:
+                    kmax = int(cnt.max().item())                               # (one more host look per round: the launch size of the kept-point query)
+                    if kmax > 0:
+                        kmax = min(S, (kmax + 63) // 64 * 64)
+                        ok = order[:, :kmax]
+                        kp = heads_at(pre.gather(1, ok[..., None].expand(B, kmax, 3)), kmax)
+                        for name, pred in zip(out_names[1:], kp):
+                            pr = pred.reshape(B, -1, kmax).transpose(1, 2)     # (B, kmax, C)
+                            Cc = pr.shape[2]
+                            if name not in buf:
+                                buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
+                            buf[name].scatter_(1, dest[:, :kmax, None].expand(B, kmax, Cc), pr)
+                else:
+                    for name, pred in zip(out_names[1:], preds[1:]):
+                        pr = pred.reshape(B, -1, S).transpose(1, 2)                # (B, S, C)
+                        Cc = pr.shape[2]
+                        if name not in buf:
+                            buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
+                        buf[name].scatter_(1, dest[..., None].expand(B, S, Cc), pr.gather(1, order[..., None].expand(B, S, Cc)))
                 fill = torch.minimum(fill + cnt, torch.full_like(fill, cap))
                 # the one host sync of the round: the round's minimum over the active frames and every frame's fill level
                 big = torch.full_like(cnt, 1 << 40)
@@ -183,12 +243,19 @@ class Generator:
                 if not mute:
                     print(f"{samples_count} points")
                 fill_h = host[1:]
+                if stats is not None:
+                    stats.append((it, int(active.sum()), int(host[0]), int(samples_count), int(fill_h.min()), int(np.median(fill_h)), int(fill_h.max())))
                 if samples_count >= num_points:
                     # done -- unless the final common count has overtaken a frame that sat rounds out: then only those frames continue
                     active = fill_h < min(samples_count, cap)
                     refill = bool(active.any())
                 elif self.skip_done_frames:
-                    keep = active & (fill_h < stop_at)
+                    if self.adaptive_sit_out and it >= 3:
+                        max_min = max(max_min, int(host[0]))
+                        level = min(stop_at, num_points + 2 * max_min)
+                    else:
+                        max_min = max(max_min, int(host[0])); level = stop_at
+                    keep = active & (fill_h < level)
                     if keep.any():
                         active = keep
             # samples of the next round
@@ -202,6 +269,8 @@ class Generator:
             it += 1
             if it == max_iter:
                 raise RuntimeError(f"point generation for df {df_type} failed after {max_iter} iterations for files: {batch.get('path')}")
+        if stats is not None:
+            print("[VT_GEN_STATS] (round, active frames, round min, common count, fill min / median / max):", stats)
         # hand the buffers over in the reference's per-frame list layout (views, no copies) and let compose_outdict reduce them
         out_dict = {"points": [[buf["points"][i, :cap]] for i in range(B)]}
         for name in out_names[1:]:
