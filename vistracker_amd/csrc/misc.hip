@@ -562,31 +562,39 @@ __global__ __launch_bounds__(256) void sweep_stats_kernel(const float *__restric
                         pt[i][k] = *reinterpret_cast<const float4 *>(a + (((size_t)b * lh + yy) * lw + xx) * C + 4 * c4);
                     }
                 }
+                // separable form with FIVE-tap weight rows: the four cubic weights of an output pixel sit at patch columns (rows) d .. d + 3 with d = 0 or 1
+                // (its tap base against the patch origin), the fifth weight is zero -- every product with it adds an exact zero, so the sums are the ones of
+                // the 4 x 4 form (row sums first, then the column sum, in the same order), without a select per tap and channel and with every row sum
+                // computed once for both output rows that use it
+                float w5x[2][5], w5y[2][5];
 #pragma unroll
-                for (int ey = 0; ey < 2; ey++) {
-                    float wy[4]; cubic_w(fy[ey] - iy[ey], wy);
-                    const bool dy = iy[ey] != iy[0];
+                for (int e = 0; e < 2; e++) {
+                    float wx[4], wy[4]; cubic_w(fx[e] - ix[e], wx); cubic_w(fy[e] - iy[e], wy);
+                    const bool dx = ix[e] != ix[0], dy = iy[e] != iy[0];
+                    w5x[e][0] = dx ? 0.f : wx[0]; w5x[e][1] = dx ? wx[0] : wx[1]; w5x[e][2] = dx ? wx[1] : wx[2]; w5x[e][3] = dx ? wx[2] : wx[3]; w5x[e][4] = dx ? wx[3] : 0.f;
+                    w5y[e][0] = dy ? 0.f : wy[0]; w5y[e][1] = dy ? wy[0] : wy[1]; w5y[e][2] = dy ? wy[1] : wy[2]; w5y[e][3] = dy ? wy[2] : wy[3]; w5y[e][4] = dy ? wy[3] : 0.f;
+                }
+                float4 rs[5][2];
+#pragma unroll
+                for (int i = 0; i < 5; i++)
 #pragma unroll
                     for (int ex = 0; ex < 2; ex++) {
-                        float wx[4]; cubic_w(fx[ex] - ix[ex], wx);
-                        const bool dx = ix[ex] != ix[0];
+                        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int k = 0; k < 5; k++) { const float4 t = pt[i][k]; const float wk = w5x[ex][k]; row.x += wk * t.x; row.y += wk * t.y; row.z += wk * t.z; row.w += wk * t.w; }
+                        rs[i][ex] = row;
+                    }
+#pragma unroll
+                for (int ey = 0; ey < 2; ey++)
+#pragma unroll
+                    for (int ex = 0; ex < 2; ex++) {
                         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const float4 t0 = pt[i][k], t1 = pt[i][k + 1], u0 = pt[i + 1][k], u1 = pt[i + 1][k + 1];
-                                const float4 t = dy ? (dx ? u1 : u0) : (dx ? t1 : t0);
-                                row.x += wx[k] * t.x; row.y += wx[k] * t.y; row.z += wx[k] * t.z; row.w += wx[k] * t.w;
-                            }
-                            v.x += wy[i] * row.x; v.y += wy[i] * row.y; v.z += wy[i] * row.z; v.w += wy[i] * row.w;
-                        }
+                        for (int i = 0; i < 5; i++) { const float4 row = rs[i][ex]; const float wi = w5y[ey][i]; v.x += wi * row.x; v.y += wi * row.y; v.z += wi * row.z; v.w += wi * row.w; }
                         const int oy = 2 * qy + ey, ox = 2 * qx + ex;
                         if (skip) { const float4 k4 = *reinterpret_cast<const float4 *>(skip + ((size_t)b * HW + (size_t)oy * w + ox) * C + 4 * c4); v.x += k4.x; v.y += k4.y; v.z += k4.z; v.w += k4.w; }
                         emit(oy, ox, v);
                     }
-                }
             }
         }
     if (!part) return;
