@@ -131,14 +131,22 @@ def sil_setup(ctx, d):
                       net_input_size=512).setup()
 
 
-def fit_batch(ctx, torch, d, prof=None, early_stop=True):
-    """The hot path over one batch: SMPL stage then object stage (recon/recon_fit_triplane.py:70-106)."""
+def fit_batch(ctx, torch, d, prof=None, early_stop=True, obj_stream=None):
+    """The hot path over one batch: SMPL stage then object stage (recon/recon_fit_triplane.py:70-106).  ``obj_stream``: run the object stage on
+    that stream (stream-ordered after the SMPL stage, the caller's stream waits for it) -- the --object-priority experiment."""
     from vistracker_amd import ops
     r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof, early_stop=early_stop)
     with torch.no_grad():
         verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
-    r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof,
-                                  early_stop=early_stop)
+    if obj_stream is None:
+        r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof,
+                                      early_stop=early_stop)
+        return r1, r2
+    cur = torch.cuda.current_stream(); obj_stream.wait_stream(cur)
+    with torch.cuda.stream(obj_stream):
+        r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof,
+                                      early_stop=early_stop)
+    cur.wait_stream(obj_stream)
     return r1, r2
 
 
@@ -311,6 +319,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
+    ap.add_argument("--object-priority", type=int, default=0, help="HIP stream priority of the object-stage stream of --schedule staged (-1 = high)")
     ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
                     help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
                          "stream runs the object stage of every batch as soon as its SMPL stage is done (the chip-filling query launches of one stage "
@@ -437,9 +446,10 @@ def main():
 
         def worker(k):
             torch.cuda.set_device(dev)
+            so = torch.cuda.Stream(device=dev, priority=args.object_priority) if args.object_priority else None
             with torch.cuda.stream(streams[k]):
                 for i in range(k, len(batches), args.streams):
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy))
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy), obj_stream=so)
 
         ready = [threading.Event() for _ in batches]; half = [None] * len(batches)
 
@@ -457,7 +467,7 @@ def main():
 
         def object_worker():
             torch.cuda.set_device(dev)
-            so = torch.cuda.Stream(device=dev); so.wait_stream(torch.cuda.current_stream())
+            so = torch.cuda.Stream(device=dev, priority=args.object_priority); so.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(so):
                 for i, d in enumerate(batches):
                     ready[i].wait()
