@@ -214,7 +214,10 @@ def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
         Ro, to, losses, stopped, hc = oracle_optimize_object(net, ctx_pts, c["R0"], c["t0"], c["sc"], noise, c["cc"], c["bc"], c["occ"], c["sverts"],
                                                             synth["labels"], sil=sil, O=Om, **kw)
         return O.rigid(ctx_pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), c["sc"]), losses, stopped, hc
-    Xo, losses, stopped, had_contacts = oracle_run(O)
+    if field == "bowl":        # fp32 oracle and fp64 arbiter side by side
+        (Xo, losses, stopped, had_contacts), (X64, losses64, _, _) = both(lambda: oracle_run(O), lambda: oracle_run(O64))
+    else:
+        Xo, losses, stopped, had_contacts = oracle_run(O)
     assert had_contacts, "the joint phase of this case must have contacts"
     assert res.stopped_early == stopped
     X = O.rigid(ctx_pts, O.so3_project(R), t, c["sc"]); Xp = O.rigid(ctx_pts, O.so3_project(R_p), t_p, c["sc"])
@@ -225,7 +228,6 @@ def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
     rep = dict(hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, hip_self_1e6=self_mean, steps_hip=res.steps, steps_oracle=len(losses))
     if field == "bowl" and not with_sil:
         # ---- the gate: strict bar on a fixture that can discriminate (a correct kernel ends ~1e-5 m from the oracle, one that is 1 mm off fails)
-        X64, losses64, _, _ = oracle_run(O64)
         m64, _ = v2v(X, X64); o3264, _ = v2v(Xo, X64)
         rep.update(hip_vs_oracle64_mean=m64, oracle32_vs_oracle64_mean=o3264)
         _report(f"object_{field}_sil{int(with_sil)}", **rep)
@@ -239,7 +241,6 @@ def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
         assert m64 <= max(1e-3, o3264), msg                               # fp64 arbiter
         return
     if field == "bowl":
-        X64, _, _, _ = oracle_run(O64)
         m64, _ = v2v(X, X64); o3264, _ = v2v(Xo, X64)
         rep.update(hip_vs_oracle64_mean=m64, oracle32_vs_oracle64_mean=o3264)
         msg += f"; HIP vs oracle64 {m64:.3e} m, oracle32 vs oracle64 {o3264:.3e} m"

@@ -142,7 +142,8 @@ class Generator:
         # reads them at the kept ones (generator.py:160-190); a decoder is a per-point function, so evaluating pca / parts / centres / visibility on the
         # compacted kept points (a few thousand of the 20 000 samples of a frame) gives the same values for 1/5 .. 1/10 of the work.  False: the round's
         # last step is followed by the five-head forward of ``approx_surface`` on all samples (round 3's path; A/B, tests).
-        kept_only = bool(self.kept_heads_only)
+        # (a subclass that overrides ``approx_surface`` -- the reference's extension point, generator.py:259-300 -- is called as before: its predictions are the round's)
+        kept_only = bool(self.kept_heads_only) and type(self).approx_surface is Generator.approx_surface
 
         def active_view():
             """(frame indices, query input, maps) of the frames still taking part"""
