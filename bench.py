@@ -385,7 +385,9 @@ def main():
     # run-time hand-out, ALL K batches resident on every rank and pulled one by one from a shared counter inside the timed region
     job_frames = [(lambda se: se[1] - se[0])(seq_batches[j % len(seq_batches)]) for j in range(args.steps)] if strong else [BATCH] * args.steps
     queue = None
-    if strong and use_dist and world > 1 and args.handout in ("auto", "dynamic"):
+    # every rank keeps ALL K batches resident for the hand-out (7.3 GB each at full resolution): "auto" falls back to the static shards when they do not fit
+    fits = args.steps * 7.3e9 * args.res_scale ** 2 <= 0.6 * torch.cuda.mem_get_info(dev)[1]
+    if strong and use_dist and world > 1 and (args.handout == "dynamic" or (args.handout == "auto" and fits)):
         order = sorted(range(args.steps), key=lambda j: -job_frames[j])        # longest first (stable): the 60-frame tail batch goes last
         queue = sharding.WorkQueue(args.steps, order)
         if not queue.shared:
