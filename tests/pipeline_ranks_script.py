@@ -25,15 +25,19 @@ torch.backends.cudnn.benchmark = False          # MIOpen: no timing-driven algor
 if world > 1:
     dist.init_process_group("gloo")
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-cfg = PipelineConfig(smplt_bs=40, neural_bs=32, fit_bs=48, smplt_max_iter=4, refit_max_iter=2)
+handout = sys.argv[3] if len(sys.argv) > 3 else "steal"
+cfg = PipelineConfig(smplt_bs=40, neural_bs=32, fit_bs=24, smplt_max_iter=4, refit_max_iter=2, fit_handout=handout)
 pipe, assets = demo_inputs.pipeline(cfg, n_obj_points=600)
 seq = demo_inputs.sequence(T, assets)
 out = pipe.run(seq)
 # every rank: the maps of ITS frames stayed resident between the SIF-Net pass and the joint fit, two batches were in flight, and the encoder ran
-# exactly once per frame of the rank's range (stage 6 did not encode again)
+# exactly once per frame of the rank's range (stage 6 did not encode again) -- plus once per frame of every batch the rank STOLE from another rank's
+# list (run-time hand-out: those maps live in the other rank's HBM)
 lo, hi = pipe.log["frame_range"]
-assert pipe.log["resident_maps"] and pipe.log["frames_encoded"] == hi - lo, (pipe.log["resident_maps"], pipe.log["frames_encoded"], lo, hi)
-print("RANK_OK", int(os.environ.get("RANK", "0")), lo, hi, pipe.log["frames_encoded"], flush=True)
+foreign = sum(min(s_ + cfg.fit_bs, T) - s_ for s_ in pipe.log["fit_batches"] if not lo <= s_ < hi)
+assert (foreign > 0) == (pipe.log["stolen_batches"] > 0) and (handout == "steal" or foreign == 0)
+assert pipe.log["resident_maps"] and pipe.log["frames_encoded"] == hi - lo + foreign, (pipe.log["resident_maps"], pipe.log["frames_encoded"], lo, hi, foreign)
+print("RANK_OK", int(os.environ.get("RANK", "0")), lo, hi, pipe.log["frames_encoded"], "STOLEN", pipe.log["stolen_batches"], flush=True)
 if not dist.is_initialized() or dist.get_rank() == 0:
     rc, st, nn_ = out["recon"], out["smplt_smoothed_fit"], out["neural"]
     np.savez(sys.argv[1], poses=rc["poses"], betas=rc["betas"], trans=rc["trans"], obj_angles=rc["obj_angles"], obj_trans=rc["obj_trans"],

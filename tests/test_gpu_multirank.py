@@ -82,6 +82,11 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
         assert out.returncode == 0 and "PIPELINE_OK" in out.stdout and out.stdout.count("RANK_OK") == n, out.stdout[-2000:] + out.stderr[-4000:]
         outs.append(dict(np.load(f)))
     a, b = outs
+    # run-time hand-out of stage 6 (PipelineConfig.fit_handout = "steal", the default for N > 1): rank 1 owns the 4-frame tail batch and takes
+    # 24-frame batches from the back of rank 0's list of four, encoding their maps itself -- and the packed result is still the single-rank run's
+    import re
+    stolen = [int(x) for x in re.findall(r"STOLEN (\d+)", out.stdout)]
+    assert len(stolen) == 2 and sum(stolen) >= 1, out.stdout[-1500:]
     # the step logs are per rank: rank 0 of the 2-rank run holds the first half of the batches of every stage
     n1 = len(b["smplt_steps"]) // 2; m1 = len(a["smplt_steps"]) // 2
     assert np.array_equal(a["smplt_steps"][:n1], b["smplt_steps"][:n1]) and np.array_equal(a["smplt_steps"][m1:m1 + n1], b["smplt_steps"][n1:])

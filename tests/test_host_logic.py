@@ -93,6 +93,58 @@ def test_work_queue_world2_gloo(tmp_path):
     assert "QUEUE_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_steal_queue_world2_gloo(tmp_path):
+    """Per-rank lists with stealing (sharding.StealQueue, the pipeline's stage-6 hand-out): a rank takes its own items front to back, then items from the BACK
+    of the other rank's list; every item is fitted exactly once, the slow rank keeps a prefix of its own list, and reduce_rows_exact returns every
+    row from the rank that produced it bit for bit (incl. the sign of a zero)."""
+    import torch
+    from vistracker_amd.sharding import StealQueue, reduce_rows_exact
+    q = StealQueue([3], 0)
+    assert not q.shared and [q.next() for _ in range(5)] == [(0, 0), (0, 1), (0, 2), None, None]
+    t = torch.tensor([[-0.0, 1.5]]); assert reduce_rows_exact(t, torch.tensor([True])) is t
+    script = tmp_path / "s.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time, threading, torch, torch.distributed as dist
+        sys.path.insert(0, {ROOT!r})
+        from vistracker_amd.sharding import StealQueue, reduce_rows_exact
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        counts = [9, 2]                                   # rank 0 owns nine items, rank 1 two
+        base = [0, 9]
+        q = StealQueue(counts, r)
+        assert q.shared
+        mine = []; lock = threading.Lock()
+        def worker():
+            while True:
+                j = q.next()
+                if j is None: break
+                with lock: mine.append(j)
+                time.sleep(0.05 if r == 0 else 0.01)     # the rank with the long list is also the slow one
+        th = [threading.Thread(target=worker) for _ in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        table = torch.zeros(11, 2); filled = torch.zeros(11, dtype=torch.bool)
+        for o, i in mine:
+            table[base[o] + i] = torch.tensor([-0.0, float(base[o] + i + 1) * (1 if r == 0 else -1)]); filled[base[o] + i] = True
+        full = reduce_rows_exact(table, filled)
+        got = [None] * w; dist.all_gather_object(got, mine)
+        if r == 0:
+            allv = sorted(got[0] + got[1])
+            assert allv == [(0, i) for i in range(9)] + [(1, 0), (1, 1)], allv
+            own0 = sorted(i for o, i in got[0] if o == 0)
+            assert own0 == list(range(len(own0))) and all(o == 0 for o, _ in got[0])          # the slow rank kept a PREFIX of its own list, stole nothing
+            stolen = sorted(i for o, i in got[1] if o == 0)
+            assert len(stolen) >= 2 and stolen == list(range(9 - len(stolen), 9)), stolen       # the fast rank took from the BACK
+            assert q.stolen == 0
+            assert bool((full[:, 1].abs() == torch.arange(1, 12).float()).all()) and bool(torch.signbit(full[:, 0]).all())
+            print("STEAL_OK", len(got[0]), len(got[1]))
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29536", str(script)], capture_output=True, text=True, env=env, timeout=240)
+    assert "STEAL_OK" in out.stdout, out.stdout + out.stderr
+
+
 def test_config_loader_reads_reference_style_json(tmp_path):
     from vistracker_amd.config import load_configs, get_parser, merge_configs
     (tmp_path / "x.json").write_text('{\n "exp_name": "x", // comment\n "loadSize": 1200, "net_img_size": [512, 512], "z_feat": "smpl-triplane"\n}\n')

@@ -51,6 +51,9 @@ class PipelineConfig:
     # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
     fit_streams: int = 2
+    # N > 1 ranks: "static" = every rank fits the batches of its own frames; "steal" = a rank that runs out takes batches from the rank with the most left
+    # (sharding.StealQueue) and encodes their maps itself.  Same results either way.
+    fit_handout: str = "steal"
     # encode batch k + 1 on a second stream while the surface-point generator works on batch k (needs resident maps)
     overlap_encoder: bool = True
     args: SimpleNamespace = field(default_factory=lambda: SimpleNamespace(net_img_size=[512, 512], loadSize=1200, camera_params=None))
@@ -224,31 +227,62 @@ class SequencePipeline:
         out["hvop"], out["hvop_applied"] = self.infill.infill(smplt_pack, out["obj_smooth"]["obj_angles"], neural[:, 15])
         obj_rots = out["hvop"]["obj_angles"] if out["hvop_applied"] else out["obj_smooth"]["obj_angles"]
         lap("5_objrot_smooth_infill")
-        # 6  joint optimisation of this rank's batches, gather, pack
-        shards = sharding.batches_of(T, cfg.fit_bs, lo, hi)
-        rows = [None] * len(shards); steps = [None] * len(shards)
+        # 6  joint optimisation, gather, pack.  Static: this rank's batches (the frames whose maps stage 4 left in its HBM).  With the run-time hand-out
+        # (cfg.fit_handout = "steal", N > 1): a rank that runs out of its own batches takes batches from the BACK of the list of the rank with the
+        # most left and encodes their maps again (16-frame encoder passes: 0.26 s per 96 frames) -- the stop rules make a batch cost 734 .. 2580 Adam
+        # steps, so equal COUNTS are not equal work (README.md:50-52 / recon_fit_base.py:411-419 leave the split to the user).  Results do not depend
+        # on who fits what: a batch is an independent unit, its random stream is keyed by its first frame, the encoder is per-frame arithmetic.
+        all_shards = [sharding.batches_of(T, cfg.fit_bs, *sharding.frame_range(sharding.shard_units(T, cfg.neural_bs, cfg.fit_bs, world, r))) for r in range(world)]
+        shards = all_shards[rank]
+        steal = None
+        if world > 1 and cfg.fit_handout == "steal":
+            steal = sharding.StealQueue([len(x) for x in all_shards], rank)
+            if not steal.shared:
+                steal = None
+        rows = {}; steps = {}
+        import threading
+        log_lock = threading.Lock()
 
-        def fit_one(idx, fitter, generator):
-            s, e = shards[idx]
+        def fit_one(owner, idx, fitter, generator):
+            s, e = all_shards[owner][idx]
             smpl = SMPLHGenerator.get_smplh(poses[s:e], betas[s:e], trans[s:e], gender, self.device, model_root=self.model_dict)
             if not cfg.reuse_neural:            # the random stream is only drawn from when the surface points are generated again
                 generator.reseed(s)
-            bm = ops.FeatureMaps({k: t[s - lo:e - lo] for k, t in big.items()}) if resident else None
+            bm = None
+            if resident and owner == rank:
+                bm = ops.FeatureMaps({k: t[s - lo:e - lo] for k, t in big.items()})
+            elif resident and self.net.encoder is not None:      # a stolen batch: its maps live in another rank's HBM -> encode here
+                bm = self.net.encoder(images[s:e])
+                with log_lock:
+                    self.net.frames_encoded = getattr(self.net, "frames_encoded", 0) + (e - s)
             pcg = None
             if cfg.reuse_neural:
                 tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
                 pcg = {"object": {"pca_axis": tt(neural_dict["pca_axis"][s:e]), "centers": tt(neural_dict["centers"][s:e]), "visibility": tt(neural_dict["visibility"][s:e])}}
             pc, smpl, oR, ot, osc = fitter.fit_recon_batch(cfg.args, {k: v[s:e] for k, v in data.items()}, generator, smpl, self._t(seq["kpts_crop"][s:e]),
                                                           obj_rots=np.asarray(obj_rots[s:e], np.float32), maps=bm, pc_generated=pcg)
-            steps[idx] = (fitter.last["smpl"].steps, fitter.last["object"].steps)
-            rows[idx] = packing.to_rows(smpl.pose.data, smpl.betas.data, smpl.trans.data, oR.data, ot.data, osc)
+            with log_lock:
+                steps[s] = (fitter.last["smpl"].steps, fitter.last["object"].steps)
+                rows[s] = packing.to_rows(smpl.pose.data, smpl.betas.data, smpl.trans.data, oR.data, ot.data, osc)
+
+        def jobs_of(k, nworkers):
+            """the (owner, index) pairs worker k of this rank fits: its static share, or whatever the queue hands it"""
+            if steal is None:
+                for idx in range(k, len(shards), nworkers):
+                    yield rank, idx
+                return
+            while True:
+                j = steal.next()
+                if j is None:
+                    return
+                yield j
 
         nstream = cfg.fit_streams if (resident and cfg.reuse_neural and not self.fitter.profile) else 1
-        if nstream <= 1 or len(shards) <= 1:
-            for idx in range(len(shards)):
-                fit_one(idx, self.fitter, self.generator)
+        if nstream <= 1 or (len(shards) <= 1 and steal is None):
+            for owner, idx in jobs_of(0, 1):
+                fit_one(owner, idx, self.fitter, self.generator)
         else:
-            import copy, threading
+            import copy
             streams = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
@@ -262,8 +296,8 @@ class SequencePipeline:
                     fitter = copy.copy(self.fitter); fitter.last = {}
                     generator = copy.copy(self.generator); generator.model = copy.copy(self.generator.model)
                     with torch.cuda.stream(streams[k]):
-                        for idx in range(k, len(shards), nstream):
-                            fit_one(idx, fitter, generator)
+                        for owner, idx in jobs_of(k, nstream):
+                            fit_one(owner, idx, fitter, generator)
                 except BaseException as ex:      # re-raised in the caller's thread
                     errors.append(ex)
 
@@ -274,9 +308,16 @@ class SequencePipeline:
                 torch.cuda.current_stream().wait_stream(st)
             if errors:
                 raise errors[0]
-        self.log.setdefault("fit_steps", []).extend(steps)
-        local = torch.cat(rows, 0) if rows else torch.zeros(0, packing.ROW_WIDTH, device=self.device)
-        full = self._gather(local, T, unit)
+        self.log.setdefault("fit_steps", []).extend(steps[s_] for s_ in sorted(steps))
+        self.log["fit_batches"] = sorted(rows); self.log["stolen_batches"] = steal.stolen if steal is not None else 0
+        if steal is None:
+            local = torch.cat([rows[s_] for s_ in sorted(rows)], 0) if rows else torch.zeros(0, packing.ROW_WIDTH, device=self.device)
+            full = self._gather(local, T, unit)
+        else:
+            table = torch.zeros(T, packing.ROW_WIDTH, device=self.device); filled = torch.zeros(T, dtype=torch.bool, device=self.device)
+            for s_, r_ in rows.items():
+                table[s_:s_ + r_.shape[0]] = r_; filled[s_:s_ + r_.shape[0]] = True
+            full = sharding.reduce_rows_exact(table, filled)
         self.log["frames_encoded"] = getattr(self.net, "frames_encoded", 0) - enc0
         out["recon"] = packing.pack_recon(full, frames, gender, cfg.save_name, self.ctx.smpl, neural=neural_dict)
         lap("6_joint_fit")

@@ -104,3 +104,95 @@ class WorkQueue:
         else:
             k = int(self.store.add(self.key, 1)) - 1
         return self.order[k] if k < self.n else None
+
+
+class StealQueue:
+    """Per-rank work lists with stealing: a rank takes its OWN items from the front (the batches whose feature maps it holds) and, when it has none
+    left, takes items from the BACK of the list of the rank with the most left (paying whatever the caller pays for a foreign item -- the pipeline
+    encodes the stolen batch's maps again, 0.26 s against a 0.65 .. 2.8 s fit).
+
+    One packed atomic counter per owner in the process group's store: low ``SHIFT`` bits = items taken from the front, high bits = items taken from
+    the back; ``store.add`` returns the value AFTER the add, a consistent snapshot of both, and a take is valid iff front + back <= count -- an
+    overshooting take leaves the list exhausted for everybody, which it already was.  No collective, no server thread; without a process group the
+    counters are local (a world of one rank never steals).  Every rank must construct its queues in the same order (the keys are numbered)."""
+    SHIFT = 20
+    MASK = (1 << 20) - 1
+    _serial = 0
+
+    def __init__(self, counts, rank: int, name: str = "vt_stealqueue"):
+        import threading
+        self.counts = [int(c) for c in counts]; self.rank = int(rank)
+        assert max(self.counts + [0]) <= self.MASK
+        StealQueue._serial += 1
+        self.keys = [f"{name}/{StealQueue._serial}/{r}" for r in range(len(self.counts))]
+        self._lock = threading.Lock(); self._local = [0] * len(self.counts); self._own_empty = False
+        self.store = None
+        self.stolen = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from torch.distributed import distributed_c10d as c10d
+                self.store = c10d._get_default_store()
+        except Exception:          # noqa: BLE001 -- no store: local counters, nobody else sees them; the caller must not rely on stealing then
+            self.store = None
+
+    @property
+    def shared(self) -> bool:
+        return self.store is not None
+
+    def _add(self, r, inc):
+        if self.store is not None:
+            return int(self.store.add(self.keys[r], inc))
+        with self._lock:
+            self._local[r] += inc
+            return self._local[r]
+
+    def _split(self, v):
+        return v & self.MASK, v >> self.SHIFT
+
+    def next(self):
+        """-> (owner rank, index in the owner's list) or None when every list is exhausted"""
+        if not self._own_empty:
+            f, b = self._split(self._add(self.rank, 1))
+            if f + b <= self.counts[self.rank]:
+                return self.rank, f - 1
+            self._own_empty = True
+        if self.store is None:
+            return None
+        while True:
+            best = None
+            for r in range(len(self.counts)):
+                if r == self.rank:
+                    continue
+                f, b = self._split(self._add(r, 0))
+                left = self.counts[r] - f - b
+                if left > 0 and (best is None or left > best[0]):
+                    best = (left, r)
+            if best is None:
+                return None
+            r = best[1]
+            f, b = self._split(self._add(r, 1 << self.SHIFT))
+            if f + b <= self.counts[r]:
+                with self._lock:
+                    self.stolen += 1
+                return r, self.counts[r] - b
+            # lost the race for that owner's last item: look again
+
+
+def reduce_rows_exact(table, filled_rows):
+    """Every rank holds ``table`` (T, D) float32 with the rows it produced (``filled_rows``: bool (T,)) and zeros elsewhere; returns the table with every
+    row from the rank that produced it, bit for bit (the sum runs on the int32 view: adding integer zeros cannot change a bit pattern, not even the sign
+    of a zero), and checks that every row was produced exactly once."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        assert bool(filled_rows.all()), "rows missing"
+        return table
+    via_host = table.is_cuda and dist.get_backend() == "gloo"
+    bits = table.contiguous().view(torch.int32).clone(); cnt = filled_rows.to(torch.int32).clone()
+    bits[~filled_rows] = 0
+    if via_host:
+        bits, cnt = bits.cpu(), cnt.cpu()
+    dist.all_reduce(bits); dist.all_reduce(cnt)
+    assert bool((cnt == 1).all()), "a batch was fitted by no rank or by two"
+    return bits.to(table.device).view(torch.float32)
