@@ -15,6 +15,12 @@ f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_ou
 # average includes them; the per-dispatch trace gives the average of the launches that did the work (what bench.py's avg_launch_ms measures)
 t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/trace_summary.py $t "query_kernel<2, 2" "query_kernel<1, 3" > gpurun_out/${tag}_query_launches_1stream.json && cat gpurun_out/${tag}_query_launches_1stream.json
 tail -3 gpurun_out/${tag}_prof.log
+# the same trace of the DEFAULT command's timed configuration (two batches in flight): the average the bench line reports as roofline.avg_launch_ms
+d=$(mktemp -d /tmp/prof2.XXXX)
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-extras --no-cpu-baseline ) > gpurun_out/${tag}_prof2.log 2>&1
+f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats.csv && head -4 $f
+t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/trace_summary.py $t "query_kernel<2, 2" "query_kernel<1, 3" > gpurun_out/${tag}_query_launches.json && cat gpurun_out/${tag}_query_launches.json
+grep -h '^{' gpurun_out/${tag}_prof2.log | python -c "import sys, json; [print('bench under the profiler: avg_launch_ms', json.loads(l)['roofline']['avg_launch_ms']) for l in sys.stdin]"
 # HBM-side traffic of the query kernels: separate --pmc passes (FETCH_SIZE / WRITE_SIZE do not fit one pass), one stream, one batch
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(mktemp -d /tmp/pmc.XXXX)
