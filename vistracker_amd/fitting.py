@@ -171,6 +171,44 @@ def morton_order_device(p: torch.Tensor) -> torch.Tensor:
     return torch.argsort(key, stable=True).to(torch.int32)
 
 
+class _StopWatch:
+    """FitContext._stop_watch: the device-side stop flag as the launching thread sees it.  Without look-ahead ``check()`` is a stream synchronisation (the
+    flag of the iteration just queued).  With it, ``check()`` queues an asynchronous copy of the flag to pinned memory and an event behind the iteration
+    just queued and waits for the PREVIOUS iteration's event: one iteration of launches always stands between the host and the GPU."""
+    _tls = threading.local()
+
+    def __init__(self, ctx, stop, lookahead):
+        self.ctx, self.stop, self.look = ctx, stop, lookahead
+        self.pending = None; self.n = 0
+        if lookahead:
+            pool = getattr(self._tls, "pool", None)        # pinned words + events are per launching thread, reused by its (sequential) fits
+            if pool is None or pool[0] != stop.device:
+                pool = (stop.device, torch.zeros(2, dtype=torch.int32).pin_memory(), [torch.cuda.Event(), torch.cuda.Event()])
+                self._tls.pool = pool
+            _, self.host, self.ev = pool
+
+    def _wait(self, k):
+        t0 = time.perf_counter()
+        self.ev[k].synchronize()
+        with self.ctx._counter_lock:
+            self.ctx.host_wait_s += time.perf_counter() - t0
+        return bool(int(self.host[k]))
+
+    def check(self):
+        if not self.look:
+            return bool(self.ctx._read_stop(self.stop))
+        k = self.n & 1; self.n += 1
+        self.host[k:k + 1].copy_(self.stop, non_blocking=True); self.ev[k].record()
+        prev, self.pending = self.pending, k
+        return prev is not None and self._wait(prev)
+
+    def final(self):
+        if not self.look or self.pending is None:
+            return False
+        k, self.pending = self.pending, None
+        return self._wait(k)
+
+
 class FitContext:
     """Device-resident constants shared by all batches of a sequence: SMPL-H model, body25 regressor, priors,
     SIF-Net decoders, part labels, object template / surface samples."""
@@ -192,6 +230,11 @@ class FitContext:
     fused_smpl_query = os.environ.get("VT_FUSED_SMPL_QUERY", "0") != "0"
     # the query / SMPL-H launches queued behind the step that stopped a fit return at their first instruction (vt_stream_set_skip_flag)
     device_skip = os.environ.get("VT_DEVICE_SKIP", "1") != "0"
+    # the host looks at the stop flag of outer iteration k only after it has queued iteration k + 1 (asynchronous copy of the flag to pinned memory + an
+    # event per iteration): the stream never runs dry while the launching thread wakes up, takes the GIL and queues the next launches -- the bubble a
+    # slow or contended host (8 ranks x 2 launching threads on one node) pays once per outer iteration.  Needs the device-side skip: the iteration
+    # queued behind a stop then costs ~100 launches that return at once instead of ten Adam steps; results are unchanged either way.
+    stop_lookahead = os.environ.get("VT_STOP_LOOKAHEAD", "1") != "0"
 
     def __init__(self, smpl_model, regressors, priors, decoders=None, part_labels=None, obj_verts=None, obj_faces=None, obj_points=None,
                  cam=ops.DEFAULT_CAM, device="cuda:0"):
@@ -308,7 +351,8 @@ class FitContext:
         temporal = temporal and B >= 3
         adam = None
         res = FitResult()
-        with self._skip_after_stop(stop):
+        with self._skip_after_stop(stop) as skipping:
+            watch = self._stop_watch(stop, skipping)
             for it in range(start, end):
                 if adam is None or it == iter_for_global:
                     if it < iter_for_global:      # init_globalpose_optimizer: trans, global_pose, top_betas
@@ -336,12 +380,14 @@ class FitContext:
                                                         stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
+                if (it - start) % check_every == check_every - 1 and watch.check():
                     res.stopped_early = True
                     break
+            res.stopped_early = res.stopped_early or watch.final()
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+            res.outer_iters = -(-res.steps // 10)          # (with the look-ahead one more iteration was queued; its launches returned at once)
         _check_finite(res, "fit")
         return res
 
@@ -391,7 +437,8 @@ class FitContext:
         hist = torch.full(((end - start) * 10,), float("nan"), device=dev)
         arm_after = 0.25 * max_iter + iter_for_betas + iter_for_pose
         adam = None; res = FitResult()
-        with self._skip_after_stop(stop):
+        with self._skip_after_stop(stop) as skipping:
+            watch = self._stop_watch(stop, skipping)
             for it in range(start, end):
                 if it < iter_for_betas:
                     phase = "global"
@@ -448,12 +495,14 @@ class FitContext:
                                                             stop.data_ptr(), hist.data_ptr(), (it - start) * 10 + i, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
+                if (it - start) % check_every == check_every - 1 and watch.check():
                     res.stopped_early = True
                     break
+            res.stopped_early = res.stopped_early or watch.final()
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+            res.outer_iters = -(-res.steps // 10)          # (with the look-ahead one more iteration was queued; its launches returned at once)
         _flush_events(prof, lp, res.steps if (res.stopped_early and self.device_skip) else None)
         _check_finite(res, "fit")
         return res
@@ -505,7 +554,8 @@ class FitContext:
         # -- zero for the obj_s == 1 that fit_recon passes -- but it is part of the summed loss the stop rule looks at
         ones = torch.ones_like(obj_s)
         _chk(_lib().vt_sqdiff_loss(obj_s.data_ptr(), 1, ones.data_ptr(), 1, B, 1, float(B), 0.0, terms.ptr("scale"), None, L.stream_ptr()))
-        with self._skip_after_stop(stop):
+        with self._skip_after_stop(stop) as skipping:
+            watch = self._stop_watch(stop, skipping)
             for it in range(start, end):
                 if it < iter_for_obj:
                     phase = "object only"
@@ -587,12 +637,14 @@ class FitContext:
                                                         state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, L.stream_ptr()))
                     res.steps += 1
                 res.outer_iters += 1
-                if (it - start) % check_every == check_every - 1 and self._read_stop(stop):
+                if (it - start) % check_every == check_every - 1 and watch.check():
                     res.stopped_early = True
                     break
+            res.stopped_early = res.stopped_early or watch.final()
         res.losses = hist.cpu().numpy()
         if res.stopped_early:
             res.steps = int(np.isfinite(res.losses).sum())
+            res.outer_iters = -(-res.steps // 10)          # (with the look-ahead one more iteration was queued; its launches returned at once)
         _flush_events(prof, lp, res.steps if (res.stopped_early and self.device_skip) else None)
         _check_finite(res, "fit")
         return res
@@ -614,17 +666,22 @@ class FitContext:
         iteration -- cost a launch each instead of a pass (results unchanged: Adam and the loss history ignore them already).  The callers drop the
         per-launch events of those no-op launches from a profiled run, so that bench.py prices executed launches only."""
         if not self.device_skip:
-            yield
+            yield False
             return
         sp = L.stream_ptr()
         if _lib().vt_stream_set_skip_flag(sp, stop.data_ptr()) != 0:
             # this thread already has another fit's flag registered for the stream (nested fits): run without the device-side skip
-            yield
+            yield False
             return
         try:
-            yield
+            yield True
         finally:
             _lib().vt_stream_set_skip_flag(sp, None)
+
+    def _stop_watch(self, stop, skipping):
+        """the host's view of the stop flag for one fit: with the look-ahead (needs ``skipping``, the device-side skip) ``check()`` after queuing outer
+        iteration k answers for iteration k - 1; ``final()`` after the loop answers for whatever has not been looked at"""
+        return _StopWatch(self, stop, bool(skipping and self.stop_lookahead))
 
     def _smpl_tail(self, pose, pose_init, dpose, B, w, terms, names, adam, state, stop, hist, slot, ticket, armed):
         """body prior + pinit + Adam on every group + loss reduction / stop rule + term zeroing: one launch (vt_smplstep_tail)"""
