@@ -319,6 +319,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
+    ap.add_argument("--stagger", type=float, default=None,
+                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region).  MEASURED NULL (profiles/r04_stream_stagger.txt): "
+                         "streams that start together stay in lockstep (equal batch times), but 0 .. 0.6 s of offset all give 141-142 frames/s -- the chip's "
+                         "capacity, not the phase of the two streams, is the limit.  Default: none")
     ap.add_argument("--object-priority", type=int, default=0, help="HIP stream priority of the object-stage stream of --schedule staged (-1 = high)")
     ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
                     help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
@@ -402,9 +406,11 @@ def main():
         my_jobs = list(range(args.steps)); total_frames = world * args.steps * BATCH
     # test hook: this job index runs the reference's maximum schedule (stop rules off) -- a batch 3.5 x as expensive as its neighbours
     heavy = int(os.environ.get("VT_BENCH_FULL_SCHEDULE_BATCH", "-1"))
+    warm_s = None
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
-        fit_batch(ctx, torch, d); del d
+        tw = time.perf_counter(); fit_batch(ctx, torch, d); torch.cuda.synchronize(); warm_s = time.perf_counter() - tw; del d
+    stagger = args.stagger if (args.stagger is not None and args.streams > 1) else 0.0
     batches = [run(i) for i in my_jobs]                    # inputs resident in HBM before the timed region
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events
@@ -412,6 +418,7 @@ def main():
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
+    done_at = {}            # batch position -> seconds after t0 at which its fit returned on the host (rank 0's own; shows a ramp inside the timed region)
     fitted = list(range(len(batches)))          # positions in ``batches`` this rank fitted (static: all of them)
     if dynamic:
         import threading
@@ -422,12 +429,14 @@ def main():
 
         def pull_worker(k):
             torch.cuda.set_device(dev)
+            if k and stagger > 0:
+                time.sleep(k * stagger)
             with torch.cuda.stream(streams[k]):
                 while True:
                     i = queue.next()
                     if i is None:
                         break
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy)); fitted.append(i)
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy)); fitted.append(i); done_at[i] = time.perf_counter() - t0
                 streams[k].synchronize()
         th_ = [threading.Thread(target=pull_worker, args=(k,)) for k in range(len(streams))]
         for t_ in th_: t_.start()
@@ -449,9 +458,11 @@ def main():
         def worker(k):
             torch.cuda.set_device(dev)
             so = torch.cuda.Stream(device=dev, priority=args.object_priority) if args.object_priority else None
+            if k and stagger > 0:
+                time.sleep(k * stagger)          # inside the timed region: see --stagger
             with torch.cuda.stream(streams[k]):
                 for i in range(k, len(batches), args.streams):
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy), obj_stream=so)
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy), obj_stream=so); done_at[i] = time.perf_counter() - t0
 
         ready = [threading.Event() for _ in batches]; half = [None] * len(batches)
 
@@ -624,7 +635,8 @@ def main():
                        "sharding": ((f"{args.steps} batches handed out at run time from one shared counter (longest first) to {world} rank(s), every rank holding all inputs" if dynamic else
                                      f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)") if strong
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU",
-                       "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs},
+                       "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs,
+                       "stagger_s": round(stagger, 3), "batch_done_s_rank0": [round(done_at[k], 3) for k in sorted(done_at)]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
                          "traffic": pmc_traffic_bytes(), "traffic_unit": f"B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(pmc_file() or 'none')})",
