@@ -320,9 +320,8 @@ def main():
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
     ap.add_argument("--stagger", type=float, default=None,
-                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region).  MEASURED NULL (profiles/r04_stream_stagger.txt): "
-                         "streams that start together stay in lockstep (equal batch times), but 0 .. 0.6 s of offset all give 141-142 frames/s -- the chip's "
-                         "capacity, not the phase of the two streams, is the limit.  Default: none")
+                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region; 0 = together).  Default: a fifth of the warm-up "
+                         "batch's time (0.15 s without warm-up) -- see the comment where it is applied and profiles/r04_stream_stagger.txt")
     ap.add_argument("--object-priority", type=int, default=0, help="HIP stream priority of the object-stage stream of --schedule staged (-1 = high)")
     ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
                     help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
@@ -410,7 +409,13 @@ def main():
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
         tw = time.perf_counter(); fit_batch(ctx, torch, d); torch.cuda.synchronize(); warm_s = time.perf_counter() - tw; del d
-    stagger = args.stagger if (args.stagger is not None and args.streams > 1) else 0.0
+    # start offset between the streams of a rank: batches take the same time, so streams that start together stay in LOCKSTEP -- they drain at the same
+    # moments (stage boundaries, contact sets, loss histories) and the host sections behind those drains are then exposed on both at once.  A fraction of a
+    # batch apart (0.15 s is enough, the offset then grows by itself), one stream's launches cover the other's host sections.  Worth nothing on a warm host (141-142 frames/s for 0 .. 0.6 s) and 7 % in the first
+    # process of a freshly booted box, where those host sections are slow (profiles/r04_stream_stagger.txt: 130-135 -> 142-143 frames/s)
+    stagger = 0.0
+    if args.streams > 1:
+        stagger = args.stagger if args.stagger is not None else (0.2 * warm_s if warm_s is not None else 0.15)
     batches = [run(i) for i in my_jobs]                    # inputs resident in HBM before the timed region
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events

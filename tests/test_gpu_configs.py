@@ -33,6 +33,23 @@ def test_sifnet_inference_at_config3_size(synth):
         got = t[0, ::st, ::st].cpu().numpy()
         e = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
         assert e < 2e-4, (name, e)                                         # fp32 convolutions, MIOpen vs CPU summation order (same bar as the 64 x 64 test)
+    # the 16-frame chunk went through the captured HIP graph (SIFNetEncoder.use_graph): the eager pass gives the same maps bit for bit, a second replay
+    # (other images in the static input buffer in between) too, and 40 frames = two replays + one zero-padded replay land where the eager chunks land
+    enc = net.encoder
+    assert enc.use_graph and enc._graph not in (None, False), "the encoder pass was not captured"
+    maps_graph = [t.clone() for t in net.maps.t]
+    enc.use_graph = False
+    try:
+        net.filter(images)
+        assert all(torch.equal(a, b) for a, b in zip(maps_graph, net.maps.t)), "graph replay differs from the eager pass"
+        imgs40 = torch.cat([images.flip(0), images, images[:8]], 0)
+        net.filter(imgs40); maps40_eager = [t.clone() for t in net.maps.t]
+    finally:
+        enc.use_graph = True
+    net.filter(imgs40)
+    assert all(torch.equal(a, b) for a, b in zip(maps40_eager, net.maps.t))
+    net.filter(images)
+    assert all(torch.equal(a, b) for a, b in zip(maps_graph, net.maps.t))
     # a batch of 16 is encoded in one 16-frame chunk: frame 0 alone gives the same maps
     net1 = demo_inputs.sifnet(synth["decoders"]); net1.filter(images[:1])
     assert all(torch.allclose(a[0], b[0], atol=1e-5, rtol=1e-5) for a, b in zip(net.maps.t, net1.maps.t))

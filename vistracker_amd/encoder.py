@@ -20,6 +20,8 @@ Architecture restated from the reference (stacked hourglass, group norm):
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -347,23 +349,84 @@ class SIFNetEncoder:
             if n < self.chunk and (B > self.chunk or self._full_chunk_seen):     # reuse the shapes MIOpen already has kernels for
                 x = torch.cat([x, torch.zeros(self.chunk - n, *x.shape[1:], device=x.device)], 0)
             self._full_chunk_seen = self._full_chunk_seen or x.shape[0] == self.chunk
-            feats, tmpx, _ = self.image(x[:, :5])
-            maps = {"im_feat": feats[-1], "tmpx": tmpx}
-            if self.tri[0] is self.tri[1] and self.tri[1] is self.tri[2]:
-                # shared triplane encoder (chore_triplane.py:60-95 applies the same module to the three renders): ONE pass over the 3 x chunk
-                # single-channel images instead of three -- every op of the encoder is per frame, so the maps are the same; the launches are
-                # three times larger (the 16-frame ones leave the chip half empty at the 1/4- and 1/8-resolution levels of the hourglass)
-                nb = x.shape[0]
-                f, t, _ = self.tri[0](x[:, 5:8].transpose(0, 1).reshape(3 * nb, 1, *x.shape[2:]))
-                for v in range(3):
-                    maps[f"tri_tmpx{v}"] = t[v * nb:(v + 1) * nb]; maps[f"tri_feat{v}"] = f[-1][v * nb:(v + 1) * nb]
+            graph_done = None
+            if self.use_graph and x.is_cuda and x.shape[0] == self.chunk:
+                maps, graph_done = self._chunk_graph(x)
             else:
-                for v in range(3):
-                    f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
-                    maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
+                maps = self._chunk_eager(x)
             if out is None:
                 # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from; written per chunk
                 out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}
-            for k, m in maps.items():
-                out[k][s0:s0 + n] = m[:n].permute(0, 2, 3, 1)
+            try:
+                for k, m in maps.items():
+                    out[k][s0:s0 + n] = m[:n].permute(0, 2, 3, 1)
+            finally:
+                if graph_done is not None:
+                    graph_done()
         return ops.FeatureMaps(out)
+
+    def _chunk_eager(self, x):
+        """one chunk of frames through both encoders -> the eight maps as channels-last NCHW tensors"""
+        feats, tmpx, _ = self.image(x[:, :5])
+        maps = {"im_feat": feats[-1], "tmpx": tmpx}
+        if self.tri[0] is self.tri[1] and self.tri[1] is self.tri[2]:
+            # shared triplane encoder (chore_triplane.py:60-95 applies the same module to the three renders): ONE pass over the 3 x chunk
+            # single-channel images instead of three -- every op of the encoder is per frame, so the maps are the same; the launches are
+            # three times larger (the 16-frame ones leave the chip half empty at the 1/4- and 1/8-resolution levels of the hourglass)
+            nb = x.shape[0]
+            f, t, _ = self.tri[0](x[:, 5:8].transpose(0, 1).reshape(3 * nb, 1, *x.shape[2:]))
+            for v in range(3):
+                maps[f"tri_tmpx{v}"] = t[v * nb:(v + 1) * nb]; maps[f"tri_feat{v}"] = f[-1][v * nb:(v + 1) * nb]
+        else:
+            for v in range(3):
+                f, t, _ = self.tri[v](x[:, 5 + v:6 + v])
+                maps[f"tri_tmpx{v}"] = t; maps[f"tri_feat{v}"] = f[-1]
+        return maps
+
+    # A full chunk is ~650 launches (two stacked hourglasses of fused ConvBlocks) issued from Python; in the pipeline's SIF-Net pass they come from a
+    # second host thread while the first one drives the surface-point generator's rounds (two host round trips each), and the two contend for the
+    # interpreter.  The chunk is therefore captured ONCE as a HIP graph (fixed shape: ``chunk`` frames) and replayed: one launch call per chunk, the
+    # same kernels on the same data (bit-identical maps).  The static input / output buffers are shared by all callers: a lock serialises the hosts,
+    # an event orders a replay behind the previous caller's copies out of the static outputs.  VT_ENCODER_GRAPH=0: eager.
+    use_graph = os.environ.get("VT_ENCODER_GRAPH", "1") != "0"
+    _graph = None
+
+    def _chunk_graph(self, x):
+        import threading
+        lock = self.__dict__.setdefault("_graph_lock", threading.Lock())
+        lock.acquire()
+        try:
+            ent = self._graph
+            if ent is None:
+                try:
+                    sx = x.clone()
+                    side = torch.cuda.Stream(device=x.device); side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._chunk_eager(sx)              # outside the capture: weight uploads, MIOpen's kernel choice for the stem, workspaces
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize(x.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        so = self._chunk_eager(sx)
+                    ent = (g, sx, so, torch.cuda.Event())
+                    ent[3].record()
+                except Exception as e:                      # noqa: BLE001 -- something in the pass cannot be captured on this build: stay eager, say so once
+                    import warnings
+                    warnings.warn(f"SIFNetEncoder: HIP-graph capture of the encoder pass failed ({type(e).__name__}: {e}); running it eagerly")
+                    ent = False
+                self._graph = ent
+            if ent is False or ent[1].shape != x.shape:
+                lock.release()
+                return self._chunk_eager(x), None
+            g, sx, so, ev = ent
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)                              # the previous caller has copied the static outputs out
+            sx.copy_(x)
+            g.replay()
+
+            def done():
+                ev.record(); lock.release()
+            return so, done
+        except BaseException:
+            lock.release()
+            raise

@@ -51,6 +51,9 @@ class PipelineConfig:
     # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
     fit_streams: int = 2
+    # start offset (seconds) of stream k of the joint fit after stream k - 1: streams that start together stay in lockstep (equal batch times) and drain at
+    # the same moments, exposing the host sections behind the drains on all of them at once -- 7 % in a cold process (profiles/r04_stream_stagger.txt)
+    fit_stagger_s: float = 0.15
     # N > 1 ranks: "static" = every rank fits the batches of its own frames; "steal" = a rank that runs out takes batches from the rank with the most left
     # (sharding.StealQueue) and encodes their maps itself.  Same results either way.
     fit_handout: str = "steal"
@@ -295,6 +298,8 @@ class SequencePipeline:
                     torch.cuda.set_device(self.device)
                     fitter = copy.copy(self.fitter); fitter.last = {}
                     generator = copy.copy(self.generator); generator.model = copy.copy(self.generator.model)
+                    if k and cfg.fit_stagger_s > 0:
+                        time.sleep(k * cfg.fit_stagger_s)
                     with torch.cuda.stream(streams[k]):
                         for owner, idx in jobs_of(k, nstream):
                             fit_one(owner, idx, fitter, generator)
