@@ -406,7 +406,8 @@ class SIFNetEncoder:
                     torch.cuda.current_stream().wait_stream(side)
                     torch.cuda.synchronize(x.device)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # (thread_local: another host thread -- the pipeline's generator or a second fit stream -- may allocate or synchronise meanwhile)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         so = self._chunk_eager(sx)
                     ent = (g, sx, so, torch.cuda.Event())
                     ent[3].record()
