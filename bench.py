@@ -131,16 +131,28 @@ def sil_setup(ctx, d):
                       net_input_size=512).setup()
 
 
+import threading as _threading
+SECTION_S = {}; SECTION_LOCK = _threading.Lock()
+
+
 def fit_batch(ctx, torch, d, prof=None, early_stop=True, obj_stream=None):
     """The hot path over one batch: SMPL stage then object stage (recon/recon_fit_triplane.py:70-106).  ``obj_stream``: run the object stage on
     that stream (stream-ordered after the SMPL stage, the caller's stream waits for it) -- the --object-priority experiment."""
     from vistracker_amd import ops
+    t_a = time.perf_counter()
     r1 = ctx.optimize_smpl(d["maps"], d["pose"], d["betas"], d["trans"], d["cc"], d["bc"], d["kp"], prof=prof, early_stop=early_stop)
+    t_b = time.perf_counter()
     with torch.no_grad():
         verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
     if obj_stream is None:
-        r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil_setup(ctx, d), seed=1, prof=prof,
+        sil = sil_setup(ctx, d)
+        t_c = time.perf_counter()
+        r2 = ctx.optimize_smpl_object(d["maps"], verts, d["obj_R"], d["obj_t"], d["obj_s"], d["cc"], d["bc"], d["occ"], sil=sil, seed=1, prof=prof,
                                       early_stop=early_stop)
+        # host-side seconds of the three sections of a batch (each fit ends with a stream synchronisation): where a slow host shows up
+        with SECTION_LOCK:
+            for k_, v_ in (("smpl_stage", t_b - t_a), ("between_stages", t_c - t_b), ("object_stage", time.perf_counter() - t_c)):
+                SECTION_S[k_] = SECTION_S.get(k_, 0.0) + v_
         return r1, r2
     cur = torch.cuda.current_stream(); obj_stream.wait_stream(cur)
     with torch.cuda.stream(obj_stream):
@@ -422,6 +434,7 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    SECTION_S.clear()
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
     done_at = {}            # batch position -> seconds after t0 at which its fit returned on the host (rank 0's own; shows a ramp inside the timed region)
     fitted = list(range(len(batches)))          # positions in ``batches`` this rank fitted (static: all of them)
@@ -503,6 +516,7 @@ def main():
         for s_ in streams:
             torch.cuda.current_stream().wait_stream(s_)
     torch.cuda.synchronize(); my_seconds = time.perf_counter() - t0      # this rank's own work (before it waits for the others)
+    section_s = {k_: round(v_, 3) for k_, v_ in SECTION_S.items()}
     rows_of = lambda d: torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(-1, 9), d["obj_t"], d["obj_s"][:, None]], 1)
     job_rows = None
     if use_dist and dynamic:
@@ -616,6 +630,21 @@ def main():
             else:
                 cur_e = max(cur_e, e_)
         busy += (cur_e - cur_s) if cur_e is not None else 0.0
+        # ... and, when the streams are out of phase, a launch of this kernel shares the chip with the OTHER chip-filling kernel of the path, the one-head
+        # query of the other batch's object stage (10 368 and 4 512 workgroups for 512-768 slots): a sweep over the boundaries of both kernels' per-launch
+        # intervals charges this kernel n_h / (n_h + n_o) of every segment in which n_h of its launches and n_o of the other's are executing.  Equal to the
+        # union when the two never overlap (streams in lockstep, one stream); the silhouette / SMPL-H kernels it also shares the chip with stay charged to it.
+        ev_ = [(t_, +1, 0) for t_, _ in iv] + [(t_, -1, 0) for _, t_ in iv]
+        for a_, b_, _ in prof["object"]:
+            ev_ += [(base_ev.elapsed_time(a_) * 1e-3, +1, 1), (base_ev.elapsed_time(b_) * 1e-3, -1, 1)]
+        ev_.sort(key=lambda x: (x[0], x[1]))
+        share, nrun, tprev = 0.0, [0, 0], None
+        for t_, d_, k_ in ev_:
+            if tprev is not None and nrun[0] > 0:
+                share += (t_ - tprev) * nrun[0] / (nrun[0] + nrun[1])
+            nrun[k_] += d_; tprev = t_
+        busy_union = busy
+        busy = share if share > 0 else busy
         eff = busy / max(len(iv), 1)                       # effective time per launch
         ach = flops_all / busy / 1e12 if busy > 0 else 0.0
         solo = extras.get("solo_launch_s") if isinstance(extras.get("solo_launch_s"), float) else None
@@ -641,7 +670,7 @@ def main():
                                      f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)") if strong
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU",
                        "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs,
-                       "stagger_s": round(stagger, 3), "batch_done_s_rank0": [round(done_at[k], 3) for k in sorted(done_at)]},
+                       "stagger_s": round(stagger, 3), "host_section_seconds_rank0": section_s, "batch_done_s_rank0": [round(done_at[k], 3) for k in sorted(done_at)]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",
                          "traffic": pmc_traffic_bytes(), "traffic_unit": f"B/launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{os.path.basename(pmc_file() or 'none')})",
@@ -651,8 +680,11 @@ def main():
                          # rocprofv3 kernel trace reports (profiles/rNN_kernel_stats_1stream.csv)
                          "solo_launch_ms": None if solo is None else 1e3 * solo,
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
-                         "achieved_note": "algorithmic FLOPs of all launches / time with >= 1 launch of the kernel executing (interval union of the "
-                                          "per-launch HIP events); equals flop_per_launch / avg_launch_ms when --streams 1",
+                         "frac_union": (flops_all / busy_union / 1e12 / PEAK_SPLIT_TFLOPS) if busy_union > 0 else None,
+                         "achieved_note": "algorithmic FLOPs of all launches / the kernel's share of the time in which it was executing: per-launch HIP events of both "
+                                          "query kernels, a segment with n_h launches of this kernel and n_o of the object stage's one-head query executing counts "
+                                          "n_h / (n_h + n_o) of its length; frac_union counts such segments in full (the definition of rounds 2-3: the same number "
+                                          "when the streams run in lockstep); both equal flop_per_launch / avg_launch_ms when --streams 1",
                          "launches": int(len(th)), "flop_per_launch": flops_h, "flop_all_launches": flops_all,
                          "mfma_flop_per_launch": FLOP_PER_POINT_HUMAN_MFMA * BATCH * 6890,
                          "frac_mfma_executed": ach * FLOP_PER_POINT_HUMAN_MFMA / FLOP_PER_POINT_HUMAN / PEAK_SPLIT_TFLOPS,

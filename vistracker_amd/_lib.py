@@ -140,7 +140,25 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        _host_tuning()
     return _lib
+
+
+def _host_tuning():
+    """Transparent huge pages off for this process (``prctl(PR_SET_THP_DISABLE)``; ``VT_HOST_THP=keep`` leaves them alone).
+
+    Measured on the MI355X boxes (THP mode "madvise", 3 TB / 256 cores): the FIRST process after the box comes up runs the fit 7 % slower than
+    every later one -- same kernel times, +63 ms of host time per batch in the object stage, +30 ms between the stages -- eight times out of eight;
+    with THP disabled for the process, or after touching and freeing 16 GB of anonymous memory first (2 GB is not enough), the first process runs
+    at the later ones' speed (profiles/r04_cold_process.txt).  The madvise'd host allocations of the launch path (runtime pools, numpy / torch
+    staging arrays) fault in as 2 MB pages, whose first allocation on a machine with a fragmented free list stalls the faulting thread in
+    compaction -- the launching thread, while its stream drains.  Nothing on the host side of this library gains from huge pages."""
+    if os.environ.get("VT_HOST_THP", "off") == "keep":
+        return
+    try:
+        C.CDLL(None, use_errno=True).prctl(41, 1, 0, 0, 0)          # PR_SET_THP_DISABLE: checked at fault time, covers the mappings that exist already
+    except Exception:          # noqa: BLE001 -- not Linux / no prctl: nothing to tune
+        pass
 
 
 def check(rc: int):
