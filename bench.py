@@ -332,8 +332,8 @@ def main():
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
     ap.add_argument("--stagger", type=float, default=None,
-                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region; 0 = together).  Default: a fifth of the warm-up "
-                         "batch's time (0.15 s without warm-up) -- see the comment where it is applied and profiles/r04_stream_stagger.txt")
+                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region); default 0 = together "
+                         "(profiles/r04_stream_stagger.txt: no effect on a warm host)")
     ap.add_argument("--object-priority", type=int, default=0, help="HIP stream priority of the object-stage stream of --schedule staged (-1 = high)")
     ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
                     help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
@@ -421,13 +421,13 @@ def main():
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
         tw = time.perf_counter(); fit_batch(ctx, torch, d); torch.cuda.synchronize(); warm_s = time.perf_counter() - tw; del d
-    # start offset between the streams of a rank: batches take the same time, so streams that start together stay in LOCKSTEP -- they drain at the same
-    # moments (stage boundaries, contact sets, loss histories) and the host sections behind those drains are then exposed on both at once.  A fraction of a
-    # batch apart (0.15 s is enough, the offset then grows by itself), one stream's launches cover the other's host sections.  Worth nothing on a warm host (141-142 frames/s for 0 .. 0.6 s) and 7 % in the first
-    # process of a freshly booted box, where those host sections are slow (profiles/r04_stream_stagger.txt: 130-135 -> 142-143 frames/s)
+    # start offset between the streams of a rank (--stagger, default none): batches take the same time, so streams that start together stay in LOCKSTEP
+    # and drain at the same moments (stage boundaries, contact sets, loss histories), exposing the host sections behind those drains on both at once.
+    # Worth nothing on a warm host (141-142 frames/s for 0 .. 0.6 s); it hid the 7 % the first process on a fresh box lost to huge-page faults in its
+    # launching threads (130-135 -> 142-143 frames/s) until that was fixed at the root (_lib._host_tuning, profiles/r04_cold_process.txt)
     stagger = 0.0
     if args.streams > 1:
-        stagger = args.stagger if args.stagger is not None else (0.2 * warm_s if warm_s is not None else 0.15)
+        stagger = args.stagger if args.stagger is not None else 0.0
     batches = [run(i) for i in my_jobs]                    # inputs resident in HBM before the timed region
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events
@@ -705,6 +705,11 @@ def main():
             if k in extras:
                 line[k] = extras[k]
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)
+            try:        # the CPU leg gets the host's default huge-page policy back (the library switched it off for the launch path: _lib._host_tuning)
+                import ctypes
+                ctypes.CDLL(None).prctl(41, 0, 0, 0, 0)
+            except Exception:      # noqa: BLE001
+                pass
             line["cpu_baseline"] = cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps)
         print(json.dumps(line))
     if use_dist:

@@ -52,8 +52,9 @@ class PipelineConfig:
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
     fit_streams: int = 2
     # start offset (seconds) of stream k of the joint fit after stream k - 1: streams that start together stay in lockstep (equal batch times) and drain at
-    # the same moments, exposing the host sections behind the drains on all of them at once -- 7 % in a cold process (profiles/r04_stream_stagger.txt)
-    fit_stagger_s: float = 0.15
+    # the same moments, exposing the host sections behind the drains on all of them at once.  Measured: nothing on a warm host; it hid the huge-page fault
+    # stalls of a cold process until _lib._host_tuning removed those (profiles/r04_stream_stagger.txt, r04_cold_process.txt).  Off by default.
+    fit_stagger_s: float = 0.0
     # N > 1 ranks: "static" = every rank fits the batches of its own frames; "steal" = a rank that runs out takes batches from the rank with the most left
     # (sharding.StealQueue) and encodes their maps itself.  Same results either way.
     fit_handout: str = "steal"
