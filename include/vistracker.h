@@ -397,6 +397,15 @@ int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, 
 /* d_image (B,size,size) -> dverts (B,NV,3) (overwritten). eps = NMR's 1e-4. */
 int vt_sil_backward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size,
                     const int *face_index, const float *d_image, float eps, float *ws, float *dverts, void *stream);
+/* SilLossROI's per-batch set-up on the device (recon/obj_pose_roi.py:39-75 __init__; :111-121 to_original_bbox; :123-155 compute_K_roi; :157-181 cvt_masks;
+ * recon/bbox.py:26-48 make_bbox_square; recon/opt_utils.py:148-153 mask2bbox).  mask_h / mask_o (B,H,W) person / object masks of the network input in [0,1];
+ * crop_centers (B,2) full-image pixels; expansion 0.3; out = render size (256); crop_size 1200, net_size 512; cam_norm = {fx, fy, cx, cy} / image_width (host
+ * doubles).  Writes image_ref, keep_mask (B,out,out) and K (B,9) = normalised intrinsics of the square ROI; boxes_ws: 4 B doubles of scratch.  An empty
+ * object mask gives the reference's degenerate box and all-zero crops (image_ref = 0, keep_mask = 1).  The ROIAlign underneath (detectron2
+ * BitMasks.crop_and_resize: aligned, adaptive sampling ratio, >= 0.5) is third-party: PARITY UNPINNED beyond the restatement in silhouette.py. */
+int vt_sil_setup(const float *mask_h, const float *mask_o, int B, int H, int W, const float *crop_centers, double expansion, int out, double crop_size,
+                 double net_size, const double *cam_norm, double image_width, float *image_ref, float *keep_mask, float *K, double *boxes_ws, void *stream);
+
 /* fused occlusion-aware mask term (obj_pose_roi.py:191-198; recon_fit_trivis_full.py:164-168):
  * per[b] = sum_px (keep*sil - ref)^2 ; *term += mean_b(per[b]*occ[b]); d_image = gscale * d/d sil */
 int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size,

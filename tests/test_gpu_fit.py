@@ -218,6 +218,31 @@ def test_silsetup_on_device_vs_reference():
     assert np.array_equal(s.keep_mask.cpu().numpy(), _unpack(g["keep_mask"], 256)) and np.array_equal(s.image_ref.cpu().numpy(), _unpack(g["image_ref"], 256))
 
 
+def test_silsetup_kernels_vs_host_restatement():
+    """vt_sil_setup (two launches) against the host restatement it replaces (masks2bbox -> make_bbox_square -> roi_align_masks -> cvt_masks -> compute_K_roi,
+    float64 numpy / torch) on masks whose boxes need 1, 2 and 3 samples per ROI bin, a box that leaves the image, and an EMPTY object mask (the
+    reference's degenerate box: all-zero crops, keep mask of ones)."""
+    from vistracker_amd import silhouette as PS, synthetic as syn
+    rng = np.random.default_rng(5)
+    B, S = 7, 512
+    om = np.zeros((B, S, S), np.float32); pm = np.zeros_like(om)
+    yy, xx = np.mgrid[:S, :S]
+    specs = [(256, 256, 60, 40), (200, 300, 120, 150), (300, 220, 230, 200), (40, 60, 90, 70), (470, 480, 80, 60), (256, 256, 255, 250)]
+    for b, (cy, cx, ry, rx) in enumerate(specs):
+        om[b] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1) & (rng.uniform(size=(S, S)) > 0.03)
+        pm[b] = (((yy - cy - 0.6 * ry) / (1.2 * ry)) ** 2 + ((xx - cx + 0.5 * rx) / (0.8 * rx)) ** 2 < 1)
+    pm[6] = pm[0]                                                   # frame 6: person only, no object pixel at all
+    cc = (np.tile([[1018.952, 779.486]], (B, 1)) + rng.normal(0, 30, (B, 2))).astype(np.float32)
+    ov, of = syn.object_template()
+    dev_side = PS.SilLossROI(cu(pm), cu(om), (ov, of), cu(cc), camera_params={}, crop_size=1200, net_input_size=512)
+    host_side = PS.SilLossROI(torch.from_numpy(pm), torch.from_numpy(om), (ov, of), torch.from_numpy(cc), device="cpu", camera_params={}, crop_size=1200, net_input_size=512)
+    assert np.array_equal(dev_side.image_ref.cpu().numpy(), host_side.image_ref.numpy())
+    assert np.array_equal(dev_side.keep_mask.cpu().numpy(), host_side.keep_mask.numpy())
+    assert np.array_equal(dev_side.K.cpu().numpy(), host_side.K.numpy()), np.abs(dev_side.K.cpu().numpy() - host_side.K.numpy()).max()
+    assert float(dev_side.image_ref[6].abs().max()) == 0.0 and float(dev_side.keep_mask[6].min()) == 1.0
+    assert 0.02 < float(dev_side.image_ref[:6].mean()) < 0.9
+
+
 def test_early_stop_on_device(synth):
     """The device-side stop flag freezes the parameters at the step the reference rule fires (no overshoot)."""
     from vistracker_amd import ops, synthetic as syn

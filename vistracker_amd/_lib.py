@@ -108,6 +108,7 @@ SIGNATURES = {
     "vt_sil_forward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, vp]),
     "vt_sil_backward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, cf, fp, fp, vp]),
     "vt_sil_mask_loss": (ci, [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp]),
+    "vt_sil_setup": (ci, [fp, fp, ci, ci, ci, fp, C.c_double, ci, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double, fp, fp, fp, fp, vp]),
     "vt_adam_step": (ci, [fp, fp, fp, fp, cl, ci, cf, cf, cf, cf, fp, vp]),
     "vt_adam_step_2d": (ci, [fp, cl, fp, cl, fp, fp, ci, ci, ci, cf, cf, cf, cf, fp, vp]),
     "vt_loss_reduce_and_stop": (ci, [fp, vp, ci, cf, ci, fp, fp, fp, ci, vp]),

@@ -534,3 +534,100 @@ extern "C" int vt_sil_mask_loss(const float *image, const float *keep, const flo
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
+
+// ---- SilLossROI's per-batch set-up (recon/obj_pose_roi.py:39-75 __init__, 111-181 to_original_bbox / compute_K_roi / cvt_masks; recon/bbox.py:26-48
+// make_bbox_square; opt_utils.py:148-153 mask2bbox): object-mask bounding box -> square x (1 + expansion) -> ROIAlign(out, aligned, sampling_ratio = 0)
+// crops of the object and the person mask, thresholded at 0.5 -> image_ref, keep mask; the square in full-image pixels -> normalised ROI intrinsics.
+// Two launches, no host round trip.  The arithmetic is the host restatement's (vistracker_amd/silhouette.py: masks2bbox, make_bbox_square,
+// roi_align_masks, compute_K_roi -- float64 in numpy / torch, the same operations in the same order here; no fused multiply-adds), because the crops are
+// thresholded: a last-bit difference in a sample position can move a pixel of the reference mask.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void sil_setup_box_kernel(const float *__restrict__ mask_o, int H, int W, const float *__restrict__ cc, double expansion, double scale,
+                                                            double crop_size, double fxn, double fyn, double cxn, double cyn, double image_width,
+                                                            double *__restrict__ boxes, float *__restrict__ K)
+{
+    __shared__ int red[4][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *m = mask_o + (size_t)b * H * W;
+    int x0 = W, x1 = -1, y0 = H, y1 = -1;
+    for (int i = tid; i < H * W; i += 256)
+        if (m[i] > 0.5f) { const int y = i / W, x = i - y * W; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+    red[0][tid] = x0; red[1][tid] = x1; red[2][tid] = y0; red[3][tid] = y1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] = min(red[0][tid], red[0][tid + s]); red[1][tid] = max(red[1][tid], red[1][tid + s]);
+                       red[2][tid] = min(red[2][tid], red[2][tid + s]); red[3][tid] = max(red[3][tid], red[3][tid + s]); }
+        __syncthreads();
+    }
+    if (tid) return;
+    double bx0, by0, bx1, by1;
+    if (red[1][0] < 0) { bx0 = 50000.0; by0 = 50000.0; bx1 = -100.0; by1 = -100.0; }          // EMPTY_BBOX (opt_utils.py:148-153): no foreground pixel
+    else { bx0 = red[0][0]; by0 = red[2][0]; bx1 = red[1][0] + 1; by1 = red[3][0] + 1; }
+    const double w = bx1 - bx0, h = by1 - by0;
+    const double c0 = bx0 + w / 2, c1 = by0 + h / 2;
+    const double s = fmax(w, h) * (1 + expansion);
+    const double sx = c0 - s / 2, sy = c1 - s / 2;
+    boxes[4 * b + 0] = sx; boxes[4 * b + 1] = sy; boxes[4 * b + 2] = sx + s; boxes[4 * b + 3] = sy + s;
+    // to_original_bbox: the square in pixels of the full image (the crop centre arrives as float32, as in the reference's loader)
+    const float half = (float)(crop_size / 2.0);
+    const double X = sx * scale + (double)(cc[2 * b] - half), Y = sy * scale + (double)(cc[2 * b + 1] - half), S = s * scale;
+    float *k = K + 9 * b;
+    k[0] = (float)(fxn * image_width / S); k[1] = 0.f; k[2] = (float)((cxn * image_width - X) / S);
+    k[3] = 0.f; k[4] = (float)(fyn * image_width / S); k[5] = (float)((cyn * image_width - Y) / S);
+    k[6] = 0.f; k[7] = 0.f; k[8] = 1.f;
+}
+
+__device__ __forceinline__ void roi_prep(double v, int n, int &lo, int &hi, double &l, bool &dead)
+{
+    dead = (v < -1.0) || (v > (double)n);
+    v = fmax(v, 0.0);
+    lo = (int)floor(v);
+    const bool top = lo >= n - 1;
+    if (top) { lo = n - 1; hi = lo; v = (double)lo; } else hi = lo + 1;
+    l = v - (double)lo;
+}
+__global__ __launch_bounds__(256) void sil_setup_roi_kernel(const float *__restrict__ mask_h, const float *__restrict__ mask_o, int H, int W, const double *__restrict__ boxes,
+                                                            int out, float *__restrict__ ref, float *__restrict__ keep)
+{
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= out * out) return;
+    const int oy = p / out, ox = p - oy * out;
+    const double x1 = boxes[4 * b], y1 = boxes[4 * b + 1], rw = boxes[4 * b + 2] - x1, rh = boxes[4 * b + 3] - y1;
+    const int gw = (int)ceil(rw / out), gh = (int)ceil(rh / out);
+    float vo = 0.f, vh = 0.f;
+    if (gw > 0 && gh > 0) {
+        const double bw = rw / out, bh = rh / out;
+        const float *mo = mask_o + (size_t)b * H * W, *mh = mask_h + (size_t)b * H * W;
+        double so = 0.0, sh = 0.0;
+        for (int iy = 0; iy < gh; iy++) {
+            const double y = ((double)oy * bh + (y1 - 0.5)) + ((double)iy + 0.5) * bh / (double)gh;
+            int ylo, yhi; double ly; bool dy; roi_prep(y, H, ylo, yhi, ly, dy);
+            for (int ix = 0; ix < gw; ix++) {
+                const double x = ((double)ox * bw + (x1 - 0.5)) + ((double)ix + 0.5) * bw / (double)gw;
+                int xlo, xhi; double lx; bool dx; roi_prep(x, W, xlo, xhi, lx, dx);
+                const double w00 = (1 - ly) * (1 - lx), w01 = (1 - ly) * lx, w10 = ly * (1 - lx), w11 = ly * lx;
+                const double live = (dy ? 0.0 : 1.0) * (dx ? 0.0 : 1.0);
+                so += ((((double)mo[ylo * W + xlo] * w00 + (double)mo[ylo * W + xhi] * w01) + (double)mo[yhi * W + xlo] * w10) + (double)mo[yhi * W + xhi] * w11) * live;
+                sh += ((((double)mh[ylo * W + xlo] * w00 + (double)mh[ylo * W + xhi] * w01) + (double)mh[yhi * W + xlo] * w10) + (double)mh[yhi * W + xhi] * w11) * live;
+            }
+        }
+        vo = (float)(so / (double)(gh * gw)); vh = (float)(sh / (double)(gh * gw));
+    }
+    const bool obj = vo >= 0.5f, ps = vh >= 0.5f;
+    ref[(size_t)b * out * out + p] = obj ? 1.f : 0.f;                   // image_ref = (object crop > 0)
+    keep[(size_t)b * out * out + p] = (ps && !obj) ? 0.f : 1.f;         // cvt_masks: keep foreground and free background, drop person-only pixels
+}
+
+extern "C" int vt_sil_setup(const float *mask_h, const float *mask_o, int B, int H, int W, const float *crop_centers, double expansion, int out, double crop_size,
+                            double net_size, const double *cam_norm, double image_width, float *image_ref, float *keep_mask, float *K, double *boxes_ws, void *stream)
+{
+    VT_REQUIRE(mask_h && mask_o && crop_centers && cam_norm && image_ref && keep_mask && K && boxes_ws && B > 0 && H > 0 && W > 0 && out > 0 && net_size > 0,
+               "vt_sil_setup: bad argument");
+    hipStream_t st = vt_stream(stream);
+    hipLaunchKernelGGL(sil_setup_box_kernel, dim3(B), dim3(256), 0, st, mask_o, H, W, crop_centers, expansion, crop_size / net_size, crop_size, cam_norm[0], cam_norm[1],
+                       cam_norm[2], cam_norm[3], image_width, boxes_ws, K);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_setup_roi_kernel, dim3((out * out + 255) / 256, B), dim3(256), 0, st, mask_h, mask_o, H, W, boxes_ws, out, image_ref, keep_mask);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}

@@ -152,11 +152,34 @@ class SilLossROI(nn.Module):
         verts, faces = (temp_mesh.v, temp_mesh.f) if hasattr(temp_mesh, "v") else temp_mesh
         B = person_masks.shape[0]
         pm = torch.as_tensor(person_masks).float(); om = torch.as_tensor(obj_masks).float()
+        camera_params = {} if camera_params is None else camera_params
+        if om.is_cuda and pm.is_cuda and not camera_params.keys() - {"crop_size"}:
+            # the whole set-up as two launches of the library (vt_sil_setup), no host round trip: same arithmetic as the host restatement below
+            from . import _lib as L
+            import ctypes as C
+            dev = om.device
+            pm = pm.contiguous(); om = om.contiguous()
+            H, W = om.shape[1:]
+            ref = torch.empty(B, rend_size, rend_size, device=dev); keep = torch.empty_like(ref); K = torch.empty(B, 9, device=dev)
+            ws = torch.empty(4 * B, dtype=torch.float64, device=dev)
+            cc_d = torch.as_tensor(crop_centers).to(dev, torch.float32).contiguous()
+            iw = 2048
+            cam = (C.c_double * 4)(979.7844 / iw, 979.840 / iw, 1018.952 / iw, 779.486 / iw)            # compute_K_roi's defaults, normalised as it does
+            with torch.cuda.device(dev):
+                L.check(L.lib().vt_sil_setup(L.dptr(pm), L.dptr(om), B, H, W, L.dptr(cc_d), float(bbox_expansion), rend_size, float(crop_size), float(net_input_size),
+                                             cam, float(iw), L.dptr(ref), L.dptr(keep), L.dptr(K), ws.data_ptr(), L.stream_ptr()))
+            self.register_buffer("image_ref", ref); self.register_buffer("keep_mask", keep); self.register_buffer("K", K)
+            odev = torch.device(device)
+            self.register_buffer("vertices", torch.as_tensor(np.asarray(verts), dtype=torch.float32).to(odev))
+            self.register_buffer("faces", torch.as_tensor(np.asarray(faces).astype(np.int32)).to(odev))
+            self.pool = nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+            self.rend_size = rend_size
+            self._edt = None
+            return
         boxes = masks2bbox(om)                                                                          # xyxy, all frames at once on the device
         xywh = np.concatenate([boxes[:, :2], boxes[:, 2:] - boxes[:, :2]], 1)
         squares = make_bbox_square(xywh, bbox_expansion)                                                # xywh
         sq_xyxy = np.concatenate([squares[:, :2], squares[:, :2] + squares[:, 2:]], 1)
-        camera_params = {} if camera_params is None else camera_params
         scale = crop_size / net_input_size
         Ks, keeps, refs = [], [], []
         cc = torch.as_tensor(crop_centers).float().cpu().numpy()
