@@ -153,7 +153,7 @@ class SilLossROI(nn.Module):
         B = person_masks.shape[0]
         pm = torch.as_tensor(person_masks).float(); om = torch.as_tensor(obj_masks).float()
         camera_params = {} if camera_params is None else camera_params
-        if om.is_cuda and pm.is_cuda and not camera_params.keys() - {"crop_size"}:
+        if om.is_cuda and pm.is_cuda and not camera_params.keys() - {"crop_size", "fx", "fy", "cx", "cy", "image_width"}:
             # the whole set-up as two launches of the library (vt_sil_setup), no host round trip: same arithmetic as the host restatement below
             from . import _lib as L
             import ctypes as C
@@ -163,8 +163,12 @@ class SilLossROI(nn.Module):
             ref = torch.empty(B, rend_size, rend_size, device=dev); keep = torch.empty_like(ref); K = torch.empty(B, 9, device=dev)
             ws = torch.empty(4 * B, dtype=torch.float64, device=dev)
             cc_d = torch.as_tensor(crop_centers).to(dev, torch.float32).contiguous()
-            iw = 2048
-            cam = (C.c_double * 4)(979.7844 / iw, 979.840 / iw, 1018.952 / iw, 779.486 / iw)            # compute_K_roi's defaults, normalised as it does
+            # compute_K_roi's parameters (its defaults unless the caller's camera dict overrides them), normalised by the image width as it does
+            iw = camera_params.get("image_width", 2048)
+            fx, fy, cx, cy = (camera_params.get(k, v) for k, v in (("fx", 979.7844), ("fy", 979.840), ("cx", 1018.952), ("cy", 779.486)))
+            if fx > 1.0:
+                fx, fy, cx, cy = fx / iw, fy / iw, cx / iw, cy / iw
+            cam = (C.c_double * 4)(fx, fy, cx, cy)
             with torch.cuda.device(dev):
                 L.check(L.lib().vt_sil_setup(L.dptr(pm), L.dptr(om), B, H, W, L.dptr(cc_d), float(bbox_expansion), rend_size, float(crop_size), float(net_input_size),
                                              cam, float(iw), L.dptr(ref), L.dptr(keep), L.dptr(K), ws.data_ptr(), L.stream_ptr()))
