@@ -8,7 +8,8 @@ from vistracker_amd.encoder import SIFNetEncoder
 from vistracker_amd.pipeline import PipelineConfig, SequencePipeline
 from vistracker_amd.sifnet import SIFNetQuery
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+T = int(sys.argv[1]) if len(sys.argv) > 1 and '=' not in sys.argv[1] else 1500
+CFG = {a.split('=')[0]: float(a.split('=')[1]) for a in sys.argv[1:] if '=' in a}       # PipelineConfig overrides, e.g. fit_stagger_s=0.15 fit_streams=2
 G = lambda n: np.load(f'/root/repo/tests/golden/{n}.npz')
 def seeded(g, seed, norm_gain=False):
     sd = {}
@@ -27,7 +28,7 @@ net = SIFNetQuery(dec); net.encoder = SIFNetEncoder.from_state_dict(syn.encoder_
 ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, 3000, seed=6)
 pca_init = np.linalg.svd(ov - ov.mean(0), full_matrices=False)[2].astype(np.float32)
 pipe = SequencePipeline(model, regs, pri, net, labels, (ov, of), opts, pca_init, S.SmoothNetSMPL(seeded(G("smooth"), 21)), S.SmoothNet(seeded(G("smooth_objrot"), 22)),
-                        I.ConditionalMInfiller(seeded(G("infill"), 31, True), opt), PipelineConfig())
+                        I.ConditionalMInfiller(seeded(G("infill"), 31, True), opt), PipelineConfig(**{k: (int(v) if k.endswith('streams') or k.endswith('bs') else v) for k, v in CFG.items()}))
 sp = syn.sequence_params(T, seed=7)
 h = ops.SmplhHandle(model); b25 = ops.LandmarkHandle(regs["body25"])
 cu = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
