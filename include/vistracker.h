@@ -468,6 +468,22 @@ int vt_fill(float *p, long n, float value, void *stream);
  * through one stream do not interfere); registering a second, different flag for the same stream from the same thread is an error (VT_ERR_ARG). */
 int vt_stream_set_skip_flag(void *stream, const int *flag);
 
+/* ---- bookkeeping of one round of the surface-point generator (recon/gen/generator.py:149-212, Generator.gen_pc_batch) ----------------------------------
+ * vt_gen_round_compact: surface (B,S,3) projected samples, df_target (B,S) clamped distance of the last query, pre (B,S,3) positions of that query (or NULL),
+ *   active (B) bytes.  A sample is kept when df_target < filter_val and z > zmin and its frame is active (generator.py:160-166).  order (B,S) int32 receives the
+ *   kept sample indices in sample order (first cnt[b] entries: torch.argsort(~mask, stable=True)'s prefix); kept_pre (B,S,3) (or NULL) the positions `pre` at
+ *   them; with write != 0 the kept points are appended to buf_points (B,cap+1,3) at row fill[b] (rows >= cap dropped: the reference cuts every frame to the common
+ *   count anyway); cnt (B), fill_out (B) = min(fill + cnt, cap) (= fill without write) as int64.
+ * vt_gen_scatter_heads: pred (B,C,kmax) predictions at the kept points -> buf (B,cap+1,C) rows fill_old[b] + k, k < cnt[b].
+ * vt_gen_resample: the next round's M samples per frame (generator.py:190-210): samples[order[floor(u * cnt)]] + near_scale * pert where cnt > 1, else a
+ *   restart init[floor(u * S0)] + 0.5 * pert; u (B,M) uniform, pert (B,M,3) normal (drawn by the caller's seeded generator). */
+int vt_gen_round_compact(const float *surface, const float *df_target, const float *pre, const unsigned char *active, int B, int S, float filter_val,
+                         float zmin, const long long *fill, int cap, int write, float *buf_points, int *order, float *kept_pre, long long *cnt,
+                         long long *fill_out, void *stream);
+int vt_gen_scatter_heads(const float *pred, int B, int C, int kmax, const long long *fill_old, const long long *cnt, int cap, float *buf, void *stream);
+int vt_gen_resample(const float *samples, const int *order, const long long *cnt, const float *init, int B, int S, int S0, const float *u,
+                    const float *pert, int M, float near_scale, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

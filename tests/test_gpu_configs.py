@@ -122,14 +122,15 @@ def test_generator_frames_that_sit_out_do_not_change_the_result(synth):
     outs = []
     # default (sit-out at the adaptive level), sit-out at the fixed 1.5 x level, every frame in every round; then round 3's path for the heads other than
     # the distance field (five-head forward on all samples instead of the four heads at the kept points)
-    for skip, adaptive, kept in ((True, True, True), (True, False, True), (False, False, True), (True, True, False)):
-        gen = GeneratorTriplaneVis(net, "x", seed=5); gen.skip_done_frames = skip; gen.adaptive_sit_out = adaptive; gen.kept_heads_only = kept
+    # last: the default again with the rounds' bookkeeping in torch ops instead of the three library launches (Generator.fused_rounds)
+    for skip, adaptive, kept, fused in ((True, True, True, True), (True, False, True, True), (False, False, True, True), (True, True, False, True), (True, True, True, False)):
+        gen = GeneratorTriplaneVis(net, "x", seed=5); gen.skip_done_frames = skip; gen.adaptive_sit_out = adaptive; gen.kept_heads_only = kept; gen.fused_rounds = fused
         gen.reseed(0)
         pc = gen.generate_pclouds_batch(data, num_points=3000, num_steps=10, targets=("object",))["object"]
         outs.append({k: (v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in pc.items()})
     a = outs[0]
     assert a["points"].shape[1] >= 3000
-    for b in outs[1:3]:
+    for b in outs[1:3] + outs[4:5]:
         assert a["points"].shape == b["points"].shape
         for k in a:
             assert np.array_equal(a[k], b[k], equal_nan=True), k        # (the human half of `centers` is NaN when only the object is sampled)

@@ -108,6 +108,9 @@ SIGNATURES = {
     "vt_sil_forward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, vp]),
     "vt_sil_backward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, cf, fp, fp, vp]),
     "vt_sil_mask_loss": (ci, [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp]),
+    "vt_gen_round_compact": (ci, [fp, fp, fp, vp, ci, ci, cf, cf, vp, ci, ci, fp, vp, fp, vp, vp, vp]),
+    "vt_gen_scatter_heads": (ci, [fp, ci, ci, ci, vp, vp, ci, fp, vp]),
+    "vt_gen_resample": (ci, [fp, vp, vp, fp, ci, ci, ci, fp, fp, ci, cf, fp, vp]),
     "vt_sil_setup": (ci, [fp, fp, ci, ci, ci, fp, C.c_double, ci, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_double, fp, fp, fp, fp, vp]),
     "vt_adam_step": (ci, [fp, fp, fp, fp, cl, ci, cf, cf, cf, cf, fp, vp]),
     "vt_adam_step_2d": (ci, [fp, cl, fp, cl, fp, fp, ci, ci, ci, cf, cf, cf, cf, fp, vp]),

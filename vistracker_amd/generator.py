@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -37,6 +38,10 @@ class Generator:
     # fixed 1.5 x num_points.  Frames leave the launches one to two rounds earlier (-15 % frame-rounds).  False: the fixed level.
     adaptive_sit_out = True
     kept_heads_only = True      # see gen_pc_batch: the four heads other than the distance field are evaluated at the kept points only
+    # the bookkeeping of a round (mask, stable compaction of the kept samples, append to the output buffers, scatter of the kept-point predictions, next
+    # round's samples) as three launches of the library (csrc/gen.hip) instead of ~40 torch launches and two host round trips: same results bit for bit
+    # (tests/test_gpu_configs.py), one host look per round.  Needs the kept-points path; False (VT_GEN_FUSED_ROUNDS=0): the torch formulation below.
+    fused_rounds = os.environ.get("VT_GEN_FUSED_ROUNDS", "1") != "0"
 
     def __init__(self, model, exp_name=None, threshold=1.0, checkpoint=None, device="cuda:0", multi_gpus=True, sparse_thres=0.05,
                  filter_val=0.03, seed=0, **kwargs):
@@ -127,7 +132,7 @@ class Generator:
         out_names = self.get_out_names()
         sample_num = 20000
         cap = num_points + max(sample_num, S0)
-        samples_init = samples_init.to(dev)
+        samples_init = samples_init.to(dev).float().contiguous()
         buf = {"points": torch.zeros(B, cap + 1, 3, device=dev)}
         fill = torch.zeros(B, dtype=torch.long, device=dev)
         it, samples_count = 0, 0
@@ -203,9 +208,61 @@ class Generator:
             return [scatter_frames(outs[n], idx) for n in out_names[1:]]
 
         stats = [] if os.environ.get("VT_GEN_STATS") else None
+        fused = bool(self.fused_rounds) and kept_only and torch.device(dev).type == "cuda"
         while samples_count < num_points or refill:
             samples_surface, preds, df_target, pre = project(samples)
             S = samples.shape[1]
+            if fused:
+                lib = L.lib()
+                ss_c, df_c, pre_c, smp_c = samples_surface.contiguous(), df_target.contiguous(), pre.contiguous(), samples.contiguous()
+                act_u8 = torch.as_tensor(active.astype(np.uint8), device=dev)
+                order = torch.empty(B, S, dtype=torch.int32, device=dev); kept_pre = torch.empty(B, S, 3, device=dev) if it > 0 else None
+                cnt = torch.empty(B, dtype=torch.long, device=dev); fill_new = torch.empty(B, dtype=torch.long, device=dev)
+                L.check(lib.vt_gen_round_compact(L.dptr(ss_c), L.dptr(df_c), L.dptr(pre_c), act_u8.data_ptr(), B, S, float(self.filter_val), 1.0, fill.data_ptr(), cap,
+                                                 int(it > 0), L.dptr(buf["points"]), order.data_ptr(), L.dptr(kept_pre), cnt.data_ptr(), fill_new.data_ptr(), L.stream_ptr()))
+                if it > 0:
+                    host = torch.cat([cnt, fill_new]).cpu().numpy()                 # the one host look of the round: kept points and fill level of every frame
+                    cnt_h, fill_h = host[:B], host[B:]
+                    kmax = int(cnt_h.max())
+                    if kmax > 0:
+                        kmax = min(S, (kmax + 63) // 64 * 64)
+                        kp = heads_at(kept_pre[:, :kmax], kmax)
+                        for name, pred in zip(out_names[1:], kp):
+                            pr = pred.reshape(B, -1, kmax).contiguous()            # (B, C, kmax)
+                            Cc = pr.shape[1]
+                            if name not in buf:
+                                buf[name] = torch.zeros(B, cap + 1, Cc, device=dev)
+                            L.check(lib.vt_gen_scatter_heads(L.dptr(pr), B, Cc, kmax, fill.data_ptr(), cnt.data_ptr(), cap, L.dptr(buf[name]), L.stream_ptr()))
+                    fill = fill_new
+                    round_min = int(cnt_h[active].min()) if active.any() else 0
+                    if not refill:
+                        samples_count += round_min
+                    if not mute:
+                        print(f"{samples_count} points")
+                    if stats is not None:
+                        stats.append((it, int(active.sum()), round_min, int(samples_count), int(fill_h.min()), int(np.median(fill_h)), int(fill_h.max())))
+                    if samples_count >= num_points:
+                        active = fill_h < min(samples_count, cap)
+                        refill = bool(active.any())
+                    elif self.skip_done_frames:
+                        if self.adaptive_sit_out and it >= 3:
+                            max_min = max(max_min, round_min)
+                            level = min(stop_at, num_points + 2 * max_min)
+                        else:
+                            max_min = max(max_min, round_min); level = stop_at
+                        keep = active & (fill_h < level)
+                        if keep.any():
+                            active = keep
+                u = torch.rand(B, sample_num, device=dev, generator=self.rng)
+                pert = torch.randn(B, sample_num, 3, device=dev, generator=self.rng)
+                nxt = torch.empty(B, sample_num, 3, device=dev)
+                L.check(lib.vt_gen_resample(L.dptr(smp_c), order.data_ptr(), cnt.data_ptr(), L.dptr(samples_init), B, S, S0, L.dptr(u), L.dptr(pert), sample_num,
+                                            float(np.float32(self.threshold / 3)), L.dptr(nxt), L.stream_ptr()))
+                samples = nxt
+                it += 1
+                if it == max_iter:
+                    raise RuntimeError(f"point generation for df {df_type} failed after {max_iter} iterations for files: {batch.get('path')}")
+                continue
             act = torch.as_tensor(active, device=dev)
             mask = (df_target < self.filter_val) & (samples_surface[:, :, 2] > 1.0) & act[:, None]
             cnt = mask.sum(1)                                                  # (B,) kept points per frame
