@@ -50,3 +50,4 @@ print(f"T = {T} frames: {dt:.1f} s = {T / dt:.1f} frames/s end to end (one MI355
 if pipe.fitter.profile:
     print("fit_recon_batch parts [s] (both passes):", {k: round(v, 2) for k, v in pipe.fitter.last["seconds"].items()})
 print("Adam steps per joint-fit batch (smpl, object):", pipe.log["fit_steps"][:4], "...; SMPL-T steps:", pipe.log["smplt_steps"])
+print('stage 4, generator part per 64-frame batch [s]:', pipe.log.get('stage4_batch_s'))

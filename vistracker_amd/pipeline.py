@@ -208,7 +208,9 @@ class SequencePipeline:
                     bm = self.net.maps
                 # only the object's predictions (PCA axes, centre, visibility) are packed and used downstream: the human cloud of the reference's
                 # neural-only pass is written to disk and never read again by steps 5-6 (work whose result is unused)
+                t_b4 = time.perf_counter()
                 pc, *_ = self.fitter.fit_recon_batch(cfg.args, batch, self.generator, None, None, neural_only=True, maps=bm, targets=("object",))
+                self.log.setdefault("stage4_batch_s", []).append(round(time.perf_counter() - t_b4, 3))      # (host time of the generator's part of a batch)
                 o = pc["object"]
                 rows.append(torch.cat([o["pca_axis"].reshape(e - s, 9).to(self.device), o["centers"].reshape(e - s, 6).to(self.device), o["visibility"].reshape(e - s, -1)[:, :1].to(self.device)], 1).float())
         finally:
