@@ -222,7 +222,8 @@ def strict_fp32_leg(ctx, torch, make, n_batches, streams=2):
     for d in ds:
         d["maps"].set_force_fp32(True)
     torch.cuda.synchronize()
-    ss = [torch.cuda.Stream(device=ctx.device) for _ in range(streams)]
+    from vistracker_amd.streams import concurrent_streams
+    ss = concurrent_streams(streams, ctx.device)
     results = [None] * len(ds)
 
     def w(k):
@@ -417,6 +418,7 @@ def main():
         my_jobs = list(range(args.steps)); total_frames = world * args.steps * BATCH
     # test hook: this job index runs the reference's maximum schedule (stop rules off) -- a batch 3.5 x as expensive as its neighbours
     heavy = int(os.environ.get("VT_BENCH_FULL_SCHEDULE_BATCH", "-1"))
+    all_heavy = os.environ.get("VT_BENCH_FULL_SCHEDULE_ALL") == "1"          # experiment: every batch on the full schedule (stop rules off)
     warm_s = None
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
@@ -434,14 +436,21 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    # the streams of the timed region: TESTED to run concurrently (two HIP streams may share a hardware queue and then serialise: vistracker_amd/streams.py)
+    from vistracker_amd.streams import concurrent_streams
+    fit_streams = concurrent_streams(max(1, args.streams) + (1 if args.schedule == "staged" else 0), dev)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
     SECTION_S.clear()
+    main_streams = []          # the timed region's streams, reused by the two-in-flight half of the full-schedule leg
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
     done_at = {}            # batch position -> seconds after t0 at which its fit returned on the host (rank 0's own; shows a ramp inside the timed region)
     fitted = list(range(len(batches)))          # positions in ``batches`` this rank fitted (static: all of them)
     if dynamic:
         import threading
         results = [None] * len(batches); fitted = []
-        streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+        streams = list(fit_streams[:max(1, args.streams)])
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())
 
@@ -454,7 +463,7 @@ def main():
                     i = queue.next()
                     if i is None:
                         break
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy)); fitted.append(i); done_at[i] = time.perf_counter() - t0
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy and not all_heavy)); fitted.append(i); done_at[i] = time.perf_counter() - t0
                 streams[k].synchronize()
         th_ = [threading.Thread(target=pull_worker, args=(k,)) for k in range(len(streams))]
         for t_ in th_: t_.start()
@@ -463,13 +472,14 @@ def main():
             torch.cuda.current_stream().wait_stream(s_)
         fitted.sort()
     elif args.streams <= 1:
-        results = [fit_batch(ctx, torch, d, prof, early_stop=(j != heavy)) for j, d in zip(my_jobs, batches)]
+        results = [fit_batch(ctx, torch, d, prof, early_stop=(j != heavy and not all_heavy)) for j, d in zip(my_jobs, batches)]
     else:
         # independent batches (the unit the path shards by) on separate HIP streams: the launch-latency-bound small kernels of one
         # batch overlap with the chip-filling query kernels of another
         import threading
         results = [None] * len(batches)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        streams = list(fit_streams[:args.streams])
+        main_streams.extend(streams)
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())
 
@@ -480,7 +490,7 @@ def main():
                 time.sleep(k * stagger)          # inside the timed region: see --stagger
             with torch.cuda.stream(streams[k]):
                 for i in range(k, len(batches), args.streams):
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy), obj_stream=so); done_at[i] = time.perf_counter() - t0
+                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(my_jobs[i] != heavy and not all_heavy), obj_stream=so); done_at[i] = time.perf_counter() - t0
 
         ready = [threading.Event() for _ in batches]; half = [None] * len(batches)
 
@@ -498,7 +508,7 @@ def main():
 
         def object_worker():
             torch.cuda.set_device(dev)
-            so = torch.cuda.Stream(device=dev, priority=args.object_priority); so.wait_stream(torch.cuda.current_stream())
+            so = fit_streams[-1] if not args.object_priority else torch.cuda.Stream(device=dev, priority=args.object_priority); so.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(so):
                 for i, d in enumerate(batches):
                     ready[i].wait()
@@ -574,22 +584,24 @@ def main():
         leg("solo_launch_s", lambda: solo_kernel_leg(ctx, torch, full96))
 
         def full_schedule():
-            d = make_batch(ctx, syn, torch, seed=900, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize(); t1 = time.perf_counter()
+            d = run(0); torch.cuda.synchronize(); t1 = time.perf_counter()          # the headline's batches (first three of the sequence), fresh copies
             r1, r2 = fit_batch(ctx, torch, d, early_stop=False); torch.cuda.synchronize(); dt = time.perf_counter() - t1
-            out = {"workload": "one 96-frame batch, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
+            out = {"workload": "the first 96-frame batch of the sequence, early stop disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 object-stage Adam "
                                "steps, of which 1100 in phase 'joint' with the contact Chamfer term), one batch in flight",
                    "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds": dt, "frames_per_s": BATCH / dt,
                    "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
             # the same with two batches in flight, like the headline
             import threading
             del d
-            ds = [make_batch(ctx, syn, torch, seed=901 + k_, dev=dev, res_scale=args.res_scale) for k_ in range(2)]; torch.cuda.synchronize()
-            ss = [torch.cuda.Stream(device=dev) for _ in ds]
+            ds = [run(1 + k_) for k_ in range(2)]; torch.cuda.synchronize()
+            ss = concurrent_streams(2, dev)
+
+            pf2 = {"human": [], "object": []} if os.environ.get("VT_BENCH_LEG_PROF") == "1" else None
 
             def w2(k):
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(ss[k]):
-                    fit_batch(ctx, torch, ds[k], early_stop=False)
+                    fit_batch(ctx, torch, ds[k], pf2, early_stop=False)
             t1 = time.perf_counter()
             th2 = [threading.Thread(target=w2, args=(k,)) for k in range(2)]
             for t_ in th2: t_.start()

@@ -30,6 +30,7 @@ from .infill import MotionInfillAutoreg
 from .recon_fit import ReconFitterTriVisFull
 from .smoothing import ObjrotSmoother, SMPLTSmoother
 from .smpl import SMPLHGenerator
+from .streams import concurrent_streams
 from .triplane import TriplaneNrRenderer
 
 
@@ -174,7 +175,7 @@ class SequencePipeline:
         enc_maps = [None] * len(nb4)
         if overlap:
             import threading
-            enc_stream = torch.cuda.Stream(device=self.device); enc_stream.wait_stream(torch.cuda.current_stream())
+            enc_stream = concurrent_streams(1, self.device)[0]; enc_stream.wait_stream(torch.cuda.current_stream())      # tested to overlap with this stream
             enc_done = [threading.Event() for _ in nb4]; enc_ev = [torch.cuda.Event() for _ in nb4]; enc_err = []; enc_cancel = threading.Event()
 
             def encode_all():
@@ -289,7 +290,7 @@ class SequencePipeline:
                 fit_one(owner, idx, self.fitter, self.generator)
         else:
             import copy
-            streams = [torch.cuda.Stream(device=self.device) for _ in range(nstream)]
+            streams = concurrent_streams(nstream, self.device)
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
             errors = []
