@@ -278,7 +278,8 @@ def pipeline_leg(torch, T=1500):
     pipe.run(seq)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     return {"workload": f"scripts/demo.sh steps 1-6 in memory, {T} synthetic frames, one GPU (BASELINE configs[4])", "frames_per_s": T / dt, "seconds": dt,
-            "stage_seconds": {k: round(float(v), 2) for k, v in pipe.log["seconds"].items()}}
+            "stage_seconds": {k: round(float(v), 2) for k, v in pipe.log["seconds"].items()},
+            "stage4_generator_seconds_per_64_frames": pipe.log.get("stage4_batch_s")}
 
 
 def cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps, budget_s=20.0):
