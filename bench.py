@@ -594,12 +594,10 @@ def main():
             ds = [run(1 + k_) for k_ in range(2)]; torch.cuda.synchronize()
             ss = concurrent_streams(2, dev)
 
-            pf2 = {"human": [], "object": []} if os.environ.get("VT_BENCH_LEG_PROF") == "1" else None
-
             def w2(k):
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(ss[k]):
-                    fit_batch(ctx, torch, ds[k], pf2, early_stop=False)
+                    fit_batch(ctx, torch, ds[k], early_stop=False)
             t1 = time.perf_counter()
             th2 = [threading.Thread(target=w2, args=(k,)) for k in range(2)]
             for t_ in th2: t_.start()
