@@ -33,6 +33,17 @@ def v2v(a, b):
     return float(d.mean()), float(d.max())
 
 
+def chamfer_cm(verts_a, verts_b, faces, n=10000):
+    """the reference's evaluation metric (recon/eval/chamfer_distance.py:43-48, evaluate.py:43,151-155): bidirectional mean nearest-neighbour DISTANCE between
+    10 000 area-weighted surface samples of the two meshes, summed over the two directions; per frame, returned as (mean, max) over the frames, in metres"""
+    from vistracker_amd import evaluation as E
+    # ONE set of (face, barycentric) draws for both meshes (independent draws put a ~1 cm sampling-noise floor under the metric: 10 000 samples of 2 m^2)
+    va, vb = np.asarray(verts_a, np.float32), np.asarray(verts_b, np.float32)
+    pts = E.surface_sampling(np.concatenate([va, vb], 0), faces, n)
+    d = E.chamfer_distance(pts[:len(va)], pts[len(va):]).cpu().numpy()
+    return float(d.mean()), float(d.max())
+
+
 def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
 
@@ -104,7 +115,9 @@ def main():
     n = min(res.steps, len(losses)); mean, mx = v2v(verts_hip, verts_cpu)
     rep["smpl_stage"] = {"steps_hip": res.steps, "steps_oracle": len(losses), "stopped_hip": bool(res.stopped_early), "stopped_oracle": bool(stopped),
                          "loss_history_rel": rel(res.losses[:n], losses[:n]), "v2v_mean_m": mean, "v2v_max_m": mx, "moved_from_start_mean_m": v2v(verts_hip, vs)[0],
-                         "seconds_hip": t_hip, "seconds_oracle": t_cpu}
+                         "seconds_hip": t_hip, "seconds_oracle": t_cpu,
+                         # "compute both on SMPL verts and transformed template verts" -- the same surface samples on both meshes, so 0 for equal meshes
+                         "chamfer_10k_samples_mean_max_m": chamfer_cm(verts_hip, verts_cpu, np.asarray(model["f"]))}
     print("SMPL stage:", rep["smpl_stage"], flush=True)
 
     # ---------------------------------------------------------------- object stage on the analytic field: HIP vs oracle32 vs oracle64
@@ -121,16 +134,19 @@ def main():
         R, t, s = cu(R0.copy()), cu(t0_ + np.float32(dt)), torch.ones(B, device="cuda")
         tt = time.perf_counter()
         r = ctxb.optimize_smpl_object(fm, cu(verts_cpu), R, t, s, cu(cc), cu(bc), cu(occ), noise=cu(noise), **kw); torch.cuda.synchronize()
-        outs[tag] = (O.rigid(pts, O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc), r.steps, r.losses, time.perf_counter() - tt)
+        outs[tag] = (O.rigid(pts, O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc), r.steps, r.losses, time.perf_counter() - tt, None,
+                     O.rigid(ov.astype(np.float32), O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc))
     for tag, Om in (("oracle32", O), ("oracle64", O64)):
         tt = time.perf_counter()
         Ro, to, ls, st, hc = FO.oracle_optimize_object(Om.SifNet(decb, mp), pts, R0, t0_, sc, noise, cc, bc, occ, verts_cpu, labels, sil=None, O=Om, **kw)
-        outs[tag] = (O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc), len(ls), np.array(ls), time.perf_counter() - tt, hc)
+        outs[tag] = (O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc), len(ls), np.array(ls), time.perf_counter() - tt, hc,
+                     O.rigid(ov.astype(np.float32), O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc))
     n = min(outs["hip"][1], outs["oracle32"][1])
     rep["object_stage_bowl"] = {"steps_hip": outs["hip"][1], "steps_oracle32": outs["oracle32"][1], "steps_oracle64": outs["oracle64"][1], "had_contacts": bool(outs["oracle32"][4]),
                                 "loss_history_rel": rel(outs["hip"][2][:n], outs["oracle32"][2][:n]),
                                 "hip_vs_oracle32_mean_max_m": v2v(outs["hip"][0], outs["oracle32"][0]), "hip_vs_oracle64_mean_max_m": v2v(outs["hip"][0], outs["oracle64"][0]),
                                 "oracle32_vs_oracle64_mean_max_m": v2v(outs["oracle32"][0], outs["oracle64"][0]), "hip_self_1e-6_mean_max_m": v2v(outs["hip"][0], outs["hip_1e-6"][0]),
+                                "chamfer_10k_samples_template_mesh_hip_vs_oracle32_mean_max_m": chamfer_cm(outs["hip"][5], outs["oracle32"][5], of),
                                 "seconds_hip": outs["hip"][3], "seconds_oracle32": outs["oracle32"][3], "seconds_oracle64": outs["oracle64"][3]}
     print("object stage:", rep["object_stage_bowl"], flush=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
