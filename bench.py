@@ -334,8 +334,8 @@ def main():
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
     ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
     ap.add_argument("--stagger", type=float, default=None,
-                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region); default 0 = together "
-                         "(profiles/r04_stream_stagger.txt: no effect on a warm host)")
+                    help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region; 0 = together).  Default: a fifth of the "
+                         "warm-up batch's time (0.15 s without warm-up) -- see the comment where it is applied")
     ap.add_argument("--object-priority", type=int, default=0, help="HIP stream priority of the object-stage stream of --schedule staged (-1 = high)")
     ap.add_argument("--schedule", choices=("batch", "staged"), default="batch",
                     help="batch: every stream fits whole batches (SMPL stage, then object stage); staged: --streams streams run the SMPL stages, one more "
@@ -424,13 +424,17 @@ def main():
     for wi in range(args.warmup):
         d = make_batch(ctx, syn, torch, seed=777 + 1000 * rank + wi, dev=dev, res_scale=args.res_scale); torch.cuda.synchronize()
         tw = time.perf_counter(); fit_batch(ctx, torch, d); torch.cuda.synchronize(); warm_s = time.perf_counter() - tw; del d
-    # start offset between the streams of a rank (--stagger, default none): batches take the same time, so streams that start together stay in LOCKSTEP
-    # and drain at the same moments (stage boundaries, contact sets, loss histories), exposing the host sections behind those drains on both at once.
-    # Worth nothing on a warm host (141-142 frames/s for 0 .. 0.6 s); it hid the 7 % the first process on a fresh box lost to huge-page faults in its
-    # launching threads (130-135 -> 142-143 frames/s) until that was fixed at the root (_lib._host_tuning, profiles/r04_cold_process.txt)
+    # start offset between the streams of a rank (--stagger; default a fifth of the warm-up batch's time, ~0.15 s; the offset then grows to ~0.35 s by
+    # itself).  Batches take the same time, so streams that start together stay in LOCKSTEP: both launching threads then go through their host-heavy
+    # sections -- the object stage (0.3-0.5 ms GPU steps), the set-up between the stages -- at the same moments.  On a warm process that costs nothing
+    # (141-142 frames/s for 0 .. 0.6 s of offset); in the FIRST process of a fresh container -- what a driver measures -- those sections run 20-60 ms per
+    # batch slower for both threads at once and the line drops to 130-135 frames/s (twelve first runs out of fifteen); a small offset lets each stream
+    # cover the other's host sections: 139-143 in four first runs out of four (profiles/r04_cold_process.txt, r04_stream_stagger.txt).  Price: a launch of
+    # the dominant kernel that runs beside the other batch's object stage takes longer, so the two-stream roofline figure is lower than in lockstep
+    # (frac 0.36-0.37 vs 0.40; frac_single_stream is the kernel's own number)
     stagger = 0.0
     if args.streams > 1:
-        stagger = args.stagger if args.stagger is not None else 0.0
+        stagger = args.stagger if args.stagger is not None else (0.2 * warm_s if warm_s is not None else 0.15)
     batches = [run(i) for i in my_jobs]                    # inputs resident in HBM before the timed region
     prof = {"human": [], "object": []}
     base_ev = torch.cuda.Event(enable_timing=True); base_ev.record()       # common time base of the per-launch events
@@ -444,6 +448,16 @@ def main():
     if use_dist:
         dist.barrier()
     SECTION_S.clear()
+    alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)          # hipMalloc calls of the caching allocator (each one synchronises the device)
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+
+    def _io():
+        try:
+            return {k_: int(v_) for k_, v_ in (l_.split(": ") for l_ in open("/proc/self/io").read().strip().splitlines())}
+        except Exception:      # noqa: BLE001
+            return {}
+    io0 = _io()
     main_streams = []          # the timed region's streams, reused by the two-in-flight half of the full-schedule leg
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
     done_at = {}            # batch position -> seconds after t0 at which its fit returned on the host (rank 0's own; shows a ramp inside the timed region)
@@ -528,6 +542,15 @@ def main():
             torch.cuda.current_stream().wait_stream(s_)
     torch.cuda.synchronize(); my_seconds = time.perf_counter() - t0      # this rank's own work (before it waits for the others)
     section_s = {k_: round(v_, 3) for k_, v_ in SECTION_S.items()}
+    section_s["device_allocs"] = int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - alloc0)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF); io1 = _io()
+    try:
+        section_s["thp_enabled"] = [l_.split()[1] for l_ in open("/proc/self/status") if l_.startswith("THP_enabled")][0]
+    except Exception:      # noqa: BLE001
+        pass
+    section_s.update({"minor_faults": ru1.ru_minflt - ru0.ru_minflt, "major_faults": ru1.ru_majflt - ru0.ru_majflt, "vol_ctx_switches": ru1.ru_nvcsw - ru0.ru_nvcsw,
+                      "invol_ctx_switches": ru1.ru_nivcsw - ru0.ru_nivcsw, "cpu_user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "cpu_sys_s": round(ru1.ru_stime - ru0.ru_stime, 2),
+                      "read_bytes": io1.get("read_bytes", 0) - io0.get("read_bytes", 0)})
     rows_of = lambda d: torch.cat([d["pose"], d["betas"], d["trans"], d["obj_R"].reshape(-1, 9), d["obj_t"], d["obj_s"][:, None]], 1)
     job_rows = None
     if use_dist and dynamic:

@@ -149,15 +149,14 @@ def lib():
 
 
 def _host_tuning():
-    """Transparent huge pages off for this process (``prctl(PR_SET_THP_DISABLE)``; ``VT_HOST_THP=keep`` leaves them alone).
+    """``VT_HOST_THP=off``: transparent huge pages off for this process (``prctl(PR_SET_THP_DISABLE)``).  Opt-in.
 
-    Measured on the MI355X boxes (THP mode "madvise", 3 TB / 256 cores): the FIRST process after the box comes up runs the fit 7 % slower than
-    every later one -- same kernel times, +63 ms of host time per batch in the object stage, +30 ms between the stages -- eight times out of eight;
-    with THP disabled for the process, or after touching and freeing 16 GB of anonymous memory first (2 GB is not enough), the first process runs
-    at the later ones' speed (profiles/r04_cold_process.txt).  The madvise'd host allocations of the launch path (runtime pools, numpy / torch
-    staging arrays) fault in as 2 MB pages, whose first allocation on a machine with a fragmented free list stalls the faulting thread in
-    compaction -- the launching thread, while its stream drains.  Nothing on the host side of this library gains from huge pages."""
-    if os.environ.get("VT_HOST_THP", "off") == "keep":
+    Round 4 chased a 7 % loss of the FIRST process in a fresh container (same kernel times, slower host sections: profiles/r04_cold_process.txt).  THP
+    looked like the cause for a while -- the first runs with this prctl, and one after touching 16 GB of anonymous memory, were fast -- but later first
+    processes were slow with THP off as well (131.5, 132.0, 131.9 frames/s) and one with THP on was fast: not the cause, or not the only one.  What
+    reliably removes the loss is keeping the launching threads out of lockstep (bench.py --stagger, PipelineConfig.fit_stagger_s).  The switch stays for
+    hosts where huge-page compaction stalls are known to hurt."""
+    if os.environ.get("VT_HOST_THP", "keep") != "off":
         return
     try:
         C.CDLL(None, use_errno=True).prctl(41, 1, 0, 0, 0)          # PR_SET_THP_DISABLE: checked at fault time, covers the mappings that exist already

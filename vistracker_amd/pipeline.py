@@ -52,10 +52,10 @@ class PipelineConfig:
     # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
     fit_streams: int = 2
-    # start offset (seconds) of stream k of the joint fit after stream k - 1: streams that start together stay in lockstep (equal batch times) and drain at
-    # the same moments, exposing the host sections behind the drains on all of them at once.  Measured: nothing on a warm host; it hid the huge-page fault
-    # stalls of a cold process until _lib._host_tuning removed those (profiles/r04_stream_stagger.txt, r04_cold_process.txt).  Off by default.
-    fit_stagger_s: float = 0.0
+    # start offset (seconds) of stream k of the joint fit after stream k - 1: streams that start together stay in lockstep (equal batch times) and
+    # their launching threads hit the host-heavy sections (object stage, set-up between the stages) at the same moments.  Nothing on a warm process,
+    # 7 % in the first process of a fresh container (bench.py --stagger, profiles/r04_cold_process.txt)
+    fit_stagger_s: float = 0.15
     # N > 1 ranks: "static" = every rank fits the batches of its own frames; "steal" = a rank that runs out takes batches from the rank with the most left
     # (sharding.StealQueue) and encodes their maps itself.  Same results either way.
     fit_handout: str = "steal"
