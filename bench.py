@@ -40,6 +40,7 @@ FLOP_PER_POINT_OBJECT = 4 * (611 * 128 + 2 * 128 * 128 + 128 * 2)
 # ALGORITHMIC FLOPs of the reference formulation; the share the kernel still executes on the MFMA pipe is reported next to it.
 FLOP_PER_POINT_HUMAN_MFMA = FLOP_PER_POINT_HUMAN - 4 * 2 * 256 * 128
 PEAK_F16_MFMA_TFLOPS = 2516.6      # MI355X_MICROARCH.md: f16/bf16 MFMA, dense (16 x the 157.3 TFLOP/s of the f32-input MFMA)
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (the strict-fp32 route, query_f32.hip)
 MFMA_PER_MAC = 3                   # split operands: one algorithmic multiply-add = hi.hi + hi.lo + lo.hi on the f16 pipe (query.hip)
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / MFMA_PER_MAC   # the roofline of the arithmetic the kernel actually issues, in algorithmic FLOPs
 # bytes through the vector-memory (texture) path per query point of the SMPL-stage kernel, counted from the launch geometry (weights
@@ -162,9 +163,10 @@ def fit_batch(ctx, torch, d, prof=None, early_stop=True, obj_stream=None):
     return r1, r2
 
 
-def solo_kernel_leg(ctx, torch, d, launches=20):
+def solo_kernel_leg(ctx, torch, d, launches=20, fp32=False):
     """The dominant kernel ALONE on the chip: `launches` back-to-back launches of vt_query_human_loss on one stream (what a single-stream
-    rocprofv3 kernel trace shows as its average duration), timed with HIP events on the launch stream, outside the timed region."""
+    rocprofv3 kernel trace shows as its average duration), timed with HIP events on the launch stream, outside the timed region.
+    ``fp32``: the same call served by the strict-fp32 kernels (vt_maps::force_fp32 -> query_f32.hip)."""
     import ctypes as C
     from vistracker_amd import _lib as L, ops
     from vistracker_amd.fitting import morton_order_device
@@ -173,7 +175,11 @@ def solo_kernel_leg(ctx, torch, d, launches=20):
         verts, _, _ = ops.smplh_forward(ctx.smpl, d["pose"], d["betas"], d["trans"])
     verts = verts.contiguous(); v0 = verts[B // 2]
     order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
-    d["maps"].build_projection(ctx.net)
+    was_fp32 = d["maps"].force_fp32
+    if fp32:
+        d["maps"].set_force_fp32(True)
+    else:
+        d["maps"].build_projection(ctx.net)
     terms = torch.zeros(2, dtype=torch.float64, device=verts.device); dv = torch.empty_like(verts)
     call = lambda: L.check(L.lib().vt_query_human_loss(ctx.net.h, C.byref(d["maps"].c), verts.data_ptr(), d["cc"].data_ptr(), d["bc"].data_ptr(), B, V,
                                                        ctx.labels.data_ptr(), order.data_ptr(), 50.0, 0.00125, dv.data_ptr(), terms.data_ptr(), L.stream_ptr()))
@@ -184,6 +190,7 @@ def solo_kernel_leg(ctx, torch, d, launches=20):
     for i in range(launches):
         call(); ev[i + 1].record()
     torch.cuda.synchronize()
+    d["maps"].set_force_fp32(was_fp32)
     return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
 
 
@@ -238,7 +245,13 @@ def strict_fp32_leg(ctx, torch, make, n_batches, streams=2):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     frames = sum(int(d["pose"].shape[0]) for d in ds)
     fs = sum(int(d["pose"].shape[0]) * (r[0].steps + r[1].steps) for d, r in zip(ds, results))
-    return {"workload": f"the first {n_batches} batches of the headline sequence on the strict-fp32 decoder kernels (exact fp32 products), {streams} in flight",
+    # the route's dominant kernel alone on the chip (f32::human_loss_kernel, query_f32.hip) against the f32-input MFMA roof
+    solo = solo_kernel_leg(ctx, torch, ds[0], launches=10, fp32=True)
+    flop = FLOP_PER_POINT_HUMAN * int(ds[0]["pose"].shape[0]) * 6890
+    roof = {"bound": "mfma", "kernel": "f32q human loss kernel (query_f32.hip: v_mfma_f32_16x16x4_f32, exact fp32 products)", "solo_launch_ms": 1e3 * solo,
+            "achieved": flop / solo / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": flop / solo / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "flop_per_launch": flop, "note": "algorithmic FLOPs of one launch (no hoisting on this route) / the kernel's solo time, HIP events on the launch stream"}
+    return {"roofline": roof, "workload": f"the first {n_batches} batches of the headline sequence on the strict-fp32 decoder kernels (exact fp32 products), {streams} in flight",
             "frames_per_s": frames / dt, "seconds": dt, "frame_steps_per_s": fs / dt,
             "adam_steps_smpl_stage": float(np.mean([r[0].steps for r in results])), "adam_steps_object_stage": float(np.mean([r[1].steps for r in results]))}
 
@@ -347,8 +360,10 @@ def main():
     ap.add_argument("--handout", choices=("auto", "static", "dynamic"), default="auto",
                     help="strong mode with N > 1 ranks: static = contiguous runs of whole batches per rank (the reference's --start/--end contract); dynamic = "
                          "every rank holds all batches' inputs and pulls the next batch index at run time from one shared counter, longest batch first "
-                         "(vistracker_amd.sharding.WorkQueue); auto = dynamic when N > 1")
-    ap.add_argument("--fp32-batches", type=int, default=8, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
+                         "(vistracker_amd.sharding.WorkQueue); auto (default) = the static shards are the headline -- the reference's contract, what a real driver "
+                         "runs: every rank holds only its own batches -- and, for N > 1, a second timed pass with the run-time hand-out is reported beside it "
+                         "(`dynamic_handout` in the line) when all K batches fit every rank's HBM")
+    ap.add_argument("--fp32-batches", type=int, default=4, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -404,7 +419,7 @@ def main():
     queue = None
     # every rank keeps ALL K batches resident for the hand-out (7.3 GB each at full resolution): "auto" falls back to the static shards when they do not fit
     fits = args.steps * 7.3e9 * args.res_scale ** 2 <= 0.6 * torch.cuda.mem_get_info(dev)[1]
-    if strong and use_dist and world > 1 and (args.handout == "dynamic" or (args.handout == "auto" and fits)):
+    if strong and use_dist and world > 1 and args.handout == "dynamic":
         order = sorted(range(args.steps), key=lambda j: -job_frames[j])        # longest first (stable): the 60-frame tail batch goes last
         queue = sharding.WorkQueue(args.steps, order)
         if not queue.shared:
@@ -462,30 +477,35 @@ def main():
     t0 = time.perf_counter(); host_wait0 = float(ctx.host_wait_s)
     done_at = {}            # batch position -> seconds after t0 at which its fit returned on the host (rank 0's own; shows a ramp inside the timed region)
     fitted = list(range(len(batches)))          # positions in ``batches`` this rank fitted (static: all of them)
-    if dynamic:
+    def run_dynamic(batches_, queue_, prof_, t_ref, done_):
+        """run-time hand-out: this rank's streams pull batch indices from the shared counter until it runs dry; returns (results, fitted positions)"""
         import threading
-        results = [None] * len(batches); fitted = []
-        streams = list(fit_streams[:max(1, args.streams)])
-        for s_ in streams:
+        res_ = [None] * len(batches_); fit_ = []
+        streams_ = list(fit_streams[:max(1, args.streams)])
+        for s_ in streams_:
             s_.wait_stream(torch.cuda.current_stream())
 
         def pull_worker(k):
             torch.cuda.set_device(dev)
             if k and stagger > 0:
                 time.sleep(k * stagger)
-            with torch.cuda.stream(streams[k]):
+            with torch.cuda.stream(streams_[k]):
                 while True:
-                    i = queue.next()
+                    i = queue_.next()
                     if i is None:
                         break
-                    results[i] = fit_batch(ctx, torch, batches[i], prof, early_stop=(i != heavy and not all_heavy)); fitted.append(i); done_at[i] = time.perf_counter() - t0
-                streams[k].synchronize()
-        th_ = [threading.Thread(target=pull_worker, args=(k,)) for k in range(len(streams))]
+                    res_[i] = fit_batch(ctx, torch, batches_[i], prof_, early_stop=(i != heavy and not all_heavy)); fit_.append(i); done_[i] = time.perf_counter() - t_ref
+                streams_[k].synchronize()
+        th_ = [threading.Thread(target=pull_worker, args=(k,)) for k in range(len(streams_))]
         for t_ in th_: t_.start()
         for t_ in th_: t_.join()
-        for s_ in streams:
+        for s_ in streams_:
             torch.cuda.current_stream().wait_stream(s_)
-        fitted.sort()
+        fit_.sort()
+        return res_, fit_
+
+    if dynamic:
+        results, fitted = run_dynamic(batches, queue, prof, t0, done_at)
     elif args.streams <= 1:
         results = [fit_batch(ctx, torch, d, prof, early_stop=(j != heavy and not all_heavy)) for j, d in zip(my_jobs, batches)]
     else:
@@ -591,10 +611,39 @@ def main():
         rank_jobs = [list(my_jobs)]
     if os.environ.get("VT_BENCH_DUMP_ROWS") and rank == 0:
         np.save(os.environ["VT_BENCH_DUMP_ROWS"], (job_rows if job_rows is not None else torch.cat([rows_of(d) for d in batches])).cpu().numpy())
-    results = [results[i] for i in fitted]; batches_fitted = [batches[i] for i in fitted]
-    batch_frames = [int(d_["pose"].shape[0]) for d_ in batches_fitted]        # (the informational legs below release the batches)
+    results = [results[i] for i in fitted]
+    batch_frames = [int(batches[i]["pose"].shape[0]) for i in fitted]        # plain ints: nothing below may keep a batch alive (the informational legs release them)
     if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+
+    dyn_leg = None
+    if strong and use_dist and world > 1 and args.handout == "auto" and fits and not os.environ.get("VT_BENCH_NO_DYNAMIC_LEG"):
+        # second timed pass, reported beside the headline: the same K batches (fresh copies) handed out at run time -- early stop makes batches uneven
+        # (282 + 452 .. 1030 + 1550 Adam steps), a shared counter evens the ranks out at the price of every rank holding all K inputs
+        order = sorted(range(args.steps), key=lambda j: -job_frames[j])
+        q2 = sharding.WorkQueue(args.steps, order)
+        if q2.shared:
+            batches.clear(); torch.cuda.empty_cache()
+            batches2 = [run(i) for i in range(args.steps)]
+            torch.cuda.synchronize(); dist.barrier()
+            t2 = time.perf_counter(); done2 = {}
+            res2, fit2 = run_dynamic(batches2, q2, None, t2, done2)
+            torch.cuda.synchronize(); mine2 = time.perf_counter() - t2
+            offs = np.concatenate([[0], np.cumsum(job_frames)]).astype(int)
+            packed = torch.zeros(int(offs[-1]), 182, device=dev)
+            for i in fit2:
+                packed[offs[i]:offs[i + 1]] = rows_of(batches2[i])
+            packed = packed.to(cdev); dist.all_reduce(packed)
+            torch.cuda.synchronize(); dist.barrier()
+            el2 = torch.tensor([time.perf_counter() - t2], device=cdev, dtype=torch.float64); dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+            rs2 = [None] * world; dist.all_gather_object(rs2, (mine2, [int(i) for i in fit2]))
+            same = bool(job_rows is not None and packed.shape == job_rows.shape and torch.equal(packed, job_rows))
+            dyn_leg = {"value": total_frames / float(el2.item()), "unit": "frames/s", "seconds": float(el2.item()), "rank_seconds": [round(float(x[0]), 4) for x in rs2],
+                       "rank_jobs": [x[1] for x in rs2], "rows_bit_identical_to_static": same,
+                       "note": "the same K batches pulled at run time from one shared counter (sharding.WorkQueue), every rank holding all K inputs"}
+            if os.environ.get("VT_BENCH_DUMP_ROWS") and rank == 0:
+                np.save(os.environ["VT_BENCH_DUMP_ROWS"] + ".dynamic.npy", packed.cpu().numpy())
+            del batches2
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -639,7 +688,12 @@ def main():
                 leg("strict_fp32", lambda: strict_fp32_leg(ctx, torch, run, min(args.fp32_batches, len(seq_batches)), max(1, args.streams)))
             torch.cuda.empty_cache()
         leg("sifnet_inference", lambda: sifnet_inference_leg(torch, syn))
-        torch.cuda.empty_cache()
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        # the pipeline keeps the maps of a 1500-frame sequence resident: it must start from an (almost) empty HBM -- a leak of the legs above shows here
+        extras["hbm_allocated_before_pipeline_gb"] = round(torch.cuda.memory_allocated(dev) / 1e9, 2)
+        if extras["hbm_allocated_before_pipeline_gb"] > 8.0:
+            print(f"bench.py: {extras['hbm_allocated_before_pipeline_gb']} GB still allocated before the demo_pipeline leg", file=sys.stderr)
         leg("demo_pipeline", lambda: pipeline_leg(torch, args.pipeline_frames))
     if rank == 0:
         frames = total_frames
@@ -734,7 +788,9 @@ def main():
                          "object_kernel_avg_ms": 1e3 * float(to.mean()),
                          "object_kernel_tflops": FLOP_PER_POINT_OBJECT * N_OBJ * float(fo.sum()) / max(to.sum(), 1e-12) / 1e12},
         }
-        for k in ("full_schedule", "smplt_prefit", "strict_fp32", "sifnet_inference", "demo_pipeline"):
+        if dyn_leg is not None:
+            line["dynamic_handout"] = dyn_leg
+        for k in ("full_schedule", "smplt_prefit", "strict_fp32", "sifnet_inference", "hbm_allocated_before_pipeline_gb", "demo_pipeline"):
             if k in extras:
                 line[k] = extras[k]
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only (rank 0's host cores)

@@ -27,6 +27,7 @@ extern "C" {
 #define VT_OK 0
 #define VT_ERR_ARG -1
 #define VT_ERR_HIP -2
+#define VT_ERR_BUSY -3     /* the resource is already held by the same thread (vt_stream_set_skip_flag: another stop flag registered for the stream) */
 
 #define VT_SMPL_V 6890
 #define VT_SMPL_J 52
@@ -465,7 +466,7 @@ int vt_fill(float *p, long n, float value, void *stream);
  * `flag` registered for `stream` the query and SMPL-H launches queued behind the stopping step return at once when *flag != 0 (the Adam / loss-history
  * launches ignore those steps already).  flag = NULL removes the registration; the owner must remove it before the flag's memory is released.
  * The registration belongs to the CALLING HOST THREAD: only launches issued by that thread on `stream` see the flag (two fits driven by two threads
- * through one stream do not interfere); registering a second, different flag for the same stream from the same thread is an error (VT_ERR_ARG). */
+ * through one stream do not interfere); registering a second, different flag for the same stream from the same thread is refused with VT_ERR_BUSY. */
 int vt_stream_set_skip_flag(void *stream, const int *flag);
 
 /* ---- bookkeeping of one round of the surface-point generator (recon/gen/generator.py:149-212, Generator.gen_pc_batch) ----------------------------------

@@ -232,6 +232,10 @@ def test_silsetup_kernels_vs_host_restatement():
         om[b] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1) & (rng.uniform(size=(S, S)) > 0.03)
         pm[b] = (((yy - cy - 0.6 * ry) / (1.2 * ry)) ** 2 + ((xx - cx + 0.5 * rx) / (0.8 * rx)) ** 2 < 1)
     pm[6] = pm[0]                                                   # frame 6: person only, no object pixel at all
+    # frame 1: a SOFT halo of 0.501 around the object -- above 0.5 but (0.501 * 255) truncated = 127 is background for the reference's uint8 threshold
+    # (opt_utils.mask2bbox): the box must not grow with it (the kernel used to test m > 0.5)
+    halo = (((yy - 200) / 150) ** 2 + ((xx - 300) / 190) ** 2 < 1) & (om[1] == 0)
+    om[1][halo] = 0.501
     cc = (np.tile([[1018.952, 779.486]], (B, 1)) + rng.normal(0, 30, (B, 2))).astype(np.float32)
     ov, of = syn.object_template()
     dev_side = PS.SilLossROI(cu(pm), cu(om), (ov, of), cu(cc), camera_params={}, crop_size=1200, net_input_size=512)

@@ -252,7 +252,7 @@ def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
         assert abs(res.steps - len(losses)) <= 2, (res.steps, len(losses))
         n = min(res.steps, len(losses))
         assert rel(res.losses[:n], losses[:n]) < 5e-3
-        assert mean < max(2e-3, 3 * self_mean), msg
+        assert mean < max(2e-3, 3 * self_mean) and mean < 3e-3, msg          # (absolute ceiling: the bound must not scale with the run's own chaos alone)
     else:
         # piecewise-constant objective: 300 'sil' steps separate ANY two runs -- measured on the MI355X: HIP vs oracle 3.0e-3 m, HIP vs the same HIP
         # path started 1e-6 m away 4.7e-3 m.  The bar is therefore the path's own sensitivity: the oracle must be no further from the HIP result

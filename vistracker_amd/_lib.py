@@ -164,6 +164,9 @@ def _host_tuning():
         pass
 
 
+VT_OK, VT_ERR_ARG, VT_ERR_HIP, VT_ERR_BUSY = 0, -1, -2, -3        # include/vistracker.h
+
+
 def check(rc: int):
     if rc != 0:
         raise VtError(f"libvistracker_hip error {rc}: {lib().vt_last_error().decode()}")

@@ -1283,7 +1283,7 @@ extern "C" int vt_stream_set_skip_flag(void *stream, const int *flag)
         if (t_skip_tab[i].st == st && t_skip_tab[i].dev == dev) {
             // a second fit of THIS thread on the stream while the first one's flag is still registered (nested / leaked registration): refuse instead of
             // redirecting the first fit's launches to another flag
-            VT_REQUIRE(!flag || t_skip_tab[i].flag == flag, "vt_stream_set_skip_flag: another stop flag is already registered for this stream by this thread");
+            if (flag && t_skip_tab[i].flag != flag) VT_FAIL(VT_ERR_BUSY, "vt_stream_set_skip_flag: another stop flag is already registered for this stream by this thread");
             if (!flag) { t_skip_tab[i] = t_skip_tab.back(); t_skip_tab.pop_back(); }
             return VT_OK;
         }

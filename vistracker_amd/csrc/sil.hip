@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256) void sil_setup_box_kernel(const float *__restr
     const float *m = mask_o + (size_t)b * H * W;
     int x0 = W, x1 = -1, y0 = H, y1 = -1;
     for (int i = tid; i < H * W; i += 256)
-        if (m[i] > 0.5f) { const int y = i / W, x = i - y * W; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
+        // the reference's loader thresholds the uint8 image: (m * 255) truncated > 127 (opt_utils.mask2bbox via obj_pose_roi.py:179; silhouette.masks2bbox) --
+        // identical to m > 0.5 for the 256 values k / 255, NOT for soft masks in (0.5, 128 / 255)
+        if ((int)(m[i] * 255.0f) > 127) { const int y = i / W, x = i - y * W; x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y); }
     red[0][tid] = x0; red[1][tid] = x1; red[2][tid] = y0; red[3][tid] = y1;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {

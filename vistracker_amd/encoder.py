@@ -391,12 +391,24 @@ class SIFNetEncoder:
     use_graph = os.environ.get("VT_ENCODER_GRAPH", "1") != "0"
     _graph = None
 
+    def _graph_key(self):
+        return (self.__dict__.get("_graph_epoch", 0),) + tuple(bool(e.use_hip_conv) for e in [self.image] + list(self.tri))
+
+    def invalidate_graph(self):
+        """call after changing weights (the state dict the encoders were built from) or any switch the captured pass depends on"""
+        self._graph_epoch = self.__dict__.get("_graph_epoch", 0) + 1
+
     def _chunk_graph(self, x):
         import threading
         lock = self.__dict__.setdefault("_graph_lock", threading.Lock())
-        lock.acquire()
+        lock.acquire(); held = True
         try:
             ent = self._graph
+            # a captured graph keeps its kernels and their arguments: a switch of the convolution route (HGFilterEncoder.use_hip_conv, the tests toggle it)
+            # or a call of invalidate_graph() after a weight reload must not be served by a stale replay
+            key = self._graph_key()
+            if ent not in (None, False) and ent[4] != key:
+                ent = None
             if ent is None:
                 try:
                     sx = x.clone()
@@ -409,7 +421,7 @@ class SIFNetEncoder:
                     # (thread_local: another host thread -- the pipeline's generator or a second fit stream -- may allocate or synchronise meanwhile)
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         so = self._chunk_eager(sx)
-                    ent = (g, sx, so, torch.cuda.Event())
+                    ent = (g, sx, so, torch.cuda.Event(), key)
                     ent[3].record()
                 except Exception as e:                      # noqa: BLE001 -- something in the pass cannot be captured on this build: stay eager, say so once
                     import warnings
@@ -417,9 +429,9 @@ class SIFNetEncoder:
                     ent = False
                 self._graph = ent
             if ent is False or ent[1].shape != x.shape:
-                lock.release()
+                lock.release(); held = False                # the eager pass runs OUTSIDE the lock (and outside this handler's release)
                 return self._chunk_eager(x), None
-            g, sx, so, ev = ent
+            g, sx, so, ev = ent[:4]
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)                              # the previous caller has copied the static outputs out
             sx.copy_(x)
@@ -429,5 +441,6 @@ class SIFNetEncoder:
                 ev.record(); lock.release()
             return so, done
         except BaseException:
-            lock.release()
+            if held:
+                lock.release()
             raise

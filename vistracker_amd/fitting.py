@@ -669,10 +669,12 @@ class FitContext:
             yield False
             return
         sp = L.stream_ptr()
-        if _lib().vt_stream_set_skip_flag(sp, stop.data_ptr()) != 0:
-            # this thread already has another fit's flag registered for the stream (nested fits): run without the device-side skip
+        rc = _lib().vt_stream_set_skip_flag(sp, stop.data_ptr())
+        if rc == L.VT_ERR_BUSY:
+            # this thread already has another fit's flag registered for the stream (nested fits): run without the device-side skip (and the look-ahead)
             yield False
             return
+        L.check(rc)                 # anything else is an error, not a reason to silently lose the skip
         try:
             yield True
         finally:

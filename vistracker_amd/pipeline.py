@@ -244,7 +244,9 @@ class SequencePipeline:
         steal = None
         if world > 1 and cfg.fit_handout == "steal":
             steal = sharding.StealQueue([len(x) for x in all_shards], rank)
-            if not steal.shared:
+            # the choice below decides which collective ends the stage (reduce_rows_exact vs gather_params): it must be the SAME on every rank, so the
+            # ranks agree on "everybody got the shared store" first -- one rank falling back alone would hang the job in mismatched collectives
+            if not sharding.all_ranks_agree(steal.shared, self.device):
                 steal = None
         rows = {}; steps = {}
         import threading
@@ -285,15 +287,18 @@ class SequencePipeline:
                 yield j
 
         nstream = cfg.fit_streams if (resident and cfg.reuse_neural and not self.fitter.profile) else 1
+        errors = []
         if nstream <= 1 or (len(shards) <= 1 and steal is None):
-            for owner, idx in jobs_of(0, 1):
-                fit_one(owner, idx, self.fitter, self.generator)
+            try:
+                for owner, idx in jobs_of(0, 1):
+                    fit_one(owner, idx, self.fitter, self.generator)
+            except Exception as ex:             # noqa: BLE001 -- re-raised below, after the ranks agreed
+                errors.append(ex)
         else:
             import copy
             streams = concurrent_streams(nstream, self.device)
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
-            errors = []
 
             def worker(k):
                 # the network object carries "the feature maps of the current batch" (the reference's filter() -> query() protocol): every
@@ -315,8 +320,11 @@ class SequencePipeline:
             for t_ in th: t_.join()
             for st in streams:
                 torch.cuda.current_stream().wait_stream(st)
-            if errors:
-                raise errors[0]
+        # a rank whose fit raised must not leave the others waiting in the stage's final collective: everybody learns about it first
+        if world > 1 and not sharding.all_ranks_agree(not errors, self.device):
+            raise errors[0] if errors else RuntimeError("joint fit failed on another rank")
+        if errors:
+            raise errors[0]
         self.log.setdefault("fit_steps", []).extend(steps[s_] for s_ in sorted(steps))
         self.log["fit_batches"] = sorted(rows); self.log["stolen_batches"] = steal.stolen if steal is not None else 0
         if steal is None:

@@ -179,6 +179,19 @@ class StealQueue:
             # lost the race for that owner's last item: look again
 
 
+def all_ranks_agree(flag: bool, device=None) -> bool:
+    """True iff ``flag`` is true on EVERY rank (one all_reduce MIN; a world of one rank: the flag itself).  Ranks that pick between two collective
+    patterns from a rank-local fact -- e.g. "did I get the process group's store" -- must agree first, or the job hangs in mismatched collectives."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    on_host = dist.get_backend() == "gloo" or device is None
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def reduce_rows_exact(table, filled_rows):
     """Every rank holds ``table`` (T, D) float32 with the rows it produced (``filled_rows``: bool (T,)) and zeros elsewhere; returns the table with every
     row from the rank that produced it, bit for bit (the sum runs on the int32 view: adding integer zeros cannot change a bit pattern, not even the sign

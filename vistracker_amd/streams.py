@@ -33,9 +33,11 @@ def _timed(streams):
 
 
 def overlaps(a, b) -> bool:
-    """do streams a and b execute concurrently (different hardware queues)?"""
-    one = min(_timed([a]), _timed([a]))
-    two = min(_timed([a, b]), _timed([a, b]))
+    """do streams a and b execute concurrently (different hardware queues)?  Wall-clock test around device-wide synchronisations: call it while the
+    device is otherwise IDLE (another thread's GPU work lengthens both measurements and can make an overlapping pair look serial); the minimum over
+    four repetitions keeps a stray host hiccup from rejecting a good pair."""
+    one = min(_timed([a]) for _ in range(4))
+    two = min(_timed([a, b]) for _ in range(4))
     return two < 1.5 * one
 
 
@@ -63,5 +65,6 @@ def concurrent_streams(n: int, device=None, with_current: bool = True, max_tries
             if len(good) < n:
                 import warnings
                 warnings.warn(f"concurrent_streams: only {len(good)} of {n} mutually concurrent streams found on {dev}; the rest may share a hardware queue")
-                good.extend(torch.cuda.Stream(device=dev) for _ in range(n - len(good)))
+                # the untested fill-ins are NOT cached: a later call must not take them for tested streams (nor test new candidates against them)
+                return list(good) + [torch.cuda.Stream(device=dev) for _ in range(n - len(good))]
             return list(good[:n])
