@@ -39,6 +39,13 @@ for thr in variants:
     print(f"variant {thr}: {ms:.3f} ms/launch = {0.59265024 / ms * 1e3:.0f} TFLOP/s algorithmic = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; "
           f"finite {bool(torch.isfinite(dp).all())}; rerun bit-identical {bool(torch.equal(dp, first[0]))} terms {bool(torch.equal(terms, first[1]))}")
     res[thr] = (first[0].cpu().numpy(), first[1].cpu().numpy())
+    import os
+    if os.environ.get("QAB_DUMP"):          # A/B across builds (VT_LIB_PATH): dump, then compare the files bit for bit (QAB_CMP)
+        np.savez(os.environ["QAB_DUMP"] + f"_{thr}.npz", dp=res[thr][0], terms=res[thr][1])
+    if os.environ.get("QAB_CMP"):
+        ref = np.load(os.environ["QAB_CMP"] + f"_{thr}.npz")
+        print(f"variant {thr} vs {os.environ['QAB_CMP']}: gradients bit-identical {np.array_equal(ref['dp'], res[thr][0])}, terms bit-identical {np.array_equal(ref['terms'], res[thr][1])}, "
+              f"max |diff| {np.abs(ref['dp'] - res[thr][0]).max():.3e}")
 L.check(L.lib().vt_query_set_human_kernel(256))
 a = res[variants[0]]
 for v in variants[1:]:

@@ -62,4 +62,8 @@ for mode, n in ((("human", N),) if pc else (("human", N), ("object", 3000))):
             print(role, "clocks per workgroup (two tiles):", {k: int(x / wgs) for k, x in zip(names, v) if k != "-"}, "total", int(v[:6].sum() / wgs))
             print("   fine timers of the L1 fwd loop, clocks per workgroup:", [int(x / wgs) for x in list(out)[16 + o:16 + o + 8]])
         continue
+    fine = np.array(list(out)[8:24], np.float64)
+    if fine.sum() > 0:      # slots of the two-head hidden pipeline (PCLK(8..) after each barrier); they are part of the hidden phase, whose own bin holds only the tail
+        out[2] = int(out[2] + fine.sum())
+        print(mode, "hidden-pipeline slots, clocks per WG:", [int(x / 5 / (B * ((n + 63) // 64))) for x in fine if x > 0])
     v = np.array(list(out)[:5], np.float64); print(mode, "share per phase:", {k: f"{100 * x / v.sum():.1f}%" for k, x in zip(names, v)}, "clocks per WG:", int(v.sum() / 5 / (B * ((n + 63) // 64))))

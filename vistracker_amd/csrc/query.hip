@@ -382,12 +382,21 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
 // v_med3_f32); asm only ever sees their results.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, h2)); }      // v_cvt_pk_f16_f32 (RTN)
+#ifndef RELU_MAX_ASM
+#define RELU_MAX_ASM 1
+#endif
 // ReLU + split of two pre-activations whose RAW fp16 conversion `hr` is already known: hi = max(hr, 0) (packed, = fp16(max(x, 0)): the conversion is
 // monotone), lo = fp16(y - hi) with y = max(x, 0).  8 VALU instructions per pair with the range tracker (y >= 0: no |.|).
 __device__ __forceinline__ void relu_split2(float x0, float x1, unsigned hr, unsigned &hi, unsigned &lo, float &rmax)
 {
     // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf is canonicalised first: two per value)
-    const float y0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff()), y1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+    float y0, y1;
+#if RELU_MAX_ASM
+    // (hipcc turns med3(x, 0, +inf) into canonicalise + max: two instructions per value; x0 / x1 were read by the caller's conversion already: HAZARD RULE)
+    asm("v_max_f32 %0, 0, %1" : "=v"(y0) : "v"(x0)); asm("v_max_f32 %0, 0, %1" : "=v"(y1) : "v"(x1));
+#else
+    y0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff()); y1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+#endif
     float r0, r1;
     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(rmax) : "v"(y0), "v"(y1));
     asm("v_pk_max_f16 %0, %1, 0" : "=v"(hi) : "v"(hr));
@@ -503,6 +512,132 @@ __device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
 }
 
+// ---- two-head pipeline of the hidden layers (query_kernel<2, MODE_HUMAN>, HPIPE): a wave alone on its SIMD spends the hidden phase as GEMM (96 MFMAs, matrix
+// pipe busy, VALU idle) -> epilogue (~200 VALU, matrix pipe idle) -> barrier -> plane stores -> barrier -> ...: a serial chain (52 k of the 145 k clocks of a
+// workgroup alone on a CU, profiles/r05_phase_1wg_vs_2wg.txt).  The SIMD issues ~2 independent VALU instructions per v_mfma_f32_16x16x32_f16 for free
+// (profiles/r05_coexec.txt), so the two heads leapfrog: while the GEMM of one head runs, the epilogue of the OTHER head's previous GEMM is issued between its MFMAs
+// and its split halves go straight to that head's planes (every reader of them is behind the barrier that ended the previous slot): one barrier per GEMM instead
+// of two, no packed halves held in registers, the weight fragments of the next GEMM reloaded K32 step by K32 step into the registers the current one just
+// finished with.  Same MFMA sequence per accumulator and the same epilogue arithmetic as the head-by-head form: bit-identical results.
+#ifndef HPIPE
+#define HPIPE 1
+#endif
+enum { EPI_RELU = 1, EPI_MASK = 2 };
+// epilogue of ONE D fragment F = 4 nt + p (four hidden units of one point) + store of its split halves into the planes.  EPI_RELU: `m` collects the raw
+// sign bits (the caller inverts it once all eight fragments are through: relu_pack); EPI_MASK: `m` is the activity mask (mask_pack)
+template <int EPI, int F>
+__device__ __forceinline__ void epi_frag(const Acc8 &c, unsigned &m, uint2 *hi8, uint2 *lo8, int wave, int lane, float &rmax)
+{
+    constexpr int nt = F >> 2, p = F & 3;
+    const int q = lane >> 4, j = lane & 15;
+    const f32x4 x = c.v[nt][p];
+    uint2 hi, lo;
+    if (EPI == EPI_RELU) {
+        const unsigned h01 = cvt_pk(x[0], x[1]), h23 = cvt_pk(x[2], x[3]);
+        sign_bits<F>(m, h01, h23);
+        relu_split2(x[0], x[1], h01, hi.x, lo.x, rmax);
+        relu_split2(x[2], x[3], h23, hi.y, lo.y, rmax);
+    } else {
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            unsigned keep;
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(MASK_BIT(F, r)));
+            y[r] = __uint_as_float(__float_as_uint(x[r]) & keep);
+        }
+        split2_nr(y[0], y[1], hi.x, lo.x); split2_nr(y[2], y[3], hi.y, lo.y);
+    }
+    const int idx = (((4 * wave + 2 * nt + (q >> 1)) * 64 + 16 * p + j) << 1) + (q & 1);
+    hi8[idx] = hi; lo8[idx] = lo;
+}
+template <int EPI>
+__device__ __forceinline__ void epi_all(const Acc8 &c, unsigned &m, uint2 *hi8, uint2 *lo8, int wave, int lane, float &rmax)
+{
+    epi_frag<EPI, 0>(c, m, hi8, lo8, wave, lane, rmax); epi_frag<EPI, 1>(c, m, hi8, lo8, wave, lane, rmax);
+    epi_frag<EPI, 2>(c, m, hi8, lo8, wave, lane, rmax); epi_frag<EPI, 3>(c, m, hi8, lo8, wave, lane, rmax);
+    epi_frag<EPI, 4>(c, m, hi8, lo8, wave, lane, rmax); epi_frag<EPI, 5>(c, m, hi8, lo8, wave, lane, rmax);
+    epi_frag<EPI, 6>(c, m, hi8, lo8, wave, lane, rmax); epi_frag<EPI, 7>(c, m, hi8, lo8, wave, lane, rmax);
+}
+// reload the fragments of K32 step s of a T-pack (the registers the GEMM in flight just finished with) with the next GEMM's
+__device__ __forceinline__ void wreload(WPre &p, int s, const uint4 *__restrict__ Wp, int wave, int lane)
+{
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[(unsigned)(wave * 256 + lane) + (unsigned)(s * 1024 + (nt * 2 + hl) * 64)];
+}
+template <bool HAS>
+__device__ __forceinline__ void bias_load(float4 (&b)[2], const float *__restrict__ bias, int wave, int lane)
+{
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+        b[nt] = HAS ? *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// B fragments of one K32 step for HALF the points of the wave tile (p = 2 half + {0, 1}): 16 registers.  The GEMMs below run a K32 step as two half steps
+// and request the fragments of the next K32 step's half as soon as the MFMAs of this step's half have been issued (same registers): the LDS round trip -- ~400
+// clocks when the four waves of a workgroup leave a barrier together and all ask for 8 x 1 KB -- runs under the other half's 12 MFMAs instead of in front of all 24.
+// Per accumulator the products still arrive as hi.hi, hi.lo, lo.hi of step 0, 1, 2, 3: the bits of k32_step.
+struct BHalf { h8 xh[2], xl[2]; };
+__device__ __forceinline__ void bhalf_load(BHalf &b, const uint4 *Xhi, const uint4 *Xlo, int kb_base, int half, int lane)
+{
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) { b.xh[pp] = as_h8(Xhi[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); b.xl[pp] = as_h8(Xlo[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); }
+}
+__device__ __forceinline__ void mfma12(Acc8 &c, const uint4 (&w)[2][2], const BHalf &b, int half)
+{
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xh[pp], c.v[nt][2 * half + pp]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xl[pp], c.v[nt][2 * half + pp]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][1]), b.xh[pp], c.v[nt][2 * half + pp]);
+}
+// scheduling fence that pins matrix instructions and LDS reads to their side, everything else (VALU, SALU, vector memory, LDS writes) may cross
+#define SB_PIN_MFMA_DSREAD() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x200 | 0x400)
+// cg = M x X (gemm128) with the epilogue of `ce` (another head's finished accumulators) issued between its MFMAs: one fragment per half step.  `nextW` (may be
+// NULL): T-pack of the GEMM that follows in this wave's stream, `nextBias` its bias (NULL: zeros).  EPI = 0: no epilogue
+template <int EPI, int F>
+__device__ __forceinline__ void epi_opt(const Acc8 &ce, unsigned &m, uint2 *Ehi8, uint2 *Elo8, int wave, int lane, float &rmax)
+{
+    if (EPI != 0) epi_frag<(EPI ? EPI : EPI_RELU), F>(ce, m, Ehi8, Elo8, wave, lane, rmax);
+}
+// (NEXTW / NEXTB are compile-time: a run-time test of the pointers would put branches -- scheduling region borders -- between the half steps)
+template <int EPI, bool NEXTW, bool NEXTB>
+__device__ __forceinline__ void gemm128_epi(Acc8 &cg, const uint4 *Xhi, const uint4 *Xlo, WPre &w, const uint4 *__restrict__ nextW, const float *__restrict__ nextBias,
+                                            const Acc8 &ce, unsigned &m, uint2 *Ehi8, uint2 *Elo8, int wave, int lane, float &rmax)
+{
+    BHalf bA, bB;
+    bhalf_load(bA, Xhi, Xlo, 0, 0, lane); bhalf_load(bB, Xhi, Xlo, 0, 1, lane);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) cg.v[nt][pp] = (f32x4){w.bias[nt].x, w.bias[nt].y, w.bias[nt].z, w.bias[nt].w};
+    float4 nb[2];
+    bias_load<NEXTB>(nb, nextBias, wave, lane);
+#define GEMM_EPI_STEP(s_)                                                                                       \
+    SB_PIN_MFMA_DSREAD();                                                                                       \
+    mfma12(cg, w.v[s_], bA, 0);                                                                                 \
+    SB_PIN_MFMA_DSREAD();                                                                                       \
+    if ((s_) < 3) bhalf_load(bA, Xhi, Xlo, 4 * ((s_) + 1), 0, lane);                                            \
+    epi_opt<EPI, 2 * (s_)>(ce, m, Ehi8, Elo8, wave, lane, rmax);                                                \
+    SB_PIN_MFMA_DSREAD();                                                                                       \
+    mfma12(cg, w.v[s_], bB, 1);                                                                                 \
+    SB_PIN_MFMA_DSREAD();                                                                                       \
+    if ((s_) < 3) bhalf_load(bB, Xhi, Xlo, 4 * ((s_) + 1), 1, lane);                                            \
+    if (NEXTW) wreload(w, (s_), nextW, wave, lane);                                                             \
+    epi_opt<EPI, 2 * (s_) + 1>(ce, m, Ehi8, Elo8, wave, lane, rmax);
+    GEMM_EPI_STEP(0) GEMM_EPI_STEP(1) GEMM_EPI_STEP(2) GEMM_EPI_STEP(3)
+#undef GEMM_EPI_STEP
+    SB_PIN_MFMA_DSREAD();
+    w.bias[0] = nb[0]; w.bias[1] = nb[1];
+}
 // Compile-time interleave of the MFMAs of one chunk with the independent VALU work of the next (blend / split of the taps): left to itself
 // hipcc issues the 24 G MFMAs of a K32 step back to back (the wave then waits 16 cycles per MFMA with empty VALU slots) and the ~100 VALU
 // instructions of the blend afterwards (with an idle matrix pipe).  MEASURED: no effect (2.033 vs 2.039 ms per launch of the SMPL-stage kernel; the
@@ -719,11 +854,13 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 #undef LOAD_W1
     PCLK(1);
     __syncthreads();        // region 0 changes role: chunk buffers -> hidden-activation planes
+    constexpr bool PIPE2 = (G == 2) && (MODE == MODE_HUMAN) && HPIPE;
+    constexpr int GH = PIPE2 ? 0 : G;        // the head-by-head form below runs for every other instantiation
     // hidden-1 activations of ALL heads go to their planes right away: no head's layer-1 accumulators stay live in registers
     // while another head runs its layers 2..4 and backward.  The layer-1 bias came in through the constant-one channel of the xyz step.
     unsigned m1s[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
+    for (int g = 0; g < GH; g++) {
         Packed8 pk;
         m1s[g] = relu_pack(acc1[g], pk, rmax);
         planes_store(pk, reinterpret_cast<uint2 *>(Hp + g * 2048), reinterpret_cast<uint2 *>(Hp + g * 2048 + 1024), wave, lane); OVF_PUBLISH();
@@ -731,8 +868,181 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 
     // ---- per head: layers 2..4, objective / upstream gradient, backward to d(hidden-1)
     double loss_acc[2] = {0.0, 0.0};
+    if constexpr (PIPE2) {
+        // ---- layer 4 (points as rows: wave w owns the 16 points of tile w, columns = up to 16 outputs, zero padded), the objective / upstream gradient of head g and
+        //      its per-point normalisation into the gradient buffer Gg ({hi [2 kb][64], lo [2 kb][64]}); returns false for MODE_FWD (nothing to back-propagate)
+        // (the global operands of the objective -- layer-4 weight fragments, bias, part labels of the wave's points -- are requested by obj_prefetch, which the
+        //  two-head pipeline issues a slot ahead: inside head_objective their latency would sit in front of a serial chain)
+        struct ObjPre { uint4 w4[8]; float bias4; int lab[4]; };
+        auto obj_prefetch = [&](const int g, ObjPre &o) {
+            const HeadW &hw = a.hw[g];
+    #pragma unroll
+            for (int i = 0; i < 8; i++) o.w4[i] = hw.w4p[i * 64 + lane];
+            o.bias4 = hw.b4[j];
+    #pragma unroll
+            for (int r = 0; r < 4; r++) o.lab[r] = (MODE == MODE_HUMAN && hw.id != 0) ? a.labels[sIn[wave * 16 + q * 4 + r] >> 1] : 0;
+        };
+        auto head_objective = [&](const int g, const uint4 *Hhi, const uint4 *Hlo, uint4 *Gg, const ObjPre &op, const bool pre) {       // !pre: operands loaded in place
+            const HeadW &hw = a.hw[g];
+            f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const h8 xh = as_h8(Hhi[(4 * s + q) * 64 + 16 * wave + j]), xl = as_h8(Hlo[(4 * s + q) * 64 + 16 * wave + j]);
+                const h8 wh = as_h8(pre ? op.w4[s * 2 + 0] : hw.w4p[(s * 2 + 0) * 64 + lane]), wl = as_h8(pre ? op.w4[s * 2 + 1] : hw.w4p[(s * 2 + 1) * 64 + lane]);
+                o4 = MFMAH(xh, wh, o4); o4 = MFMAH(xl, wh, o4); o4 = MFMAH(xh, wl, o4);
+            }
+            const float bias4 = pre ? op.bias4 : hw.b4[j];
+            float go[4];    // upstream gradient of output j at points wave*16 + q*4 + r
+    #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pt = wave * 16 + q * 4 + r, n = n0 + pt;
+                const bool valid = n < a.N, live = j < hw.kout;
+                const bool inimg = (sIn[pt] & 1) != 0;
+                const int pn = sIn[pt] >> 1;
+                float val = o4[r] * hw.cout + bias4;
+                if (*sOvf) val = __builtin_nanf("");        // an operand left the split range: no silent finite garbage
+                go[r] = 0.f;
+                if (MODE == MODE_FWD) {
+                    if (hw.id == 0 && !inimg) val = OUT_DIST;                       // df[~in_img] = 5.0 (chore_triplane.py:156-159)
+                    if (hw.id == 4) val = 1.0f / (1.0f + expf(-val));                // sigmoid on visibility (chore_tri_vis.py:22-27)
+                    if (valid && live) a.out[g][((size_t)b * hw.kout + j) * a.N + pn] = val;
+                } else if (MODE == MODE_BWD) {
+                    float gg = (valid && live) ? a.gout[g][((size_t)b * hw.kout + j) * a.N + pn] : 0.f;
+                    if (hw.id == 0 && !inimg) gg = 0.f;
+                    if (hw.id == 4) { const float s = 1.0f / (1.0f + expf(-val)); gg *= s * (1.0f - s); }
+                    go[r] = gg;
+                } else if (MODE == MODE_HUMAN) {
+                    if (hw.id == 0) {
+                        // df_h = clamp(df[:,0], max=.1).mean()  (recon_fit_base.py:640-647)
+                        if (j == 0 && valid) {
+                            const float d = inimg ? val : OUT_DIST;
+                            loss_acc[0] += (double)fminf(d, 0.1f);
+                            if (inimg && d <= 0.1f) go[r] = a.w0 / ((float)a.B * (float)a.N);
+                        }
+                    } else {
+                        // part = mean_B sum_N CE(parts, labels)  (recon_fit_behave.py:486): softmax over the 14 logits held by lanes j<14
+                        const float mx = row16_max(live ? val : -INFINITY);
+                        const float e = live ? expf(val - mx) : 0.f;
+                        const float se = row16_sum(e);
+                        const int lab = pre ? op.lab[r] : a.labels[pn];
+                        if (valid && live) {
+                            go[r] = (e / se - (j == lab ? 1.f : 0.f)) * a.w1 / (float)a.B;
+                            if (j == lab) loss_acc[1] += (double)(logf(se) - (val - mx));
+                        }
+                    }
+                } else if (MODE == MODE_PROJECT) {
+                    // Generator.approx_surface (recon/gen/generator.py:72-103): target = clamp(df[:, idx], max = threshold), the step
+                    // differentiates sum(target): gradient 1 where the prediction is below the threshold and the point is in the image
+                    if (j == a.df_idx) {
+                        const float d = inimg ? val : OUT_DIST;
+                        sDf[pt] = fminf(d, a.w0);
+                        if (valid && inimg && d <= a.w0) go[r] = 1.0f;
+                    }
+                } else {  // MODE_OBJECT: object = mean_B( mean_N clamp(df[:,1], max=.8) * occ )  (recon_fit_trivis_full.py:155-162)
+                    if (j == 1 && valid) {
+                        const float d = inimg ? val : OUT_DIST, ob = a.occ[b];
+                        loss_acc[0] += (double)(fminf(d, 0.8f) * ob);
+                        if (inimg && d <= 0.8f) go[r] = a.w0 * ob / ((float)a.B * (float)a.N);
+                    }
+                }
+            }
+            if (MODE == MODE_FWD) return;
+            // ---- normalise the upstream gradient per point (the backward chain is linear in it): go' = go * 2^e with
+            //      max_o |go'| in [2^GO_EXP, 2^(GO_EXP+1)); the inverse is applied to d(features) in the layer-1 backward
+    #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float m = row16_max(fabsf(go[r]));
+                const int eb = (int)((__float_as_uint(m) >> 23) & 255u);
+                const int ge = hw.goexp;                            // go' in [2^ge, 2^(ge+1)): the weight scales s_4 s_3 s_2 of the chain are taken out in advance
+                const bool ok = eb >= ge + 2 && eb >= 2 && eb < 255 && eb - ge < 254;      // zero / denormal-sized / non-finite gradients pass unscaled
+                const float s = ok ? __uint_as_float((unsigned)(254 + ge - eb) << 23) : 1.0f;
+                const float inv = ok ? __uint_as_float((unsigned)(eb - ge) << 23) : 1.0f;
+                const int pt = wave * 16 + q * 4 + r;
+                if (j == 0) sInv[g * 64 + pt] = inv;
+                const float x = go[r] * s;
+                const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
+                _Float16 *gh = reinterpret_cast<_Float16 *>(Gg), *gl = reinterpret_cast<_Float16 *>(Gg + 128);
+                gh[((j >> 3) * 64 + pt) * 8 + (j & 7)] = hi; gl[((j >> 3) * 64 + pt) * 8 + (j & 7)] = lo;
+            }
+        };
+        // ---- backward through layer 4: g3[n][pt] = W4[o][n] . go'[o][pt]   (K = 16 outputs, zero padded to one K32 step); w = the four w4tp fragments of the wave
+        auto head_g4t = [&](Acc8 &c, const uint4 (&w)[2][2], const uint4 *Gg) {
+            acc_zero(c);
+            h8 xh[4], xl[4];
+    #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                xh[p] = as_h8(q < 2 ? Gg[q * 64 + 16 * p + j] : z); xl[p] = as_h8(q < 2 ? Gg[128 + q * 64 + 16 * p + j] : z);
+            }
+    #pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+    #pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xh[p], c.v[nt][p]);
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xl[p], c.v[nt][p]);
+                    c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
+                }
+        };
+        // ---- the two heads leapfrog through layers 2..4 and back (see gemm128_epi): slot k = { GEMM of one head | epilogue of the other head's previous GEMM,
+        //      stored straight into that head's planes } + ONE barrier.  P0 / P1 = the planes of head 0 / 1, in place as before.
+        uint4 *P0 = Hp, *P1 = Hp + 2048;
+        uint2 *P0h = reinterpret_cast<uint2 *>(P0), *P0l = reinterpret_cast<uint2 *>(P0 + 1024), *P1h = reinterpret_cast<uint2 *>(P1), *P1l = reinterpret_cast<uint2 *>(P1 + 1024);
+        uint4 *Go0 = Go, *Go1 = reinterpret_cast<uint4 *>(sGeo);      // the tap-geometry ring (6 KB) is idle between the two layer-1 loops: second gradient buffer (4 KB)
+        const HeadW &h0 = a.hw[0], &h1 = a.hw[1];
+        WPre w;
+        Acc8 c0, c1;
+        unsigned m1_0 = 0, m1_1 = 0, m2_0 = 0, m2_1 = 0, m3_0 = 0, m3_1 = 0;
+        wprefetch(w, h0.w2p, wave, lane, h0.b2);
+        epi_all<EPI_RELU>(acc1[0], m1_0, P0h, P0l, wave, lane, rmax); m1_0 = ~m1_0; OVF_PUBLISH();
+        __syncthreads();                                                                                        // H1[0] visible
+        PCLK(8);
+        gemm128_epi<EPI_RELU, true, true>(c0, P0, P0 + 1024, w, h1.w2p, h1.b2, acc1[1], m1_1, P1h, P1l, wave, lane, rmax); m1_1 = ~m1_1; OVF_PUBLISH();      // L2[0] | E1[1]
+        __syncthreads();                                                                                        // H1[1] visible; P0 read
+        PCLK(9);
+        gemm128_epi<EPI_RELU, true, true>(c1, P1, P1 + 1024, w, h0.w3p, h0.b3, c0, m2_0, P0h, P0l, wave, lane, rmax); m2_0 = ~m2_0; OVF_PUBLISH();           // L2[1] | E2[0]
+        __syncthreads();                                                                                        // H2[0] visible; P1 read
+        PCLK(10);
+        gemm128_epi<EPI_RELU, true, true>(c0, P0, P0 + 1024, w, h1.w3p, h1.b3, c1, m2_1, P1h, P1l, wave, lane, rmax); m2_1 = ~m2_1; OVF_PUBLISH();           // L3[0] | E2[1]
+        __syncthreads();                                                                                        // H2[1] visible; P0 read
+        PCLK(11);
+        gemm128_epi<EPI_RELU, true, false>(c1, P1, P1 + 1024, w, h0.w3tp, nullptr, c0, m3_0, P0h, P0l, wave, lane, rmax); m3_0 = ~m3_0; OVF_PUBLISH();       // L3[1] | E3[0]
+        __syncthreads();                                                                                        // H3[0] visible; P1 read
+        PCLK(12);
+        uint4 w4a[2][2], w4b[2][2];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int hl = 0; hl < 2; hl++) { w4a[nt][hl] = h0.w4tp[(((size_t)wave * 2 + nt) * 2 + hl) * 64 + lane]; w4b[nt][hl] = h1.w4tp[(((size_t)wave * 2 + nt) * 2 + hl) * 64 + lane]; }
+        ObjPre op0, op1;
+        obj_prefetch(0, op0); obj_prefetch(1, op1);
+        epi_all<EPI_RELU>(c1, m3_1, P1h, P1l, wave, lane, rmax); m3_1 = ~m3_1; OVF_PUBLISH();                   // E3[1]
+        head_objective(0, P0, P0 + 1024, Go0, op0, true);                                                             // L4[0], objective
+        __syncthreads();                                                                                        // H3[1], Go0 visible; P0 read
+        PCLK(13);
+        head_g4t(c0, w4a, Go0);                                                                                 // L4^T[0]
+        head_objective(1, P1, P1 + 1024, Go1, op1, true);                                                             // L4[1], objective
+        epi_all<EPI_MASK>(c0, m3_0, P0h, P0l, wave, lane, rmax);                                                // g3[0] -> P0
+        __syncthreads();                                                                                        // g3[0], Go1 visible; P1 read
+        PCLK(14);
+        head_g4t(c1, w4b, Go1);                                                                                 // L4^T[1]
+        gemm128_epi<EPI_MASK, true, false>(c0, P0, P0 + 1024, w, h1.w3tp, nullptr, c1, m3_1, P1h, P1l, wave, lane, rmax);       // W3^T[0] | g3[1] -> P1
+        __syncthreads();                                                                                        // g3[1] visible; P0 read
+        PCLK(15);
+        gemm128_epi<EPI_MASK, true, false>(c1, P1, P1 + 1024, w, h0.w2tp, nullptr, c0, m2_0, P0h, P0l, wave, lane, rmax);       // W3^T[1] | g2[0] -> P0
+        __syncthreads();                                                                                        // g2[0] visible; P1 read
+        PCLK(16);
+        gemm128_epi<EPI_MASK, true, false>(c0, P0, P0 + 1024, w, h1.w2tp, nullptr, c1, m2_1, P1h, P1l, wave, lane, rmax);       // W2^T[0] | g2[1] -> P1
+        __syncthreads();                                                                                        // g2[1] visible; P0 read
+        PCLK(17);
+        gemm128_epi<EPI_MASK, false, false>(c1, P1, P1 + 1024, w, nullptr, nullptr, c0, m1_0, P0h, P0l, wave, lane, rmax);       // W2^T[1] | d(hidden-1)[0] -> P0
+        __syncthreads();                                                                                        // P1 read
+        PCLK(18);
+        epi_all<EPI_MASK>(c1, m1_1, P1h, P1l, wave, lane, rmax);                                                // d(hidden-1)[1] -> P1
+        __syncthreads();
+        PCLK(19);
+    }
+#pragma unroll
+    for (int g = 0; g < GH; g++) {
         const HeadW &hw = a.hw[g];
         uint4 *Hhi = Hp + g * 2048, *Hlo = Hhi + 1024;
         uint2 *Hhi8 = reinterpret_cast<uint2 *>(Hhi), *Hlo8 = reinterpret_cast<uint2 *>(Hlo);
@@ -2086,7 +2396,10 @@ static size_t lds_bytes(int G)
 template <int G, int MODE, bool USEP>
 static int launch_(const QArgs &a, hipStream_t st)
 {
-    const size_t lds = lds_bytes(G);
+#ifndef LDS_PAD
+#define LDS_PAD 0       /* experiment builds only: extra dynamic LDS per workgroup, to lower the workgroups per CU */
+#endif
+    const size_t lds = lds_bytes(G) + LDS_PAD;
     VT_LDS_LIMIT((query_kernel<G, MODE, USEP>), lds);
     QArgs b = a; b.skip = vt_skip_flag_of(st);
     hipLaunchKernelGGL((query_kernel<G, MODE, USEP>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, b);
