@@ -239,11 +239,10 @@ int vt_groupnorm_stats(const float *x, int cstride, int coff, int B, int HW, int
 int vt_sifnet_set_precision(vt_sifnet *h, int mode);
 int vt_sifnet_get_precision(const vt_sifnet *h);
 
-/* Kernel selection for vt_query_human_loss when the maps carry the hoisted projection: 256 (default: the two-workgroups-per-CU kernel all
- * query entry points use), 512 (one 512-thread workgroup per CU and 64-point tile, thin waves, three chunks of taps in flight -- measured slower, kept for
- * A/B measurements and as an independent cross-check) or 128 (one 512-thread workgroup per TWO tiles = 128 points: in the two layer-1 loops waves 0-3 only
- * issue MFMAs for both tiles -- layer-1 weights once per 128 points -- and waves 4-7 only gather / blend / contract; csrc/query_pc.h).  Same arithmetic,
- * results agree to the round-off of the gradient's summation order.  Process-wide. */
+/* Kernel selection for vt_query_human_loss when the maps carry the hoisted projection.  The product library holds ONE kernel (256: the two-workgroups-per-CU
+ * kernel all query entry points use) and refuses anything else with VT_ERR_ARG.  The experiments build (csrc/experiments, `make experiments`, never shipped)
+ * additionally accepts 512 (one 512-thread workgroup per 64-point tile, thin waves) and 128 (producer / consumer waves, 128 points per workgroup): measured
+ * 52 % / 22 % slower, kept for A/B measurements and as independently written cross-checks of the same arithmetic.  Process-wide. */
 int vt_query_set_human_kernel(int threads);
 
 /* One projection step of the SIF-Net surface-point generator, fused.  Replaces one iteration of

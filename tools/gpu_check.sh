@@ -1,13 +1,21 @@
 #!/bin/bash
-# Standard GPU-box run (through gpurun): the -m gpu suite, the default bench line, a single-stream kernel trace of the bench command.
+# Standard GPU-box run (through gpurun): the -m gpu suite, the bench line of the DRIVER'S EXACT COMMAND (python bench.py --gpus 1 --steps 20 --warmup 5: the command
+# BENCH_rNN.json records; VERDICT r04: it had never been run by the builder and its demo_pipeline leg OOM'd), a single-stream kernel trace of the bench command.
 # usage: tools/gpu_check.sh [tag]   -> gpurun_out/<tag>_{pytest.log,bench.json,kernel_stats_1stream.csv,...}
 tag=${1:-run}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 3000 python -m pytest tests -m gpu -q --durations=15 ) > gpurun_out/${tag}_pytest.log 2>&1; python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/${tag}_pytest.log 2>&1
 tail -30 gpurun_out/${tag}_pytest.log
-( time timeout 900 python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-tail -c 3000 gpurun_out/${tag}_bench.json; tail -5 gpurun_out/${tag}_bench.err
+( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/${tag}_bench_driver_cmd.json 2> gpurun_out/${tag}_bench.err
+tail -c 3000 gpurun_out/${tag}_bench_driver_cmd.json; tail -5 gpurun_out/${tag}_bench.err
+grep -h '^{' gpurun_out/${tag}_bench_driver_cmd.json | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); r = d['roofline']
+    print('HEADLINE', round(d['value'], 2), 'frames/s', round(d['ms_per_step'], 1), 'ms/batch; solo', round(r['solo_launch_ms'], 4), 'ms frac', round(r['frac_single_stream'], 4), 'in situ frac', round(r['frac'], 4),
+          '; legs:', {k: ('ERROR ' + str(d[k]['error'])[:80] if isinstance(d.get(k), dict) and 'error' in d[k] else 'ok') for k in ('full_schedule', 'smplt_prefit', 'strict_fp32', 'sifnet_inference', 'demo_pipeline', 'cpu_baseline')})
+"
 d=$(mktemp -d /tmp/prof.XXXX)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o r -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 2 --warmup 1 --no-extras --no-cpu-baseline ) > gpurun_out/${tag}_prof.log 2>&1
 f=$(find $d -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_1stream.csv && head -12 $f

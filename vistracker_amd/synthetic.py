@@ -410,3 +410,45 @@ def bowl_decoders(center_o, center_h, seed: int = 3, field_gain: float = 0.05, c
     dec["df"] = [(w1.astype(np.float32), b1.astype(np.float32)), (w2.astype(np.float32), b2.astype(np.float32)),
                  (w3.astype(np.float32), b3.astype(np.float32)), (w4.astype(np.float32), b4.astype(np.float32))]
     return dec
+
+
+def body_bowl_decoders(center_h, labels=None, v_template=None, seed: int = 3, field_gain: float = 0.05, curv_h: float = 0.06, logit_gain: float = 4.0) -> dict:
+    """The SMPL-stage counterpart of ``bowl_decoders`` ("full-schedule runs on a well-conditioned analytic-field fixture"): both heads the
+    objective of ``optimize_smpl`` reads (recon_fit_behave.py:467-497) become smooth, well-conditioned functions of the query point, expressed through real
+    decoder evaluations (all four layers, ReLUs, every gather still live at ``field_gain`` of the random map-feature path):
+
+        df[:, 0](p)  = curv_h * sum_k phi(n_k . (p - center_h))            the convex piecewise-linear bowl of ``bowl_decoders`` (below the 0.1 clamp within
+                                                                           1 m of the centre for curv_h = 0.06: the clamp's active set does not flip)
+        parts_c(p)   = logit_gain * a_c . (p - center_h)                   a LINEAR classifier: the coordinates pass layers 1-3 as +- pairs of identity
+                                                                           hinges (relu(s) - relu(-s) = s), a_c = unit direction of the template centroid of
+                                                                           part c (``labels`` / ``v_template``; a fixed fan of directions without them)
+
+    The cross-entropy of linear logits is convex in p and the bowl is convex: with the keypoint term and the priors the stage has ONE basin, so two correct
+    implementations end within rounding of each other and a wrong sign or a missing term moves the result by centimetres -- the discriminating fixture
+    the random-weight field (on which any two runs end 3e-4 m apart) is not."""
+    dec = bowl_decoders(center_h, center_h, seed=seed, field_gain=field_gain, curv_h=curv_h)
+    cen = np.asarray(center_h, np.float64); z0 = np.array([0, 0, 2.2])
+    k = HEAD_DIMS[2]
+    if labels is not None and v_template is not None:
+        vt = np.asarray(v_template, np.float64); vt = vt - vt.mean(0)
+        lab = np.asarray(labels).reshape(-1)
+        dirs = np.stack([vt[lab == c].mean(0) if np.any(lab == c) else np.array([0.0, 0.0, 1.0]) for c in range(k)])
+        dirs /= np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-3)
+    else:
+        ang = np.arange(k) * (2 * np.pi / k)
+        dirs = np.stack([np.cos(ang), np.sin(ang), 0.5 * np.cos(2 * ang)], 1); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    (w1, b1), (w2, b2), (w3, b3), (w4, b4) = [(w.copy(), b.copy()) for w, b in dec["parts"]]
+    n_an = 6
+    w1[:HIDDEN - 32] = 0; b1[:HIDDEN - 32] = 0; w2[:HIDDEN - 32] = 0; w2[:, :HIDDEN - 32] = 0; b2[:HIDDEN - 32] = 0
+    w3[:HIDDEN - 32] = 0; w3[:, :HIDDEN - 32] = 0; b3[:HIDDEN - 32] = 0; w4[:, :HIDDEN - 32] = 0
+    w1[HIDDEN - 32:, 256:259] = 0                    # the random block sees map features only
+    w4 *= field_gain; b4[:] = 0
+    for c in range(3):
+        for i, sgn in enumerate((1.0, -1.0)):
+            u = 2 * c + i
+            w1[u, 256 + c] = sgn; b1[u] = -sgn * float(cen[c] - z0[c])
+            w2[u, u] = 1.0; w3[u, u] = 1.0
+            w4[:, u] = sgn * logit_gain * dirs[:, c]
+    dec["parts"] = [(w1.astype(np.float32), b1.astype(np.float32)), (w2.astype(np.float32), b2.astype(np.float32)),
+                    (w3.astype(np.float32), b3.astype(np.float32)), (w4.astype(np.float32), b4.astype(np.float32))]
+    return dec
