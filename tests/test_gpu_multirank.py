@@ -126,3 +126,58 @@ def test_rccl_path_with_a_group_of_one(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29562", str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """The driver's 8-GPU command -- ``torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --steps 20`` -- as a DRY RUN with eight ranks on the one GPU of the
+    test box (gloo collectives on host copies; feature maps at 1/8 resolution so that eight processes fit): the static shards of the 1500-frame sequence's batch
+    list (20 batches cyclically: "first 20 % 8 ranks one more" -> 3, 3, 3, 3, 2, 2, 2, 2; the 60-frame tail batch is job 15), the final all_gather, the
+    MAX-reduced time, and the second timed pass with the run-time hand-out -- every job fitted exactly once -- return rows BIT-IDENTICAL to one rank's
+    (recon_fit_base.py:411-419: a batch is an independent unit, who fits it cannot matter)."""
+    import numpy as np
+    base = [os.path.join(ROOT, "bench.py"), "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1", "--steps", "20", "--res-scale", "0.125"]
+    lines = {}
+    for tag, n, port in (("one", 1, 29581), ("eight", 8, 29582)):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"), OMP_NUM_THREADS="4")
+        if n > 1:
+            env["VT_BENCH_TEST_SHARED_GPU"] = "1"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--gpus", str(n)]
+        else:
+            cmd = [sys.executable] + base + ["--gpus", "1"]
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+        ls = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and len(ls) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+        lines[tag] = json.loads(ls[0])
+    e = lines["eight"]; c = e["config"]
+    assert e["n_gpus"] == 8 and e["steps"] == 20 and e["scaling"] == "strong" and c["handout"] == "static"
+    assert c["rank_jobs"] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11], [12, 13], [14, 15], [16, 17], [18, 19]], c["rank_jobs"]
+    assert c["frames_timed"] == 15 * 96 + 60 + 4 * 96 and len(c["rank_seconds"]) == 8
+    assert abs(e["value"] * e["ms_per_step"] * 1e-3 * 20 - c["frames_timed"]) < 1e-6 * c["frames_timed"]
+    one, eight = np.load(tmp_path / "one.npy"), np.load(tmp_path / "eight.npy")
+    assert one.shape == (c["frames_timed"], 182) and np.array_equal(one, eight)
+    d = e["dynamic_handout"]
+    assert sorted(sum(d["rank_jobs"], [])) == list(range(20)) and d["rows_bit_identical_to_static"] and d["value"] > 0
+    assert np.array_equal(one, np.load(str(tmp_path / "eight.npy") + ".dynamic.npy"))
+    print(f"8 ranks on one GPU: static {e['value']:.1f} frames/s rank seconds {c['rank_seconds']}; dynamic {d['value']:.1f} frames/s rank jobs {d['rank_jobs']}")
+
+
+def test_pipeline_eight_ranks_equal_one_rank(tmp_path):
+    """scripts/demo.sh steps 1-6 with EIGHT ranks on the one GPU (stage 6 with the stealing hand-out, rows through reduce_rows_exact): the packed joint-fit result
+    is the single-rank run's, bit for bit; ranks whose static share is empty or a tail steal from the others."""
+    import numpy as np, re
+    script = os.path.join(ROOT, "tests", "pipeline_ranks_script.py")
+    outs = []
+    for n, port in ((1, 29591), (8, 29592)):
+        f = tmp_path / f"r{n}.npz"
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"), OMP_NUM_THREADS="4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               script, str(f), "250"]
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=2400, cwd=ROOT)
+        assert out.returncode == 0 and "PIPELINE_OK" in out.stdout and out.stdout.count("RANK_OK") == n, out.stdout[-2000:] + out.stderr[-4000:]
+        outs.append(dict(np.load(f)))
+    a, b = outs
+    stolen = [int(x) for x in re.findall(r"STOLEN (\d+)", out.stdout)]
+    assert len(stolen) == 8, out.stdout[-1500:]
+    for k in ("smplt1_poses", "smplt1_trans", "smplt_poses", "smplt_trans", "neural_pca", "neural_vis", "poses", "betas", "trans", "obj_angles", "obj_trans"):
+        assert np.array_equal(a[k], b[k]), (k, float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max()))
+    print("8-rank pipeline: batches stolen per rank", stolen)

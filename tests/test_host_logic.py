@@ -366,3 +366,79 @@ def test_sliding_windows_as_one_view_and_lazy_clip_paths():
         listed = [frames[i:i + W] for i in starts]
         assert paths[0] == listed[0] and paths[-1] == listed[-1] and paths[len(starts) // 2] == listed[len(starts) // 2]
         assert S.SMPLTSmoother.merge_paths(paths) == S.SMPLTSmoother.merge_paths(listed)
+
+
+def test_sharding_world8_gloo(tmp_path):
+    """EIGHT CPU processes (gloo) -- the world size of the node the path is built for (BASELINE configs[2]: 1500 frames over 8 GPUs; recon_fit_base.py:411-419):
+    the static shards of the 1500-frame sequence (16 batches: every rank two, the 60-frame tail on rank 7; in 192-frame units: 8 units, one per rank), the
+    gather of the fitted rows in frame order, the run-time hand-out (WorkQueue: every batch exactly once, longest first), the per-rank lists with stealing
+    (StealQueue: own items front to back, then from the back of the busiest list) with the bit-exact row reduction, and the agreement flag
+    (all_ranks_agree: one dissenting rank flips it for everybody)."""
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time, threading, torch, torch.distributed as dist
+        sys.path.insert(0, {ROOT!r})
+        from vistracker_amd import sharding as S
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        assert w == 8
+        T, bs = 1500, 96
+        # ---- static shards + gather
+        mine = S.shard_batches(T, bs, w, r)
+        assert len(mine) == 2 and (r < 7 or mine[-1] == (1440, 1500))
+        unit = S.shard_units(T, 64, 96, w, r)
+        assert len(unit) == 1 and unit[0] == (192 * r, min(192 * (r + 1), T))
+        rows = torch.cat([torch.arange(s, e, dtype=torch.float32)[:, None].repeat(1, 182) for s, e in mine])
+        allp = S.gather_params(rows, T, bs)
+        assert allp.shape == (T, 182) and torch.equal(allp[:, 5], torch.arange(T, dtype=torch.float32))
+        urows = torch.cat([torch.arange(s, e, dtype=torch.float32)[:, None].repeat(1, 16) for s, e in unit])
+        assert torch.equal(S.gather_params(urows, T, 192)[:, 0], torch.arange(T, dtype=torch.float32))
+        # ---- agreement before a collective pattern is chosen
+        assert S.all_ranks_agree(True) is True and S.all_ranks_agree(r != 3) is False
+        # ---- run-time hand-out of the 16 batches, two pulling threads per rank, rank 0 three times slower
+        allb = S.batches_of(T, bs)
+        order = sorted(range(len(allb)), key=lambda j: -(allb[j][1] - allb[j][0]))
+        q = S.WorkQueue(len(allb), order)
+        assert q.shared
+        got = []; lock = threading.Lock()
+        def worker():
+            while True:
+                i = q.next()
+                if i is None: break
+                with lock: got.append(i)
+                time.sleep(0.06 if r == 0 else 0.02)
+        th = [threading.Thread(target=worker) for _ in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        every = [None] * w; dist.all_gather_object(every, got)
+        assert sorted(sum(every, [])) == list(range(16)), every
+        # ---- per-rank lists with stealing: rank r owns r + 1 items (36 in all), rank 7 is slow
+        counts = [k + 1 for k in range(w)]; base = [sum(counts[:k]) for k in range(w)]
+        sq = S.StealQueue(counts, r)
+        assert sq.shared
+        took = []
+        def sworker():
+            while True:
+                j = sq.next()
+                if j is None: break
+                with lock: took.append(j)
+                time.sleep(0.08 if r == 7 else 0.01)
+        th = [threading.Thread(target=sworker) for _ in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        n = sum(counts)
+        table = torch.zeros(n, 3); filled = torch.zeros(n, dtype=torch.bool)
+        for o, i in took:
+            table[base[o] + i] = torch.tensor([-0.0, float(base[o] + i + 1), float(r)]); filled[base[o] + i] = True
+        full = S.reduce_rows_exact(table, filled)
+        assert bool((full[:, 1] == torch.arange(1, n + 1).float()).all()) and bool(torch.signbit(full[:, 0]).all())
+        alltook = [None] * w; dist.all_gather_object(alltook, took)
+        if r == 0:
+            assert sorted(sum(alltook, [])) == [(o, i) for o in range(w) for i in range(counts[o])]
+            own7 = sorted(i for o, i in alltook[7] if o == 7)
+            assert own7 == list(range(len(own7))) and len(own7) < 8          # the slow rank kept a prefix of its own list; the rest was stolen from the back
+            print("WORLD8_OK", [len(x) for x in every], [len(x) for x in alltook])
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29538", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert "WORLD8_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -20,6 +20,9 @@ verts, _, _ = ops.smplh_forward(ops.SmplhHandle(model), t(sp["pose"]), t(sp["bet
 pts = verts.detach().contiguous(); bc = t(sp["trans"]); cc = torch.tensor([[1018.952, 779.486]] * B, device=dev)
 labels = torch.as_tensor(syn.part_labels(model).astype(np.int32), device=dev)
 v0 = pts[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], v0[:, 1] / v0[:, 2]], 1))
+import os
+if os.environ.get('QAB_RANDOM_ORDER'):      # tiles of unrelated points: many distinct texels per tile (the overflow path of the row de-duplication)
+    order = torch.randperm(N, device=dev, generator=g).to(torch.int32)
 variants = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else '256,512,128').split(',')]
 res = {}
 for thr in variants:

@@ -360,21 +360,15 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
 // v_med3_f32); asm only ever sees their results.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, h2)); }      // v_cvt_pk_f16_f32 (RTN)
-#ifndef RELU_MAX_ASM
-#define RELU_MAX_ASM 1
-#endif
 // ReLU + split of two pre-activations whose RAW fp16 conversion `hr` is already known: hi = max(hr, 0) (packed, = fp16(max(x, 0)): the conversion is
 // monotone), lo = fp16(y - hi) with y = max(x, 0).  8 VALU instructions per pair with the range tracker (y >= 0: no |.|).
 __device__ __forceinline__ void relu_split2(float x0, float x1, unsigned hr, unsigned &hi, unsigned &lo, float &rmax)
 {
     // max(x, 0) as med3(x, 0, +inf): one instruction (fmaxf is canonicalised first: two per value)
-    float y0, y1;
-#if RELU_MAX_ASM
-    // (hipcc turns med3(x, 0, +inf) into canonicalise + max: two instructions per value; x0 / x1 were read by the caller's conversion already: HAZARD RULE)
-    asm("v_max_f32 %0, 0, %1" : "=v"(y0) : "v"(x0)); asm("v_max_f32 %0, 0, %1" : "=v"(y1) : "v"(x1));
-#else
-    y0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff()); y1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
-#endif
+    // max(x, 0) as a SIGNED-INTEGER max of the bit pattern (negative floats -- incl. -0 -- are negative integers; the order of the non-negative ones is the
+    // integers'): one v_max_i32 per value.  hipcc turns fmaxf / med3(x, 0, +inf) into canonicalise + max (two instructions), and an inline-asm v_max_f32 may be
+    // scheduled AHEAD of the builtin that is meant to read the accumulator first (HAZARD RULE below: garbage -- measured, round 5)
+    const float y0 = __int_as_float(max(__float_as_int(x0), 0)), y1 = __int_as_float(max(__float_as_int(x1), 0));
     float r0, r1;
     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(rmax) : "v"(y0), "v"(y1));
     asm("v_pk_max_f16 %0, %1, 0" : "=v"(hi) : "v"(hr));
