@@ -464,14 +464,60 @@ __device__ __forceinline__ void wprefetch(WPre &p, const uint4 *__restrict__ Wp,
 #pragma unroll
             for (int hl = 0; hl < 2; hl++) p.v[s][nt][hl] = Wp[(unsigned)(wave * 256 + lane) + (unsigned)(s * 1024 + (nt * 2 + hl) * 64)];
 }
-__device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
+// B fragments of one K32 step for HALF the points of the wave tile (p = 2 half + {0, 1}): 16 registers.  The GEMMs below run a K32 step as two half steps
+// and request the fragments of the next K32 step's half as soon as the MFMAs of this step's half have been issued (same registers): the LDS round trip -- ~400
+// clocks when the four waves of a workgroup leave a barrier together and all ask for 8 x 1 KB -- runs under the other half's 12 MFMAs instead of in front of all 24.
+// Per accumulator the products still arrive as hi.hi, hi.lo, lo.hi of step 0, 1, 2, 3: the bits of k32_step.
+struct BHalf { h8 xh[2], xl[2]; };
+__device__ __forceinline__ void bhalf_load(BHalf &b, const uint4 *Xhi, const uint4 *Xlo, int kb_base, int half, int lane)
+{
+    const int q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) { b.xh[pp] = as_h8(Xhi[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); b.xl[pp] = as_h8(Xlo[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); }
+}
+__device__ __forceinline__ void mfma12(Acc8 &c, const uint4 (&w)[2][2], const BHalf &b, int half)
 {
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xh[pp], c.v[nt][2 * half + pp]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xl[pp], c.v[nt][2 * half + pp]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][1]), b.xh[pp], c.v[nt][2 * half + pp]);
+}
+// scheduling fence that pins matrix instructions and LDS reads to their side, everything else (VALU, SALU, vector memory, LDS writes) may cross
+#define SB_PIN_MFMA_DSREAD() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x200 | 0x400)
+#ifndef GEMM_HALFSTEP
+#define GEMM_HALFSTEP 1
+#endif
+__device__ __forceinline__ void gemm128(Acc8 &c, const uint4 *Xhi, const uint4 *Xlo, const WPre &p, int lane)
+{
+#if GEMM_HALFSTEP
+    BHalf bA, bB;
+    bhalf_load(bA, Xhi, Xlo, 0, 0, lane); bhalf_load(bB, Xhi, Xlo, 0, 1, lane);
+#endif
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
         for (int pp = 0; pp < 4; pp++) c.v[nt][pp] = (f32x4){p.bias[nt].x, p.bias[nt].y, p.bias[nt].z, p.bias[nt].w};
+#if GEMM_HALFSTEP
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        SB_PIN_MFMA_DSREAD(); mfma12(c, p.v[s], bA, 0); SB_PIN_MFMA_DSREAD();
+        if (s < 3) bhalf_load(bA, Xhi, Xlo, 4 * (s + 1), 0, lane);
+        SB_PIN_MFMA_DSREAD(); mfma12(c, p.v[s], bB, 1); SB_PIN_MFMA_DSREAD();
+        if (s < 3) bhalf_load(bB, Xhi, Xlo, 4 * (s + 1), 1, lane);
+    }
+    SB_PIN_MFMA_DSREAD();
+#else
 #pragma unroll
     for (int s = 0; s < 4; s++) k32_step(c, p.v[s], Xhi, Xlo, 4 * s, lane);
+#endif
 }
 
 // ---- two-head pipeline of the hidden layers (query_kernel<2, MODE_HUMAN>, HPIPE): a wave alone on its SIMD spends the hidden phase as GEMM (96 MFMAs, matrix
@@ -535,34 +581,6 @@ __device__ __forceinline__ void bias_load(float4 (&b)[2], const float *__restric
     for (int nt = 0; nt < 2; nt++)
         b[nt] = HAS ? *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * nt + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// B fragments of one K32 step for HALF the points of the wave tile (p = 2 half + {0, 1}): 16 registers.  The GEMMs below run a K32 step as two half steps
-// and request the fragments of the next K32 step's half as soon as the MFMAs of this step's half have been issued (same registers): the LDS round trip -- ~400
-// clocks when the four waves of a workgroup leave a barrier together and all ask for 8 x 1 KB -- runs under the other half's 12 MFMAs instead of in front of all 24.
-// Per accumulator the products still arrive as hi.hi, hi.lo, lo.hi of step 0, 1, 2, 3: the bits of k32_step.
-struct BHalf { h8 xh[2], xl[2]; };
-__device__ __forceinline__ void bhalf_load(BHalf &b, const uint4 *Xhi, const uint4 *Xlo, int kb_base, int half, int lane)
-{
-    const int q = lane >> 4, j = lane & 15;
-#pragma unroll
-    for (int pp = 0; pp < 2; pp++) { b.xh[pp] = as_h8(Xhi[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); b.xl[pp] = as_h8(Xlo[(kb_base + q) * 64 + 16 * (2 * half + pp) + j]); }
-}
-__device__ __forceinline__ void mfma12(Acc8 &c, const uint4 (&w)[2][2], const BHalf &b, int half)
-{
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xh[pp], c.v[nt][2 * half + pp]);
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][0]), b.xl[pp], c.v[nt][2 * half + pp]);
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-        for (int pp = 0; pp < 2; pp++) c.v[nt][2 * half + pp] = MFMAH(as_h8(w[nt][1]), b.xh[pp], c.v[nt][2 * half + pp]);
-}
-// scheduling fence that pins matrix instructions and LDS reads to their side, everything else (VALU, SALU, vector memory, LDS writes) may cross
-#define SB_PIN_MFMA_DSREAD() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x20 | 0x40 | 0x200 | 0x400)
 // cg = M x X (gemm128) with the epilogue of `ce` (another head's finished accumulators) issued between its MFMAs: one fragment per half step.  `nextW` (may be
 // NULL): T-pack of the GEMM that follows in this wave's stream, `nextBias` its bias (NULL: zeros).  EPI = 0: no epilogue
 template <int EPI, int F>
