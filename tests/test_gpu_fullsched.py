@@ -189,8 +189,9 @@ def smpl_stage_case(synth, B, res_scale, seed=11, full_res_on_device=False):
     return dict(seq=seq, cc=cc, kp=kp, pose0=pose0.astype(np.float32), betas0=betas0.astype(np.float32), trans0=trans0, bc=trans0.copy(), dec=dec, m=m, b25=b25)
 
 
-def run_smpl_stage_three_ways(synth, c, fm, mp):
-    """HIP (+ the same HIP path started 1e-6 m away), oracle32, oracle64 through the full optimize_smpl schedule; returns the measured distances"""
+def run_smpl_stage_three_ways(synth, c, fm, mp, with_oracle64=True):
+    """HIP (+ the same HIP path started 1e-6 m away), oracle32, oracle64 through the full optimize_smpl schedule; returns the measured distances
+    (``with_oracle64=False``: the fp64 arbiter -- three times the fp32 oracle's time -- is left to the bench-size test; its columns repeat the fp32 oracle's)"""
     from oracle import oracle as O, oracle64 as O64
     from vistracker_amd import ops
     from vistracker_amd.fitting import FitContext
@@ -202,10 +203,13 @@ def run_smpl_stage_three_ways(synth, c, fm, mp):
         r = ctx.optimize_smpl(fm, p, b_, t, cu(c["cc"]), cu(c["bc"]), cu(c["kp"]))
         out[tag] = (r, ops.smplh_forward(ctx.smpl, p, b_, t)[0].cpu().numpy())
     m64 = O64.SmplModel(model)
-    (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(
-        lambda: oracle_optimize_smpl(c["m"], c["b25"], pri, O.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"]),
-        lambda: oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"], O=O64))
-    v32 = c["m"].forward(pose, betas, trans)[0]; v64 = m64.forward(p64, b64, t64)[0]
+    run32 = lambda: oracle_optimize_smpl(c["m"], c["b25"], pri, O.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"])
+    if with_oracle64:
+        (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(run32,
+            lambda: oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"], O=O64))
+    else:
+        pose, betas, trans, losses, stopped = run32(); p64, b64, t64, l64 = pose, betas, trans, losses
+    v32 = c["m"].forward(pose, betas, trans)[0]; v64 = m64.forward(p64, b64, t64)[0] if with_oracle64 else v32
     res, vh = out["hip"]
     v_start = c["m"].forward(c["pose0"], c["betas0"], c["trans0"])[0]
     n = min(res.steps, len(losses))
@@ -238,7 +242,7 @@ def test_full_schedule_smpl_stage_body_bowl_strict(synth):
     B = 4
     c = smpl_stage_case(synth, B, 1 / 8)
     mp = syn.feature_maps(B, 41, res_scale=1 / 8, smooth=4)
-    rep = run_smpl_stage_three_ways(synth, c, ops.FeatureMaps.from_nchw(mp), mp)
+    rep = run_smpl_stage_three_ways(synth, c, ops.FeatureMaps.from_nchw(mp), mp, with_oracle64=False)      # (the fp64 arbiter: test_full_schedule_at_bench_size)
     _report("smpl_stage_body_bowl", **rep)
     print("SMPL stage, body-bowl fixture:", rep)
     assert_strict_smpl_stage(rep)

@@ -14,6 +14,8 @@ for name, c, res, _ in syn.MAP_SPECS:
     lo = torch.randn(B, c, res // 8, res // 8, device=dev, generator=g)
     maps[name] = F.interpolate(lo, size=(res, res), mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
 fm = ops.FeatureMaps(maps)
+if os.environ.get('QFP32'):       # the strict-fp32 route (query_f32.hip) serves the same calls
+    fm.set_force_fp32(True)
 net = ops.SifNetHandle(syn.sifnet_decoders(3))
 if mode == "object" and "QN" not in os.environ:
     N = 3000
