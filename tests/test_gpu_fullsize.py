@@ -171,13 +171,10 @@ def test_full_schedule_at_bench_size(synth):
     B = 4
     fm = _device_maps(B, 5)
     mp = _host_maps(fm, list(range(B)))
-    # ---- SMPL stage
     c = FS.smpl_stage_case(synth, B, 1.0)
-    rep = FS.run_smpl_stage_three_ways(synth, c, fm, mp)
-    FS._report("bench_size_smpl_stage_body_bowl", **rep)
-    print("bench-size SMPL stage:", rep)
-    FS.assert_strict_smpl_stage(rep)
-    # ---- object stage ('object only' + 'joint' to the stop rule, contacts + Chamfer live) on the analytic bowl
+    # ---- the object stage's two CPU oracles start NOW, in the background (ctypes releases the GIL; they share the host cores with the SMPL stage's oracles): they need
+    #      nothing from the SMPL stage (the contact term reads the ground-truth body)
+    from concurrent.futures import ThreadPoolExecutor
     model, regs, pri, labels = (synth[k] for k in ("model", "regs", "priors", "labels"))
     seq = c["seq"]; rng = np.random.default_rng(4)
     ov, of = syn.object_template(); opts = syn.sample_surface(ov, of, 3000, seed=6)
@@ -189,6 +186,14 @@ def test_full_schedule_at_bench_size(synth):
     occ = seq["occ_ratios"].astype(np.float32); sc = np.ones(B, np.float32)
     kw = dict(iter_for_obj=15, iter_for_sil=0, joint_iter=10, max_iter=100)
     noise = np.random.default_rng(23).uniform(0, 1, (1250, B, 3, 3)).astype(np.float32)
+    run_o = lambda Om: oracle_optimize_object(Om.SifNet(decb, mp), pts, R0, t0_, sc, noise, c["cc"], c["bc"], occ, sverts, labels, sil=None, O=Om, **kw)
+    pool = ThreadPoolExecutor(2); fut32, fut64 = pool.submit(run_o, O), pool.submit(run_o, O64)
+    # ---- SMPL stage
+    rep = FS.run_smpl_stage_three_ways(synth, c, fm, mp)
+    FS._report("bench_size_smpl_stage_body_bowl", **rep)
+    print("bench-size SMPL stage:", rep)
+    FS.assert_strict_smpl_stage(rep)
+    # ---- object stage ('object only' + 'joint' to the stop rule, contacts + Chamfer live) on the analytic bowl
     cu = FS.cu
     fm.drop_projection()
     outs = {}
@@ -196,8 +201,7 @@ def test_full_schedule_at_bench_size(synth):
         R, t, s = cu(R0.copy()), cu(t0_ + np.float32(dt)), torch.ones(B, device="cuda")
         r = ctxb.optimize_smpl_object(fm, cu(sverts), R, t, s, cu(c["cc"]), cu(c["bc"]), cu(occ), noise=cu(noise), **kw)
         outs[tag] = (O.rigid(pts, O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc), r, O.rigid(ov.astype(np.float32), O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc))
-    run_o = lambda Om: oracle_optimize_object(Om.SifNet(decb, mp), pts, R0, t0_, sc, noise, c["cc"], c["bc"], occ, sverts, labels, sil=None, O=Om, **kw)
-    (Ro, to, ls, st, hc), (R64, t64, l64, _, _) = FS.both(lambda: run_o(O), lambda: run_o(O64))
+    (Ro, to, ls, st, hc), (R64, t64, l64, _, _) = fut32.result(), fut64.result(); pool.shutdown()
     X32 = O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc); X64 = O.rigid(pts, O.so3_project(R64.astype(np.float32)), t64.astype(np.float32), sc)
     M32 = O.rigid(ov.astype(np.float32), O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc)
     Xh, rh, Mh = outs["hip"]
