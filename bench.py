@@ -345,7 +345,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--res-scale", type=float, default=1.0, help="feature map resolution scale (1.0 = reference sizes)")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight per GPU (one host thread + one HIP stream each)")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (one host thread + one HIP stream each).  Round 5, the driver's command on two leases: "
+                                                           "2 streams 142.6-143.9 frames/s, 3 streams 145.3-147.1, 4 streams 142.4 (profiles/r05_streams_ab.txt)")
     ap.add_argument("--stagger", type=float, default=None,
                     help="seconds by which stream k of a rank starts after stream k - 1 (inside the timed region; 0 = together).  Default: a fifth of the "
                          "warm-up batch's time (0.15 s without warm-up) -- see the comment where it is applied")
@@ -363,7 +364,7 @@ def main():
                          "(vistracker_amd.sharding.WorkQueue); auto (default) = the static shards are the headline -- the reference's contract, what a real driver "
                          "runs: every rank holds only its own batches -- and, for N > 1, a second timed pass with the run-time hand-out is reported beside it "
                          "(`dynamic_handout` in the line) when all K batches fit every rank's HBM")
-    ap.add_argument("--fp32-batches", type=int, default=4, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
+    ap.add_argument("--fp32-batches", type=int, default=6, help="batches of the strict_fp32 leg (the first K of the sequence; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -660,25 +661,26 @@ def main():
             d = run(0); torch.cuda.synchronize(); t1 = time.perf_counter()          # the headline's batches (first three of the sequence), fresh copies
             r1, r2 = fit_batch(ctx, torch, d, early_stop=False); torch.cuda.synchronize(); dt = time.perf_counter() - t1
             one = {"workload": "the first batch alone on the chip", "seconds": dt, "frames_per_s": BATCH / dt, "frame_steps_per_s": BATCH * (r1.steps + r2.steps) / dt}
-            # the same with two batches in flight, like the headline
+            # the same with as many batches in flight as the headline has
             import threading
             del d
-            ds = [run(1 + k_) for k_ in range(2)]; torch.cuda.synchronize()
-            ss = concurrent_streams(2, dev)
+            nfl = max(2, args.streams)
+            ds = [run(1 + k_) for k_ in range(nfl)]; torch.cuda.synchronize()
+            ss = concurrent_streams(nfl, dev)
 
             def w2(k):
                 torch.cuda.set_device(dev)
                 with torch.cuda.stream(ss[k]):
                     fit_batch(ctx, torch, ds[k], early_stop=False)
             t1 = time.perf_counter()
-            th2 = [threading.Thread(target=w2, args=(k,)) for k in range(2)]
+            th2 = [threading.Thread(target=w2, args=(k,)) for k in range(nfl)]
             for t_ in th2: t_.start()
             for t_ in th2: t_.join()
             torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
-            return {"workload": "batches 2 and 3 of the sequence (96 frames each) with the stop rules disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 "
-                                "object-stage Adam steps, of which 1100 in phase 'joint' with the contact Chamfer term), two batches in flight like the headline",
-                    "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds_per_batch": dt2 / 2, "frames_per_s": 2 * BATCH / dt2,
-                    "frame_steps_per_s": 2 * BATCH * (r1.steps + r2.steps) / dt2, "one_in_flight": one}
+            return {"workload": f"batches 2 .. {1 + nfl} of the sequence (96 frames each) with the stop rules disabled: the reference's maximum schedule (1030 SMPL-stage + 1550 "
+                                f"object-stage Adam steps, of which 1100 in phase 'joint' with the contact Chamfer term), {nfl} batches in flight like the headline",
+                    "adam_steps_smpl_stage": r1.steps, "adam_steps_object_stage": r2.steps, "seconds_per_batch": dt2 / nfl, "frames_per_s": nfl * BATCH / dt2,
+                    "frame_steps_per_s": nfl * BATCH * (r1.steps + r2.steps) / dt2, "one_in_flight": one, "batches_in_flight": nfl}
         leg("full_schedule", full_schedule)
         del full96; batches.clear()
         torch.cuda.empty_cache()

@@ -10,7 +10,7 @@
 //                          fewer than two kept points -- float32 arithmetic in torch's order (u * float(cnt) truncated; scalar * normal; add)
 #include "common.h"
 
-// grid = B, block = 256.  order (B, S) int32: only the first cnt[b] entries are written.
+// grid = B, block = 256.  order (B, S) int32: only the first cnt[b] entries are written; kept_pre (B, S, 3): ALL rows (kept first, then the rest in sample order).
 __global__ __launch_bounds__(256) void gen_round_compact_kernel(const float *__restrict__ surface, const float *__restrict__ df_target, const float *__restrict__ pre,
                                                                 const unsigned char *__restrict__ active, int S, float filter_val, float zmin,
                                                                 const long long *__restrict__ fill, int cap, int write, float *__restrict__ buf_points,
@@ -53,10 +53,39 @@ __global__ __launch_bounds__(256) void gen_round_compact_kernel(const float *__r
         if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
+    const int total = base;                 // (every thread read `base` after the last barrier of the loop)
     if (tid == 0) {
-        cnt[b] = base;
-        const long long f1 = write ? f0 + base : f0;
+        cnt[b] = total;
+        const long long f1 = write ? f0 + total : f0;
         fill_out[b] = f1 < cap ? f1 : cap;
+    }
+    // The kept-points head query evaluates kmax = max over the frames of cnt[b] (rounded up to 64) rows of kept_pre for EVERY frame: the rows behind a frame's own
+    // kept points must hold valid positions too -- the split-f16 decoders poison a whole 64-point tile with NaN when one of its points leaves the operand range, and
+    // uninitialised memory does (round 5: the first generator call of a process returned NaN heads for a few kept points; later calls found the allocator's old
+    // blocks with sane values in them).  They get what torch.argsort(~mask, stable=True) puts there: the NOT-kept samples in sample order.
+    if (kept_pre) {
+        __syncthreads();
+        if (tid == 0) base = 0;
+        __syncthreads();
+        for (int s0 = 0; s0 < S; s0 += 256) {
+            const int i = s0 + tid;
+            bool drop = false;
+            if (i < S) drop = !(act && (df_target[(size_t)b * S + i] < filter_val) && (surface[((size_t)b * S + i) * 3 + 2] > zmin));
+            const unsigned long long bal = __ballot(drop);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wave; w++) woff += wsum[w];
+            if (drop) {
+                const int k = total + base + woff + before;
+                const float *q = pre + ((size_t)b * S + i) * 3; float *o = kept_pre + ((size_t)b * S + k) * 3;
+                o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+            }
+            __syncthreads();
+            if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            __syncthreads();
+        }
     }
 }
 

@@ -51,7 +51,7 @@ class PipelineConfig:
     # batches of the joint fit in flight per GPU (one host thread + one HIP stream each, like bench.py): the launch-latency-bound small kernels of
     # one batch overlap with the chip-filling query kernels of the other (+10 % frames/s).  Needs resident maps and reuse_neural (no shared
     # generator state); results do not depend on it (batches are independent and every kernel of the fit is deterministic).
-    fit_streams: int = 2
+    fit_streams: int = 3          # batches in flight in stage 6 (round 5: 3 beat 2 by 2 % and 4 in the bench, profiles/r05_streams_ab.txt)
     # start offset (seconds) of stream k of the joint fit after stream k - 1: streams that start together stay in lockstep (equal batch times) and
     # their launching threads hit the host-heavy sections (object stage, set-up between the stages) at the same moments.  Nothing on a warm process,
     # 7 % in the first process of a fresh container (bench.py --stagger, profiles/r04_cold_process.txt)
