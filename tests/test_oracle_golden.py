@@ -353,3 +353,45 @@ def test_oracle64_is_the_reference_run_in_float64(synth):
             losses.append(total); opt.step([dM, dt])
         assert rel(np.array(losses), g["losses64"]) < ltol, (name, rel(np.array(losses), g["losses64"]))
         assert np.abs(t - g["fin_t64"]).max() < xtol and np.abs(O64.so3_project(R) - g["fin_R64"]).max() < 10 * xtol, (name, np.abs(t - g["fin_t64"]).max())
+
+
+def test_analytic_fixture_fields_are_what_they_claim():
+    """The well-conditioned fixtures of the full-schedule tests (synthetic.bowl_decoders / body_bowl_decoders) evaluated through the ORACLE's decoders (all four layers, real
+    gathers) against their closed forms: the distance heads are the piecewise-linear interpolants of curv * sum_k (n_k . (p - c))^2 with knots every 0.15 m (+ the 0.02 offset
+    and the random map-feature path at 5 % of its usual scale), the part head of body_bowl_decoders is LINEAR in p: parts_c(p) = gain * a_c . (p - c) -- so second differences
+    of the logits along any line vanish up to the random path, and the logit of a point's own part direction grows along it."""
+    from oracle import oracle as O
+    from vistracker_amd import synthetic as syn
+    model = syn.smplh_model(0); labels = syn.part_labels(model)
+    cen = np.array([0.1, -0.05, 2.4])
+    dec = syn.body_bowl_decoders(cen, labels, model["v_template"])
+    B = 2
+    mp = syn.feature_maps(B, 5, res_scale=0.125)
+    net = O.SifNet(dec, mp)
+    rng = np.random.default_rng(0)
+    p0 = (cen + rng.uniform(-0.5, 0.5, (B, 300, 3))).astype(np.float32)
+    step = rng.normal(size=(1, 1, 3)); step = (0.05 * step / np.linalg.norm(step)).astype(np.float32)
+    cc = np.tile([[1018.952, 779.486]], (B, 1)).astype(np.float32); bc = np.tile(cen[None], (B, 1)).astype(np.float32)
+    q = lambda p: net.query(p.astype(np.float32), cc, bc, head_mask=0b00101)
+    df0, _, pa0, _, _ = q(p0); dfp, _, pap, _, _ = q(p0 + step); dfm, _, pam, _, _ = q(p0 - step)
+    r = p0.astype(np.float64) - cen
+    # distance head: within the interpolation error of the hinges (knot spacing 0.15: <= curv * 3 * 0.15^2 / 4) + the random path
+    bowl = 0.06 * (r ** 2).sum(-1) + 0.02
+    assert np.abs(df0[:, 0] - bowl).max() < 0.06 * 3 * 0.15 ** 2 / 4 + 0.02, np.abs(df0[:, 0] - bowl).max()
+    assert df0[:, 0].max() < 0.1                                    # below the objective's clamp: its active set cannot flip
+    # part head: linear -> second differences along a line are the random path's only
+    lin = np.abs(pap + pam - 2 * pa0).max()
+    slope = np.abs(pap - pam).max()
+    assert lin < 0.05 * slope + 0.02, (lin, slope)
+    # ... with the slope logit_gain * a_c . step: reconstruct a_c from the template centroids as the fixture does
+    vt = np.asarray(model["v_template"], np.float64); vt = vt - vt.mean(0)
+    dirs = np.stack([vt[labels == c].mean(0) if np.any(labels == c) else np.array([0.0, 0.0, 1.0]) for c in range(14)]); dirs /= np.maximum(np.linalg.norm(dirs, axis=1, keepdims=True), 1e-3)
+    want = 4.0 * (dirs @ (2 * step.reshape(3).astype(np.float64)))            # (14,)
+    got = (pap - pam).astype(np.float64).mean((0, 2))
+    assert np.abs(got - want).max() < 0.03, (got, want)
+    # object bowl of bowl_decoders: anisotropic curvatures along its six directions
+    deco = syn.bowl_decoders(cen, cen)
+    dfo = O.SifNet(deco, mp).query(p0, cc, bc, head_mask=0b00001)[0]
+    dirs_o = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.6, 0.8, 0], [0, 0.6, 0.8], [0.8, 0, 0.6]], np.float64); curv = (1.0, 0.6, 1.4)
+    quad = sum(curv[k % 3] * (r @ dirs_o[k]) ** 2 for k in range(6))
+    assert dfo[:, 1].min() > 0 and np.corrcoef(dfo[:, 1].ravel(), quad.ravel())[0, 1] > 0.98
