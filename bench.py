@@ -623,7 +623,7 @@ def main():
         # (282 + 452 .. 1030 + 1550 Adam steps), a shared counter evens the ranks out at the price of every rank holding all K inputs
         order = sorted(range(args.steps), key=lambda j: -job_frames[j])
         q2 = sharding.WorkQueue(args.steps, order)
-        if q2.shared:
+        if sharding.all_ranks_agree(q2.shared):             # (every rank must take the same branch: collectives follow)
             batches.clear(); torch.cuda.empty_cache()
             batches2 = [run(i) for i in range(args.steps)]
             torch.cuda.synchronize(); dist.barrier()
