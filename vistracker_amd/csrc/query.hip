@@ -589,7 +589,7 @@ __device__ __forceinline__ void epi_opt(const Acc8 &ce, unsigned &m, uint2 *Ehi8
     if (EPI != 0) epi_frag<(EPI ? EPI : EPI_RELU), F>(ce, m, Ehi8, Elo8, wave, lane, rmax);
 }
 // (NEXTW / NEXTB are compile-time: a run-time test of the pointers would put branches -- scheduling region borders -- between the half steps)
-template <int EPI, bool NEXTW, bool NEXTB>
+template <int EPI, bool NEXTW, bool NEXTB, bool KEEPBIAS = false>      // KEEPBIAS (with !NEXTW): the same weights AND bias serve the next GEMM (query128.h: the other half of a tile)
 __device__ __forceinline__ void gemm128_epi(Acc8 &cg, const uint4 *Xhi, const uint4 *Xlo, WPre &w, const uint4 *__restrict__ nextW, const float *__restrict__ nextBias,
                                             const Acc8 &ce, unsigned &m, uint2 *Ehi8, uint2 *Elo8, int wave, int lane, float &rmax)
 {
@@ -616,7 +616,7 @@ __device__ __forceinline__ void gemm128_epi(Acc8 &cg, const uint4 *Xhi, const ui
     GEMM_EPI_STEP(0) GEMM_EPI_STEP(1) GEMM_EPI_STEP(2) GEMM_EPI_STEP(3)
 #undef GEMM_EPI_STEP
     SB_PIN_MFMA_DSREAD();
-    w.bias[0] = nb[0]; w.bias[1] = nb[1];
+    if (!KEEPBIAS) { w.bias[0] = nb[0]; w.bias[1] = nb[1]; }
 }
 // (a compile-time 1 MFMA : 2 VALU interleave of the layer-1 loops with sched_group_barrier: measured null, 2.033 vs 2.039 ms -- the ISA interleaves already and
 //  those loops wait for their gathers: profiles/r02_experiments.md)
@@ -1478,6 +1478,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 
 
 #ifdef VT_EXPERIMENTS      /* measured-negative kernel variants: experiments/ (not in the default library) */
+#include "experiments/query128.h"           // the object objective on 128-point tiles, weights once per 128 points (VT_QUERY_OBJECT_TILE=128)
 #include "experiments/query_human8.h"      // 512-thread thin waves (vt_query_set_human_kernel(512))
 #include "experiments/query_pc.h"          // producer / consumer waves, 128 points per workgroup (vt_query_set_human_kernel(128))
 #endif
@@ -1852,5 +1853,11 @@ extern "C" int vt_query_object_loss(const vt_sifnet *h, const vt_maps *maps, con
     QArgs a; int rc = fill_common(a, h, maps, pts, crop_center, body_center, B, N); if (rc) return rc;
     VT_REQUIRE(occ && dpts && terms, "vt_query_object_loss: null argument");
     a.hw[0] = head_at(h, 0, maps->act_level); a.occ = occ; a.w0 = w_obj; a.dpts = dpts; a.terms = terms;
+#ifdef VT_EXPERIMENTS
+    // 128-point tiles (experiments/query128.h: bit-identical, 5 % SLOWER at N = 3000) with VT_QUERY_OBJECT_TILE=128, when the maps carry the hoisted projection
+    static const int tile128 = []() { const char *e = getenv("VT_QUERY_OBJECT_TILE"); return e && atoi(e) == 128; }();
+    const bool usep = a.proj != nullptr && a.pw == PROJ_COLS && (long)a.res[0] * a.res[0] * PROJ_COLS < (1L << 32) && a.hw[0].pcol >= 0;
+    if (tile128 && usep) return launch_object128(a, vt_stream(stream));
+#endif
     return launch<1, MODE_OBJECT>(a, vt_stream(stream));
 }
