@@ -373,9 +373,15 @@ def main():
     from vistracker_amd.fitting import FitContext
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-        sys.exit(2)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain ``python bench.py --gpus N`` (no launcher): re-exec under torch.distributed.run, one rank per GPU on 127.0.0.1 -- the command a driver would
+        # otherwise have to spell out (a usage error here would lose the first real multi-GPU run)
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     # test hook (tests / dry runs on a 1-GPU box only): all ranks share GPU 0 and the collectives go through gloo on host copies
     shared_gpu = os.environ.get("VT_BENCH_TEST_SHARED_GPU") == "1"
     if shared_gpu:
@@ -617,24 +623,55 @@ def main():
     if use_dist:
         tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
 
+    # what the process group really is: ranks counted by an all_reduce of ones on the collectives' device (RCCL when the backend says nccl), and every
+    # rank's device name -- so a line from N GPUs cannot be mistaken for N ranks on one GPU
+    group_info = {"backend": None, "rccl_ranks": None, "rank_devices": [torch.cuda.get_device_name(dev)]}
+    if use_dist:
+        one = torch.ones(1, device=cdev); dist.all_reduce(one)
+        names = [None] * world; dist.all_gather_object(names, f"{torch.cuda.get_device_name(dev)} [cuda:{local}]")
+        be = dist.get_backend()
+        group_info = {"backend": "rccl (torch 'nccl')" if be == "nccl" else be, "rccl_ranks": int(one.item()) if be == "nccl" else None,
+                      "group_ranks": int(one.item()), "rank_devices": names}
+
     dyn_leg = None
     if strong and use_dist and world > 1 and args.handout == "auto" and fits and not os.environ.get("VT_BENCH_NO_DYNAMIC_LEG"):
         # second timed pass, reported beside the headline: the same K batches (fresh copies) handed out at run time -- early stop makes batches uneven
         # (282 + 452 .. 1030 + 1550 Adam steps), a shared counter evens the ranks out at the price of every rank holding all K inputs
-        order = sorted(range(args.steps), key=lambda j: -job_frames[j])
-        q2 = sharding.WorkQueue(args.steps, order)
-        if sharding.all_ranks_agree(q2.shared):             # (every rank must take the same branch: collectives follow)
+        order = sorted(range(args.steps), key=lambda j: -job_frames[j]); packed2 = None
+        # A failure in this informational pass must never cost the headline line: rank-local work runs under try / except, and the ranks AGREE on
+        # "nobody failed" (one MIN all_reduce on the collectives' device) before each group of collectives, so no rank waits in one the others skipped.
+        try:
+            q2 = sharding.WorkQueue(args.steps, order); q2_ok = bool(q2.shared)
+        except Exception as e_:          # noqa: BLE001
+            q2_ok = False; print(f"bench.py: dynamic_handout leg skipped on rank {rank}: {type(e_).__name__}: {e_}", file=sys.stderr)
+        if sharding.all_ranks_agree(q2_ok, cdev):             # (every rank must take the same branch: collectives follow)
             batches.clear(); torch.cuda.empty_cache()
-            batches2 = [run(i) for i in range(args.steps)]
-            torch.cuda.synchronize(); dist.barrier()
-            t2 = time.perf_counter(); done2 = {}
-            res2, fit2 = run_dynamic(batches2, q2, None, t2, done2)
-            torch.cuda.synchronize(); mine2 = time.perf_counter() - t2
-            offs = np.concatenate([[0], np.cumsum(job_frames)]).astype(int)
-            packed = torch.zeros(int(offs[-1]), 182, device=dev)
-            for i in fit2:
-                packed[offs[i]:offs[i + 1]] = rows_of(batches2[i])
-            packed = packed.to(cdev); dist.all_reduce(packed)
+            ok2 = True; batches2 = []; fit2 = []; mine2 = 0.0
+            try:
+                batches2 = [run(i) for i in range(args.steps)]
+                torch.cuda.synchronize()
+            except Exception as e_:          # noqa: BLE001
+                ok2 = False; print(f"bench.py: dynamic_handout leg failed on rank {rank}: {type(e_).__name__}: {e_}", file=sys.stderr)
+            ok2 = sharding.all_ranks_agree(ok2, cdev)
+            t2 = time.perf_counter()
+            if ok2:
+                dist.barrier()
+                t2 = time.perf_counter(); done2 = {}
+                try:
+                    res2, fit2 = run_dynamic(batches2, q2, None, t2, done2)
+                    torch.cuda.synchronize(); mine2 = time.perf_counter() - t2
+                    offs = np.concatenate([[0], np.cumsum(job_frames)]).astype(int)
+                    packed2 = torch.zeros(int(offs[-1]), 182, device=dev)
+                    for i in fit2:
+                        packed2[offs[i]:offs[i + 1]] = rows_of(batches2[i])
+                    packed2 = packed2.to(cdev)
+                except Exception as e_:          # noqa: BLE001
+                    ok2 = False; print(f"bench.py: dynamic_handout leg failed on rank {rank}: {type(e_).__name__}: {e_}", file=sys.stderr)
+                ok2 = sharding.all_ranks_agree(ok2, cdev)
+            if not ok2:
+                dyn_leg = {"error": "a rank failed in the run-time hand-out pass (see stderr); the static-shard headline is unaffected"}
+        if dyn_leg is None and packed2 is not None:
+            packed = packed2; dist.all_reduce(packed)
             torch.cuda.synchronize(); dist.barrier()
             el2 = torch.tensor([time.perf_counter() - t2], device=cdev, dtype=torch.float64); dist.all_reduce(el2, op=dist.ReduceOp.MAX)
             rs2 = [None] * world; dist.all_gather_object(rs2, (mine2, [int(i) for i in fit2]))
@@ -758,7 +795,7 @@ def main():
                        "sharding": ((f"{args.steps} batches handed out at run time from one shared counter (longest first) to {world} rank(s), every rank holding all inputs" if dynamic else
                                      f"{args.steps} batches over {world} rank(s) in contiguous runs of whole batches (first {args.steps % world} rank(s) one more)") if strong
                                     else f"{world} ranks x {args.steps} batches") + f", no collective in the fit; {args.streams} batch(es) in flight per GPU",
-                       "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs,
+                       "process_group": group_info, "handout": "dynamic" if dynamic else "static", "rank_seconds": [round(float(x), 4) for x in rank_seconds], "rank_jobs": rank_jobs,
                        "stagger_s": round(stagger, 3), "host_section_seconds_rank0": section_s, "batch_done_s_rank0": [round(done_at[k], 3) for k in sorted(done_at)]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_SPLIT_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_SPLIT_TFLOPS,
                          "peak_note": "f16 MFMA dense peak 2516.6 TFLOP/s / 3 MFMAs per algorithmic MAC (hi.hi + hi.lo + lo.hi); the f32-input MFMA peak is 157.3",

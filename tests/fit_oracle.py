@@ -14,7 +14,9 @@ from oracle import oracle as O32
 # float64: the arbiter of what fp32 round-off alone does to a long Adam trajectory)
 
 
-def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_for_global=8, lr_global=0.01, lr_all=0.001, O=O32):
+def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_for_global=8, lr_global=0.01, lr_all=0.001, O=O32, temporal=True, pinit_w=900.0):
+    """``temporal=False, pinit_w=100``: BaseFitter (fit_SMPLH_kpts.py:57-65, 280-304); ``max_iter=30, iter_for_global=0``: SMPLHFitterSmoothed
+    (fit_SMPLH_smoothed.py:74-113: no global-pose warm-up, stop rule armed at it > 9)"""
     pose, betas, trans = (x.astype(O.REAL) for x in (pose0, betas0, trans0)); pose_init = pose.copy()
     gp, bp, tb, ob = pose[:, :3].copy(), pose[:, 3:66].copy(), betas[:, :2].copy(), betas[:, 2:].copy()
     opt = O.Adam([trans, gp, tb], lr_global); prev = 0.0; losses = []; stopped = False
@@ -23,7 +25,8 @@ def oracle_fit_smplt(m, b25, pri, pose0, betas0, trans0, kp, max_iter=100, iter_
             opt = O.Adam([trans, gp, bp, tb, ob], lr_all)
         for _ in range(10):
             pose[:, :3] = gp; pose[:, 3:66] = bp; betas[:, :2] = tb; betas[:, 2:] = ob
-            total, _, dpose, dbetas, dtrans = O.smplt_loss_and_grad(m, b25, pri, pose, betas, trans, kp, pose_init, it=it)
+            total, _, dpose, dbetas, dtrans = O.smplt_loss_and_grad(m, b25, pri, pose, betas, trans, kp, pose_init, it=it, temporal=temporal and pose.shape[0] >= 3,
+                                                                    pinit_w=pinit_w)
             grads = ([dtrans, dpose[:, :3].copy(), dbetas[:, :2].copy()] if it < iter_for_global else
                      [dtrans, dpose[:, :3].copy(), dpose[:, 3:66].copy(), dbetas[:, :2].copy(), dbetas[:, 2:].copy()])
             opt.step(grads); losses.append(total)

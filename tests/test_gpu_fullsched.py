@@ -186,17 +186,26 @@ def smpl_stage_case(synth, B, res_scale, seed=11, full_res_on_device=False):
 
 
 def run_smpl_stage_three_ways(synth, c, fm, mp, with_oracle64=True):
-    """HIP (+ the same HIP path started 1e-6 m away), oracle32, oracle64 through the full optimize_smpl schedule; returns the measured distances
-    (``with_oracle64=False``: the fp64 arbiter -- three times the fp32 oracle's time -- is left to the bench-size test; its columns repeat the fp32 oracle's)"""
+    """HIP (+ the same HIP path started 1e-6 m away, + the HIP path with the temporal term's weight set to ZERO), oracle32, oracle64 through the full
+    optimize_smpl schedule; returns the measured distances (``with_oracle64=False``: the fp64 arbiter -- three times the fp32 oracle's time -- is left to the
+    bench-size test; its columns repeat the fp32 oracle's).  The zero-weight run measures what ``stemp`` (temporal_loss_smpl, recon_fit_trivis_full.py:170-177:
+    live for B >= 4 only) contributes to the result: a strict gate only proves the term right when that contribution is far above the HIP-oracle distance."""
     from oracle import oracle as O, oracle64 as O64
-    from vistracker_amd import ops
+    from vistracker_amd import fitting, ops
     from vistracker_amd.fitting import FitContext
     model, regs, pri, labels = (synth[k] for k in ("model", "regs", "priors", "labels"))
     ctx = FitContext(model, regs, pri, c["dec"], labels, np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32), np.zeros((8, 3), np.float32))
     out = {}
-    for tag, dt in (("hip", 0.0), ("self", 1e-6)):
+    B = c["pose0"].shape[0]
+    for tag, dt in (("hip", 0.0), ("self", 1e-6), ("no_stemp", 0.0)):
         p, b_, t = cu(c["pose0"].copy()), cu(c["betas0"].copy()), cu(c["trans0"] + np.float32(dt))
-        r = ctx.optimize_smpl(fm, p, b_, t, cu(c["cc"]), cu(c["bc"]), cu(c["kp"]))
+        w_stemp = fitting.FIT_WEIGHTS["stemp"]
+        try:
+            if tag == "no_stemp":
+                fitting.FIT_WEIGHTS["stemp"] = 0.0
+            r = ctx.optimize_smpl(fm, p, b_, t, cu(c["cc"]), cu(c["bc"]), cu(c["kp"]))
+        finally:
+            fitting.FIT_WEIGHTS["stemp"] = w_stemp
         out[tag] = (r, ops.smplh_forward(ctx.smpl, p, b_, t)[0].cpu().numpy())
     m64 = O64.SmplModel(model)
     run32 = lambda: oracle_optimize_smpl(c["m"], c["b25"], pri, O.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"])
@@ -210,7 +219,10 @@ def run_smpl_stage_three_ways(synth, c, fm, mp, with_oracle64=True):
     v_start = c["m"].forward(c["pose0"], c["betas0"], c["trans0"])[0]
     n = min(res.steps, len(losses))
     faces = np.asarray(model["f"])
-    rep = dict(steps_hip=res.steps, steps_oracle32=len(losses), steps_oracle64=len(l64), stopped=bool(res.stopped_early and stopped),
+    a0 = (v_start[2:] - v_start[1:-1]) - (v_start[1:-1] - v_start[:-2]) if B >= 3 else np.zeros(1)
+    rep = dict(frames=B, stemp_live=bool(B >= 4), stemp_value_at_start=float((a0.astype(np.float64) ** 2).mean()) if B >= 4 else 0.0,
+               stemp_effect_mean=v2v(vh, out["no_stemp"][1])[0], steps_hip_without_stemp=out["no_stemp"][0].steps)
+    rep.update(steps_hip=res.steps, steps_oracle32=len(losses), steps_oracle64=len(l64), stopped=bool(res.stopped_early and stopped),
                loss_history_rel=rel(res.losses[:n], losses[:n]), hip_vs_oracle32_mean=v2v(vh, v32)[0], hip_vs_oracle32_max=v2v(vh, v32)[1],
                hip_vs_oracle64_mean=v2v(vh, v64)[0], oracle32_vs_oracle64_mean=v2v(v32, v64)[0], hip_self_1e6_mean=v2v(vh, out["self"][1])[0],
                moved_from_start_mean=v2v(vh, v_start)[0], chamfer_hip_vs_oracle32_mean_max=chamfer_ref_metric(vh, v32, faces),
@@ -227,6 +239,10 @@ def assert_strict_smpl_stage(rep):
     assert rep["hip_vs_oracle32_mean"] < 1e-3 and rep["hip_vs_oracle32_max"] < 2e-3, msg        # STRICT north-star bar, v2v
     assert rep["chamfer_hip_vs_oracle32_mean_max"][0] < 1e-3 and rep["chamfer_hip_vs_oracle64_mean_max"][0] < 1e-3, msg     # ... and the reference's Chamfer metric
     assert rep["hip_vs_oracle64_mean"] <= max(1e-3, rep["oracle32_vs_oracle64_mean"]), msg       # fp64 arbiter
+    # the temporal term is LIVE (B >= 4) and the gate can see it: switching its weight off moves the HIP result by >= 1e-4 m AND by >= 20 x the distance
+    # between HIP and the oracle -- a sign error in its gradient would move the result by twice that contribution
+    assert rep["stemp_live"] and rep["stemp_value_at_start"] > 0, msg
+    assert rep["stemp_effect_mean"] > 1e-4 and rep["stemp_effect_mean"] > 20 * rep["hip_vs_oracle32_mean"], msg
 
 
 def test_full_schedule_smpl_stage_body_bowl_strict(synth):
@@ -235,7 +251,8 @@ def test_full_schedule_smpl_stage_body_bowl_strict(synth):
     against the fp32 oracle and the fp64 arbiter, and the HIP path started 1e-6 m away ends <= 1e-4 m from itself (on the random-weight field of the test
     above every pair of runs ends 3e-4 m apart and the bar is met through the arbiter only)."""
     from vistracker_amd import ops, synthetic as syn
-    B = 3           # (the smallest batch the temporal stencils accept; the same fixture runs at bench size with B = 4 and the fp64 arbiter in test_gpu_fullsize.py)
+    B = 4           # the smallest batch for which the reference (and the product) evaluate the temporal term ``stemp`` (recon_fit_trivis_full.py:170-177: B < 4 returns);
+                    # the same fixture runs at bench size, B = 4, with the fp64 arbiter in test_gpu_fullsize.py::test_full_schedule_at_bench_size
     c = smpl_stage_case(synth, B, 1 / 8)
     mp = syn.feature_maps(B, 41, res_scale=1 / 8, smooth=4)
     rep = run_smpl_stage_three_ways(synth, c, ops.FeatureMaps.from_nchw(mp), mp, with_oracle64=False)      # (the fp64 arbiter: test_full_schedule_at_bench_size)
@@ -244,7 +261,7 @@ def test_full_schedule_smpl_stage_body_bowl_strict(synth):
     assert_strict_smpl_stage(rep)
 
 
-def _object_case(synth, B, N, seed, field="random"):
+def _object_case(synth, B, N, seed, field="random", seq_seed=5):
     """``field``: 'random' = the session's random-weight decoders on smoothed random maps (uninformative: chaotic trajectories, Appendix A.11);
     'bowl' = the analytic well-conditioned distance field of synthetic.bowl_decoders (human bowl at the body, object bowl at the objects' mean
     position) on the same maps; the start translation is then 0.1 m (sigma per axis) off, so that the fit has a real basin to descend into."""
@@ -253,7 +270,7 @@ def _object_case(synth, B, N, seed, field="random"):
     rng = np.random.default_rng(seed)
     ov, of = syn.object_template(); pts = syn.sample_surface(ov, of, N, seed=3)
     mp = syn.feature_maps(B, 31, res_scale=1 / 8, smooth=4)
-    seq = syn.sequence_params(B, seed=5)
+    seq = syn.sequence_params(B, seed=seq_seed)
     cc = np.tile(np.array([[1018.952, 779.486]], np.float32), (B, 1)); bc = seq["trans"].copy()
     m = O.SmplModel(synth["model"]); sverts, _, _ = m.forward(seq["pose"], seq["betas"], seq["trans"])
     K = np.tile(np.array([[1.5, 0, 0.5, 0, 1.5, 0.5, 0, 0, 1]], np.float32), (B, 1))
@@ -330,6 +347,18 @@ def test_full_schedule_object_stage_vs_oracle(synth, field, with_sil):
         assert rel(res.losses[:n], losses[:n]) < 1e-3, msg
         assert mean < 1e-3 and mx < 2e-3, msg                             # STRICT north-star bar
         assert m64 <= max(1e-3, o3264), msg                               # fp64 arbiter
+        # the temporal terms otemp / ovtemp (temporal_loss_joint, recon_fit_trivis_full.py:379-391: B >= 4 only) are live and visible to this gate: with their
+        # weights at zero the HIP result moves by far more than HIP and oracle differ
+        from vistracker_amd import fitting
+        saved = {k: fitting.FIT_WEIGHTS[k] for k in ("otemp", "ovtemp")}
+        try:
+            fitting.FIT_WEIGHTS.update(otemp=0.0, ovtemp=0.0)
+            _, R_n, t_n = _run_hip_object(ctx, maps, c, noise, c["t0"], **kw)
+        finally:
+            fitting.FIT_WEIGHTS.update(saved)
+        effect, _ = v2v(X, O.rigid(ctx_pts, O.so3_project(R_n), t_n, c["sc"]))
+        _report(f"object_{field}_sil{int(with_sil)}", temporal_terms_effect_mean=effect, **rep)
+        assert B >= 4 and effect > 1e-4 and effect > 20 * mean, (effect, msg)
         return
     if field == "bowl":
         m64, _ = v2v(X, X64); o3264, _ = v2v(Xo, X64)

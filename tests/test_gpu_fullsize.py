@@ -159,7 +159,7 @@ def test_fused_query_kernels_vs_oracle_at_bench_size(synth, B):
 
 def test_full_schedule_at_bench_size(synth):
     """BOTH stages of the joint fit at the bench's sizes -- V = 6890 SMPL vertices, N = 3000 object surface samples, FULL-RESOLUTION feature maps (71.3 MB per
-    frame), B = 3 frames -- from the start to the reference's stop rules (recon_fit_behave.py:393-465, recon_fit_trivis_full.py:272-377), HIP against the fp32
+    frame), B = 4 frames (temporal terms live) -- from the start to the reference's stop rules (recon_fit_behave.py:393-465, recon_fit_trivis_full.py:272-377), HIP against the fp32
     oracle AND the fp64 arbiter on the well-conditioned fixtures (synthetic.body_bowl_decoders / bowl_decoders).  Bar: the north star's, strictly -- v2v mean
     < 1e-3 m and the reference's own Chamfer metric (recon/eval/chamfer_distance.py:43-48: both directions summed) < 1e-3 m.  (tools/fullsize_parity.py is the
     B = 8 measurement script this test grew out of; profiles/r05_fullsize_parity.json holds its numbers incl. the random-weight field.)"""
@@ -168,7 +168,8 @@ def test_full_schedule_at_bench_size(synth):
     from oracle import oracle as O, oracle64 as O64
     from vistracker_amd import ops, synthetic as syn
     from vistracker_amd.fitting import FitContext
-    B = 3           # the smallest batch the temporal stencils accept (the fp64 oracle at these sizes costs a minute per frame on 128 host threads)
+    B = 4           # the smallest batch for which the temporal terms stemp / otemp / ovtemp are evaluated (recon_fit_trivis_full.py:170-177, 379-391: B < 4 returns;
+                    # the fp64 oracle at these sizes costs a minute per frame on 128 host threads)
     fm = _device_maps(B, 5)
     mp = _host_maps(fm, list(range(B)))
     c = FS.smpl_stage_case(synth, B, 1.0)

@@ -19,8 +19,11 @@ def test_bench_two_ranks_on_one_gpu(mode):
     env = dict(os.environ, VT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     # strong (the default): 3 batches of a 250-frame sequence (96 + 96 + 58 frames) over two ranks -> rank 0 two batches, rank 1 the tail
     extra = ["--steps", "3", "--sequence", "250"] if mode == "strong" else ["--steps", "1", "--mode", "weak"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"] + extra
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541"]
+    if mode == "strong":
+        # the PLAIN command, no launcher: ``python bench.py --gpus 2`` re-executes itself under torch.distributed.run
+        launcher = [sys.executable]; env = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
@@ -30,6 +33,8 @@ def test_bench_two_ranks_on_one_gpu(mode):
     # every rank's batches are counted: all frames of the job / the slowest rank's time
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 * steps - frames) < 1e-6 * frames and line["config"]["frames_timed"] == frames
     assert line["config"]["adam_steps_smpl_stage"] >= 280 and line["roofline"]["launches"] >= 280
+    pg = line["config"]["process_group"]
+    assert pg["backend"] == "gloo" and pg["group_ranks"] == 2 and len(pg["rank_devices"]) == 2, pg
 
 
 def test_dynamic_handout_two_ranks_balances_a_heavy_batch(tmp_path):
@@ -110,6 +115,7 @@ def test_rccl_path_with_a_group_of_one(tmp_path):
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["config"]["frames_timed"] == 96 and line["value"] > 0
+    assert line["config"]["process_group"]["rccl_ranks"] == 1 and "rccl" in line["config"]["process_group"]["backend"], line["config"]["process_group"]
     # the pipeline's gather through RCCL
     script = tmp_path / "g.py"
     script.write_text(

@@ -1,0 +1,172 @@
+"""GPU (-m gpu): the SINGLE-FRAME configurations of BASELINE.json against the CPU oracle (missing 3: they were property checks only).
+
+  configs[0]  one frame through the SMPL-T pre-fit, BaseFitter weights (preprocess/fit_SMPLH_kpts.py:57-65, 114-180, 280-304: no temporal terms,
+              pinit weight 100), 25 synthetic 2-D keypoints, start to stop rule -- through the driver-level mirror ``smplt_fit.BaseFitter.fit_one_batch``
+  configs[1]  one frame through ``optimize_smpl`` + ``optimize_smpl_object`` (recon/recon_fit_behave.py:393-465, recon/recon_fit_trivis_full.py:283-377)
+              at the bench's sizes: V = 6890, N = 3000 object samples, FULL-RESOLUTION maps; >= 50 Adam steps in the SMPL stage, 40 'object only' + 10
+              'sil' + >= 11 'joint' steps in the object stage (contacts-once + Chamfer term when the frame has contacts); temporal terms are skipped for
+              B < 4 exactly like the reference (recon_fit_trivis_full.py:170-177, 379-391)
+  + the SMPLHFitterSmoothed schedule (fit_SMPLH_smoothed.py:74-113: 30 outer iterations, no global-pose warm-up, stop rule armed at it > 9) through
+    ``smplt_fit.SMPLHFitterSmoothed.fit_one_batch`` against ``oracle_fit_smplt(max_iter=30, iter_for_global=0)``
+
+Bar: the north star's 1e-3 m on the final geometry, strictly (measured values are printed and written to gpurun_out/fullsched_parity.json)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from fit_oracle import oracle_fit_smplt, oracle_optimize_smpl, oracle_optimize_object
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _smplt_case(synth, B, seed):
+    """a synthetic B-frame trajectory, full-image keypoints = projection of its body25 joints + 2 px noise with confidences, a perturbed start"""
+    from oracle import oracle as O
+    from vistracker_amd import synthetic as syn
+    model, regs = synth["model"], synth["regs"]
+    sp = syn.sequence_params(B, seed=seed)
+    m = O.SmplModel(model); b25 = O.Landmarks(regs["body25"])
+    v, _, _ = m.forward(sp["pose"].astype(np.float32), sp["betas"].astype(np.float32), sp["trans"].astype(np.float32))
+    J = b25.forward(v)
+    fx, fy, cx, cy = 979.7844, 979.840, 1018.952, 779.486
+    rng = np.random.default_rng(seed + 100)
+    kp = np.stack([J[..., 0] * fx / J[..., 2] + cx + rng.normal(0, 2, J.shape[:2]), J[..., 1] * fy / J[..., 2] + cy + rng.normal(0, 2, J.shape[:2]),
+                   rng.uniform(0.2, 1.0, J.shape[:2])], -1).astype(np.float32)
+    return sp, m, b25, kp, rng
+
+
+class _MemorySource:
+    """the three IO hooks of fit_one_batch (fit_SMPLH_kpts.py:114-180) on arrays in memory"""
+
+    def __init__(self, S, model, pose, betas, trans, kp):
+        self.S, self.model, self.init, self.kp, self.saved = S, model, (pose, betas, trans), kp, []
+
+    def num_frames(self, seq):
+        return len(self.kp)
+
+    def init_smpl(self, seq, kid, start, end, redo):
+        p, b, t = self.init
+        return self.S.SMPLHGenerator.get_smplh(p, b, t, "male", "cuda:0", model_root=self.model), list(range(len(p)))
+
+    def load_kpts(self, seq, kid, start, end, redo, frames=None):
+        return self.kp, [f"{seq}/{i}" for i in frames]
+
+    def save_results(self, smpl, seq, kid, start, end, scores, files):
+        self.saved.append(smpl)
+
+
+def test_config0_single_frame_smplt_prefit_vs_oracle(synth):
+    """BASELINE.json configs[0]: ONE frame, BaseFitter (no temporal terms, pinit weight 100), full schedule to the stop rule, vs the fp32 oracle."""
+    import test_gpu_fullsched as FS
+    from vistracker_amd import ops, smpl as S
+    from vistracker_amd.smplt_fit import BaseFitter
+    B = 1
+    sp, m, b25, kp, rng = _smplt_case(synth, B, seed=21)
+    pose0 = sp["pose"].astype(np.float32).copy(); pose0[:, :66] += 0.08 * rng.normal(size=(B, 66)).astype(np.float32)
+    betas0 = np.zeros((B, 10), np.float32); betas0[:, 0] = 2.2                      # smpl_from_estimates (fit_SMPLH_30fps.py:128-135)
+    trans0 = (sp["trans"] + 0.05 * rng.normal(size=(B, 3))).astype(np.float32)
+    src = _MemorySource(S, synth["model"], pose0, betas0, trans0, kp)
+    fit = BaseFitter(args=SimpleNamespace(icap=False), smpl_model=synth["model"], regressors=synth["regs"], priors=synth["priors"], source=src)
+    res = fit.fit_one_batch("/seq", 1, 0, B, False)
+    out = src.saved[0]
+    ph, bh, th = out.pose.data.contiguous(), out.betas.data.contiguous(), out.trans.data.contiguous()
+    verts_hip = ops.smplh_forward(fit.ctx.smpl, ph, bh, th)[0].cpu().numpy()
+    pose, betas, trans, losses, stopped = oracle_fit_smplt(m, b25, synth["priors"], pose0, betas0, trans0, kp, temporal=False, pinit_w=100.0)
+    betas_back = betas0.copy(); betas_back[:, :2] = betas[:, :2]                      # copy_smpl_params: only betas[:, :2] come back (fit_SMPLH_kpts.py:269-278)
+    verts_cpu = m.forward(pose, betas_back, trans)[0]
+    mean, mx = FS.v2v(verts_hip, verts_cpu)
+    moved = FS.v2v(verts_hip, m.forward(pose0, betas0, trans0)[0])[0]
+    n = min(res.steps, len(losses))
+    FS._report("config0_single_frame_smplt", hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, steps_hip=res.steps, steps_oracle=len(losses), moved_from_start_mean=moved,
+               loss_history_rel=FS.rel(res.losses[:n], losses[:n]))
+    print(f"configs[0] one frame SMPL-T: steps {res.steps} / {len(losses)}, HIP vs oracle {mean:.2e} m mean {mx:.2e} max, moved {moved:.3f} m")
+    assert res.stopped_early == stopped and abs(res.steps - len(losses)) <= 2 and res.steps > 310, (res.steps, len(losses))
+    assert FS.rel(res.losses[:n], losses[:n]) < 1e-5
+    assert moved > 1e-2 and mean < 1e-4 and mx < 1e-3, (mean, mx, moved)
+    assert np.array_equal(bh[:, 2:].cpu().numpy(), betas0[:, 2:])
+
+
+def test_smplt_smoothed_schedule_vs_oracle(synth):
+    """SMPLHFitterSmoothed (fit_SMPLH_smoothed.py:74-113): 30 outer iterations, all-pose optimiser from the first step (get_globalopt_iters() == 0), temporal
+    terms live (B = 8), stop rule armed at it > 0.3 * 30 = 9 -- the re-fit demo.sh runs after SmoothNet."""
+    import test_gpu_fullsched as FS
+    from vistracker_amd import ops, smpl as S
+    from vistracker_amd.smplt_fit import SMPLHFitterSmoothed
+    B = 8
+    sp, m, b25, kp, rng = _smplt_case(synth, B, seed=9)
+    pose0 = sp["pose"].astype(np.float32).copy(); pose0[:, :66] += 0.03 * rng.normal(size=(B, 66)).astype(np.float32)      # a smoothed estimate: close to the truth
+    betas0 = sp["betas"].astype(np.float32).copy(); trans0 = (sp["trans"] + 0.02 * rng.normal(size=(B, 3))).astype(np.float32)
+    src = _MemorySource(S, synth["model"], pose0, betas0, trans0, kp)
+    fit = SMPLHFitterSmoothed(args=SimpleNamespace(icap=False), smpl_model=synth["model"], regressors=synth["regs"], priors=synth["priors"], source=src)
+    assert fit.get_max_iters() == 30 and fit.get_globalopt_iters() == 0
+    res = fit.fit_one_batch("/seq", 1, 0, B, False)
+    out = src.saved[0]
+    verts_hip = ops.smplh_forward(fit.ctx.smpl, out.pose.data.contiguous(), out.betas.data.contiguous(), out.trans.data.contiguous())[0].cpu().numpy()
+    pose, betas, trans, losses, stopped = oracle_fit_smplt(m, b25, synth["priors"], pose0, betas0, trans0, kp, max_iter=30, iter_for_global=0)
+    betas_back = betas0.copy(); betas_back[:, :2] = betas[:, :2]
+    verts_cpu = m.forward(pose, betas_back, trans)[0]
+    mean, mx = FS.v2v(verts_hip, verts_cpu)
+    n = min(res.steps, len(losses))
+    FS._report("smplt_smoothed_schedule", hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, steps_hip=res.steps, steps_oracle=len(losses), stopped_hip=bool(res.stopped_early),
+               stopped_oracle=bool(stopped), loss_history_rel=FS.rel(res.losses[:n], losses[:n]))
+    print(f"SMPLHFitterSmoothed: steps {res.steps} / {len(losses)} (stopped {res.stopped_early} / {stopped}), HIP vs oracle {mean:.2e} m mean {mx:.2e} max")
+    assert res.stopped_early == stopped and abs(res.steps - len(losses)) <= 2 and 100 < res.steps <= 300, (res.steps, len(losses))
+    assert FS.rel(res.losses[:n], losses[:n]) < 1e-5
+    assert mean < 1e-4 and mx < 1e-3, (mean, mx)
+
+
+def test_config1_single_frame_joint_fit_vs_oracle(synth):
+    """BASELINE.json configs[1]: ONE frame, SMPL-H + one rigid object, both stages at the bench's sizes against the fp32 oracle."""
+    import test_gpu_fullsched as FS
+    import test_gpu_fullsize as FZ
+    from oracle import oracle as O
+    from vistracker_amd import ops, synthetic as syn
+    from vistracker_amd.fitting import FitContext, SilSetup
+    B, N = 1, 3000
+    model, regs, pri, labels = (synth[k] for k in ("model", "regs", "priors", "labels"))
+    fm = FZ._device_maps(B, 5); mp = FZ._host_maps(fm, [0])
+    cu = FS.cu
+    # ---- SMPL stage: 1 + 1 + 1 + 8 outer iterations, the stop rule armed at it > 0.25 * 8 + 2 -> at least 50 Adam steps
+    c = FS.smpl_stage_case(synth, B, 1.0, seed=13)
+    ctx = FitContext(model, regs, pri, c["dec"], labels, np.zeros((8, 3), np.float32), np.zeros((1, 3), np.int32), np.zeros((8, 3), np.float32))
+    p, b_, t = cu(c["pose0"].copy()), cu(c["betas0"].copy()), cu(c["trans0"].copy())
+    r1 = ctx.optimize_smpl(fm, p, b_, t, cu(c["cc"]), cu(c["bc"]), cu(c["kp"]), max_iter=8)
+    vh = ops.smplh_forward(ctx.smpl, p, b_, t)[0].cpu().numpy()
+    pose, betas, trans, losses, stopped = oracle_optimize_smpl(c["m"], c["b25"], pri, O.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"],
+                                                                c["kp"], max_iter=8)
+    v32 = c["m"].forward(pose, betas, trans)[0]
+    mean, mx = FS.v2v(vh, v32); moved = FS.v2v(vh, c["m"].forward(c["pose0"], c["betas0"], c["trans0"])[0])[0]
+    n = min(r1.steps, len(losses))
+    rep = dict(steps_hip=r1.steps, steps_oracle32=len(losses), hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, moved_from_start_mean=moved,
+               loss_history_rel=FS.rel(r1.losses[:n], losses[:n]))
+    FS._report("config1_single_frame_smpl_stage", **rep)
+    print("configs[1] one frame, SMPL stage:", rep)
+    assert r1.steps >= 50 and abs(r1.steps - len(losses)) <= 2 and r1.stopped_early == stopped, rep
+    assert rep["loss_history_rel"] < 1e-3 and moved > 1e-2 and mean < 1e-3 and mx < 2e-3, rep
+    # ---- object stage: 40 'object only' + 10 'sil' + 'joint' steps (contacts-once, Chamfer) to the stop rule, bowl field, the frame's own silhouette inputs
+    fm.drop_projection()
+    oc = FS._object_case(synth, B, N, seed=17, field="bowl", seq_seed=8)          # (a frame whose joint phase HAS contacts: checked on the oracle)
+    ctxb = FitContext(model, regs, pri, oc["dec"], labels, oc["ov"], oc["of"], oc["pts"])
+    pts = ctxb.obj_points.cpu().numpy()
+    kw = dict(iter_for_obj=4, iter_for_sil=1, joint_iter=1, max_iter=20)         # stop rule armed at it > 0.25 * 20: one full outer iteration of 'joint' at least
+    nsteps = sum(kw.values()) * 10
+    noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
+    R, tt, s = cu(oc["R0"].copy()), cu(oc["t0"].copy()), torch.ones(B, device="cuda")
+    r2 = ctxb.optimize_smpl_object(fm, cu(oc["sverts"]), R, tt, s, cu(oc["cc"]), cu(oc["bc"]), cu(oc["occ"]), sil=SilSetup(cu(oc["K"]), cu(oc["keep"]), cu(oc["ref"])),
+                                   noise=cu(noise), **kw)
+    sil = dict(faces=oc["of"], verts=oc["ov"], K=oc["K"], keep=oc["keep"], ref=oc["ref"])
+    Ro, to, ls, st, hc = oracle_optimize_object(O.SifNet(oc["dec"], mp), pts, oc["R0"], oc["t0"], oc["sc"], noise, oc["cc"], oc["bc"], oc["occ"], oc["sverts"], labels,
+                                                sil=sil, **kw)
+    Xh = O.rigid(pts, O.so3_project(R.cpu().numpy()), tt.cpu().numpy(), oc["sc"]); Xo = O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), oc["sc"])
+    X0 = O.rigid(pts, O.so3_project(oc["R0"]), oc["t0"], oc["sc"])
+    mean, mx = FS.v2v(Xh, Xo); moved = FS.v2v(Xh, X0)[0]
+    n = min(r2.steps, len(ls))
+    repo = dict(steps_hip=r2.steps, steps_oracle32=len(ls), had_contacts=bool(hc), hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, moved_from_start_mean=moved,
+                loss_history_rel_object_only=FS.rel(r2.losses[:40], np.array(ls)[:40]), loss_history_rel=FS.rel(r2.losses[:n], np.array(ls)[:n]))
+    FS._report("config1_single_frame_object_stage", **repo)
+    print("configs[1] one frame, object stage:", repo)
+    assert r2.steps > 60 and abs(r2.steps - len(ls)) <= 2 and r2.stopped_early == st and repo["had_contacts"], repo
+    assert repo["loss_history_rel_object_only"] < 1e-3 and moved > 1e-2, repo
+    assert mean < 1e-3 and mx < 2e-3, repo

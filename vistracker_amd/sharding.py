@@ -186,8 +186,13 @@ def all_ranks_agree(flag: bool, device=None) -> bool:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return bool(flag)
-    on_host = dist.get_backend() == "gloo" or device is None
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if on_host else device)
+    # the flag lives where the group's backend can reduce it: host memory for gloo; for nccl (= RCCL, no CPU backend) the given device or, when the
+    # caller named none, this process's current GPU -- never the CPU ("No backend type associated with device type cpu")
+    if dist.get_backend() == "gloo":
+        where = "cpu"
+    else:
+        where = device if (device is not None and torch.device(device).type == "cuda") else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=where)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t.item()))
 
