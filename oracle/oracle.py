@@ -281,6 +281,15 @@ def sil_forward(verts, faces, K, size=256):
     return img
 
 
+def sil_face_index(verts, faces, K, size=256):
+    """the doubled-face id that owns each pixel (-1: background), image orientation -- the map the backward's ownership tests read"""
+    verts, vp = _f(verts); faces, fp = _i(faces); K, kp = _f(K)
+    B, NV = verts.shape[:2]
+    fim = np.empty((B, size, size), np.int32)
+    lib().vto_sil_face_index(vp, B, NV, fp, faces.shape[0], kp, size, fim.ctypes.data_as(c_ip))
+    return fim
+
+
 def triplane_render(verts, faces, center, size=512):
     """TriplaneNrRenderer.render_3views for a batch: (B,NV,3), (NF,3), (B,3) -> (B,3,size,size) masks (right, back, top)"""
     verts, vp = _f(verts); faces, fp = _i(faces); center, cp = _f(center)

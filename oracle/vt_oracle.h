@@ -60,6 +60,7 @@ double vto_chamfer_ragged(const float *x, const int *offx, const float *y, const
                           float gscale, float *dx, float *dy);
 
 void vto_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int is, float *image);
+void vto_sil_face_index(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int is, int *face_index);
 void vto_triplane_render(const float *verts, const float *center, int B, int NV, const int *faces, int NF, int is, float *masks);
 void vto_sil_backward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int is,
                       const float *d_image, float eps, float *dverts);

@@ -125,10 +125,10 @@ def test_silhouette_large_faces_take_the_whole_wave(hip):
     v = cu(verts).requires_grad_(True)
     img = ops.silhouette(v, cu(f), cu(K), 256)
     assert 0.1 < img_o.mean() < 0.9
-    assert np.abs(npy(img) - img_o).sum() <= 4
+    assert np.abs(npy(img) - img_o).sum() == 0
     gimg = (2 * (img_o - np.roll(img_o, 7, axis=2))).astype(np.float32)
     (img * cu(gimg)).sum().backward()
-    assert rel(npy(v.grad), O.sil_backward(verts, f, K, gimg, 256, 1e-4)) < 2e-3
+    assert rel(npy(v.grad), O.sil_backward(verts, f, K, gimg, 256, 1e-4)) < 1e-5
 
 
 def test_landmarks(hip, synth):
@@ -381,13 +381,13 @@ def test_silhouette(hip):
     img = ops.silhouette(v, cu(faces), cu(K), 256)
     diff = np.abs(npy(img) - img_o)
     assert 0.05 < img_o.mean() < 0.95
-    assert diff.sum() <= 4, diff.sum()       # identical coverage up to fp32 edge ties
+    assert diff.sum() == 0, diff.sum()       # identical coverage (round 6: the oracle's silhouette code is built without fp contraction, like the product)
     rng = np.random.default_rng(1)
     ref = np.roll(img_o, 5, axis=2)
     gimg = (2 * (img_o - ref)).astype(np.float32)
     (img * cu(gimg)).sum().backward()
     dv_o = O.sil_backward(verts, faces, K, gimg, 256, 1e-4)
-    assert rel(npy(v.grad), dv_o) < 2e-3
+    assert rel(npy(v.grad), dv_o) < 1e-5     # (was 2e-3 while the oracle contracted a * b + c into FMAs: sweep boundaries flipped, 1e-4 per call)
 
 
 def test_silhouette_per_call_at_bench_size(hip):
@@ -414,7 +414,16 @@ def test_silhouette_per_call_at_bench_size(hip):
     v = cu(verts).requires_grad_(True)
     img = ops.silhouette(v, cu(faces), cu(K), 256)
     bad = (npy(img) != img_o).reshape(B, -1).sum(1)
-    assert bad.max() <= 3 and bad.sum() <= 24, f"pixel disagreements per frame: max {bad.max()}, total {bad.sum()} of {B * 65536}"
+    assert bad.sum() == 0, f"pixel disagreements per frame: max {bad.max()}, total {bad.sum()} of {B * 65536}"
+    # ... and the same OWNER in every pixel: the backward's tests (face_index == f2) read the map, not the coverage
+    from vistracker_amd import _lib as L
+    NV, NF = verts.shape[1], faces.shape[0]
+    fidx = torch.empty(B, 256, 256, dtype=torch.int32, device="cuda"); im2 = torch.empty(B, 256, 256, device="cuda")
+    ws = torch.empty(L.lib().vt_sil_workspace_floats(B, NV, NF, 256), device="cuda")
+    vd, fd, kd = v.detach(), cu(faces), cu(K)          # (named: a temporary's block would be handed to the next allocation before the launch reads it)
+    L.check(L.lib().vt_sil_forward(L.dptr(vd), B, NV, L.dptr(fd), NF, L.dptr(kd), 256, L.dptr(im2), L.dptr(fidx), L.dptr(ws), L.stream_ptr()))
+    owners = (npy(fidx) != O.sil_face_index(verts, faces, K, 256)).sum()
+    assert owners == 0, f"{owners} pixels owned by different faces"
     # upstream gradient of the mask term of phase 'sil': rendered minus a reference silhouette shifted by a few pixels, half of the crop occluded
     ref = np.roll(img_o, (3, -4), axis=(1, 2)); keep = np.ones_like(ref); keep[:, 96:160, :80] = 0
     gimg = (2 * (img_o * keep - ref * keep) * keep / (256 * 256)).astype(np.float32)
@@ -423,7 +432,7 @@ def test_silhouette_per_call_at_bench_size(hip):
     num = (dv * dv_o).reshape(B, -1).sum(1); den = np.linalg.norm(dv.reshape(B, -1), axis=1) * np.linalg.norm(dv_o.reshape(B, -1), axis=1)
     cos = num / np.maximum(den, 1e-30)
     relf = np.abs(dv - dv_o).reshape(B, -1).max(1) / np.abs(dv_o).reshape(B, -1).max(1)
-    assert np.all(den > 0) and cos.min() > 0.9999 and np.median(relf) < 2e-3 and relf.max() < 5e-2, \
+    assert np.all(den > 0) and cos.min() > 0.999999 and np.median(relf) < 1e-6 and relf.max() < 1e-5, \
         f"per-frame gradient cosine min {cos.min():.6f}; relative max error median {np.median(relf):.2e}, worst frame {relf.max():.2e}"
 
 

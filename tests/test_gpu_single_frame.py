@@ -145,28 +145,55 @@ def test_config1_single_frame_joint_fit_vs_oracle(synth):
     print("configs[1] one frame, SMPL stage:", rep)
     assert r1.steps >= 50 and abs(r1.steps - len(losses)) <= 2 and r1.stopped_early == stopped, rep
     assert rep["loss_history_rel"] < 1e-3 and moved > 1e-2 and mean < 1e-3 and mx < 2e-3, rep
-    # ---- object stage: 40 'object only' + 10 'sil' + 'joint' steps (contacts-once, Chamfer) to the stop rule, bowl field, the frame's own silhouette inputs
+    # ---- object stage, bowl field, the frame's own silhouette inputs (a frame whose joint phase HAS contacts: checked on the oracle):
+    #      (a) 40 'object only' + 'joint' steps (contacts-once, Chamfer) to the stop rule -- smooth objective, STRICT 1e-3 m against the fp32 oracle;
+    #      (b) the same with 10 'sil' steps in between.  The silhouette surrogate is piecewise constant in fp32: a sweep boundary floor(d1_cross) flips when
+    #          an input changes by one ulp (~4 flips per call at 2500 faces), so two CORRECT implementations whose SO(3) projections differ in the last bit
+    #          see gradients 1e-4 .. 7e-3 apart at the SAME state with zero differing pixels (measured, tools/diag/sil_step_grad.py) and Adam's first steps
+    #          (m / sqrt(v) = sign) turn that into millimetres.  Leg (b) is therefore arbitrated like test_full_schedule_object_stage_vs_oracle's 'sil'
+    #          leg: HIP must be as close to the fp64 run as the fp32 oracle is, and no further from the fp32 oracle than its own sensitivity to a 1e-6 m
+    #          change of the start.
+    from oracle import oracle64 as O64
     fm.drop_projection()
-    oc = FS._object_case(synth, B, N, seed=17, field="bowl", seq_seed=8)          # (a frame whose joint phase HAS contacts: checked on the oracle)
+    oc = FS._object_case(synth, B, N, seed=17, field="bowl", seq_seed=8)
     ctxb = FitContext(model, regs, pri, oc["dec"], labels, oc["ov"], oc["of"], oc["pts"])
     pts = ctxb.obj_points.cpu().numpy()
-    kw = dict(iter_for_obj=4, iter_for_sil=1, joint_iter=1, max_iter=20)         # stop rule armed at it > 0.25 * 20: one full outer iteration of 'joint' at least
-    nsteps = sum(kw.values()) * 10
-    noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
-    R, tt, s = cu(oc["R0"].copy()), cu(oc["t0"].copy()), torch.ones(B, device="cuda")
-    r2 = ctxb.optimize_smpl_object(fm, cu(oc["sverts"]), R, tt, s, cu(oc["cc"]), cu(oc["bc"]), cu(oc["occ"]), sil=SilSetup(cu(oc["K"]), cu(oc["keep"]), cu(oc["ref"])),
-                                   noise=cu(noise), **kw)
     sil = dict(faces=oc["of"], verts=oc["ov"], K=oc["K"], keep=oc["keep"], ref=oc["ref"])
-    Ro, to, ls, st, hc = oracle_optimize_object(O.SifNet(oc["dec"], mp), pts, oc["R0"], oc["t0"], oc["sc"], noise, oc["cc"], oc["bc"], oc["occ"], oc["sverts"], labels,
-                                                sil=sil, **kw)
-    Xh = O.rigid(pts, O.so3_project(R.cpu().numpy()), tt.cpu().numpy(), oc["sc"]); Xo = O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), oc["sc"])
     X0 = O.rigid(pts, O.so3_project(oc["R0"]), oc["t0"], oc["sc"])
-    mean, mx = FS.v2v(Xh, Xo); moved = FS.v2v(Xh, X0)[0]
-    n = min(r2.steps, len(ls))
-    repo = dict(steps_hip=r2.steps, steps_oracle32=len(ls), had_contacts=bool(hc), hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, moved_from_start_mean=moved,
-                loss_history_rel_object_only=FS.rel(r2.losses[:40], np.array(ls)[:40]), loss_history_rel=FS.rel(r2.losses[:n], np.array(ls)[:n]))
-    FS._report("config1_single_frame_object_stage", **repo)
-    print("configs[1] one frame, object stage:", repo)
-    assert r2.steps > 60 and abs(r2.steps - len(ls)) <= 2 and r2.stopped_early == st and repo["had_contacts"], repo
-    assert repo["loss_history_rel_object_only"] < 1e-3 and moved > 1e-2, repo
-    assert mean < 1e-3 and mx < 2e-3, repo
+
+    def hip_run(kw, noise, t0):
+        R, tt, s = cu(oc["R0"].copy()), cu(t0.copy()), torch.ones(B, device="cuda")
+        r = ctxb.optimize_smpl_object(fm, cu(oc["sverts"]), R, tt, s, cu(oc["cc"]), cu(oc["bc"]), cu(oc["occ"]), sil=SilSetup(cu(oc["K"]), cu(oc["keep"]), cu(oc["ref"])),
+                                      noise=cu(noise), **kw)
+        return r, O.rigid(pts, O.so3_project(R.cpu().numpy()), tt.cpu().numpy(), oc["sc"])
+
+    def oracle_run(Om, kw, noise):
+        Ro, to, ls, st, hc = oracle_optimize_object(Om.SifNet(oc["dec"], mp), pts, oc["R0"], oc["t0"], oc["sc"], noise, oc["cc"], oc["bc"], oc["occ"], oc["sverts"], labels,
+                                                    sil=sil if kw["iter_for_sil"] else None, O=Om, **kw)
+        return O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), oc["sc"]), np.array(ls), st, hc
+
+    for leg, n_sil in (("a_no_sil", 0), ("b_with_sil", 1)):
+        kw = dict(iter_for_obj=4, iter_for_sil=n_sil, joint_iter=1, max_iter=20)         # stop rule armed at it > 0.25 * 20: one full outer iteration of 'joint' at least
+        nsteps = sum(kw.values()) * 10
+        noise = np.random.default_rng(23).uniform(0, 1, (nsteps, B, 3, 3)).astype(np.float32)
+        r2, Xh = hip_run(kw, noise, oc["t0"])
+        Xo, ls, st, hc = oracle_run(O, kw, noise)
+        mean, mx = FS.v2v(Xh, Xo); moved = FS.v2v(Xh, X0)[0]
+        n = min(r2.steps, len(ls))
+        repo = dict(steps_hip=r2.steps, steps_oracle32=len(ls), had_contacts=bool(hc), hip_vs_oracle32_mean=mean, hip_vs_oracle32_max=mx, moved_from_start_mean=moved,
+                    loss_history_rel_object_only=FS.rel(r2.losses[:40], ls[:40]), loss_history_rel=FS.rel(r2.losses[:n], ls[:n]))
+        assert r2.steps >= 50 + 10 * n_sil and abs(r2.steps - len(ls)) <= 2 and r2.stopped_early == st and repo["had_contacts"], repo
+        assert repo["loss_history_rel_object_only"] < 1e-3 and moved > 1e-2, repo
+        if n_sil == 0:
+            FS._report("config1_single_frame_object_stage_" + leg, **repo)
+            print("configs[1] one frame, object stage (object only + joint):", repo)
+            assert repo["loss_history_rel"] < 1e-3 and mean < 1e-3 and mx < 2e-3, repo          # STRICT
+        else:
+            _, Xp = hip_run(kw, noise, oc["t0"] + np.float32(1e-6))
+            X64 = oracle_run(O64, kw, noise)[0]
+            self_mean = FS.v2v(Xh, Xp)[0]; m64 = FS.v2v(Xh, X64)[0]; o3264 = FS.v2v(Xo, X64)[0]
+            repo.update(hip_self_1e6=self_mean, hip_vs_oracle64_mean=m64, oracle32_vs_oracle64_mean=o3264)
+            FS._report("config1_single_frame_object_stage_" + leg, **repo)
+            print("configs[1] one frame, object stage (with 10 'sil' steps):", repo)
+            assert m64 <= 1.25 * max(1e-3, o3264), repo                                         # fp64 arbiter
+            assert mean < 2 * max(self_mean, 1.5e-3) and mean < 1e-2, repo                      # the path's own sensitivity
