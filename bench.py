@@ -194,6 +194,43 @@ def solo_kernel_leg(ctx, torch, d, launches=20, fp32=False):
     return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
 
 
+# Box calibration.  Reference values: the box of profiles/r06_calibration_reference.txt, on which round 5's kernel (the library of commit
+# a8c3e7f) took CALIB_REF["r05_solo_ms"] per launch in this very leg -- so a later line can be read as "kernel x box": solo_launch_ms_at_reference_box rescales the
+# measured solo time by the matrix-pipe rate of the box it ran on.
+CALIB_REF = {"mfma_f16_tflops": None, "sustained_mhz": None, "l2_delivery_TBps": None, "r05_solo_ms": None}
+
+
+def calib_summary(extras, solo_ms):
+    c = extras.get("calibration")
+    if not isinstance(c, dict) or "error" in c:
+        return c
+    out = dict(c); after = extras.get("calibration_after_solo")
+    if isinstance(after, dict) and "error" not in after:
+        out["after_solo"] = {k: after[k] for k in ("mfma_f16_tflops", "sustained_mhz", "l2_delivery_TBps")}
+    out["reference_box"] = CALIB_REF
+    if solo_ms is not None and CALIB_REF["mfma_f16_tflops"]:
+        out["solo_launch_ms_at_reference_box"] = solo_ms * c["mfma_f16_tflops"] / CALIB_REF["mfma_f16_tflops"]
+        if CALIB_REF["r05_solo_ms"]:
+            out["vs_r05_kernel_at_equal_calibration"] = out["solo_launch_ms_at_reference_box"] / CALIB_REF["r05_solo_ms"]
+    return out
+
+
+def calibration_leg(torch, reps=3):
+    """vt_calibrate (csrc/calib.hip) `reps` times: median f16 MFMA TFLOP/s, sustained shader clock, L2 -> register delivery -- ~15 ms each, outside the timed region"""
+    import ctypes as C
+    from vistracker_amd import _lib as L
+    work = torch.empty(L.lib().vt_calibrate_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    out = (C.c_double * 8)(); rows = []
+    for _ in range(reps):
+        L.check(L.lib().vt_calibrate(work.data_ptr(), out, L.stream_ptr()))
+        rows.append([out[i] for i in range(5)])
+    med = np.median(np.asarray(rows), axis=0)
+    return {"mfma_f16_tflops": float(med[0]), "mfma_f16_frac_of_peak": float(med[0] / 2516.6), "sustained_mhz": float(med[1]), "l2_delivery_TBps": float(med[2]),
+            "kernel_ms": [float(med[3]), float(med[4])], "reps": reps,
+            "note": "two fixed micro-kernels (csrc/calib.hip): v_mfma_f32_16x16x32_f16 with non-trivial operands, 2 workgroups of 256 threads per CU; lane-linear "
+                    "16-byte loads from an L2-resident table; shader clock = s_memtime / s_memrealtime x 100 MHz inside the MFMA kernel"}
+
+
 def smplt_prefit_leg(ctx, torch, syn, T, bs=512):
     """The SMPL-T pre-fit (preprocess/fit_SMPLH_30fps.py -bs 512, scripts/demo.sh:13; fit_SMPLH_kpts.py:114-180) of the same synthetic sequence as
     its own line: batches of 512 consecutive frames, keypoints = projection of the ground-truth body25 joints + 2 px noise, start =
@@ -335,6 +372,11 @@ def cpu_baseline(syn, model, regs, pri, dec, labels, smpl_steps, obj_steps, budg
 
 
 def main():
+    # watchdog (off by default; VT_BENCH_WATCHDOG=<seconds>): a run that is still alive after that many seconds dumps the Python stack of every thread to stderr and
+    # exits with status 3 -- a hang (a rank waiting in a collective the others skipped, a leg stuck in a lock) then costs a bounded time and says WHERE it was
+    if os.environ.get("VT_BENCH_WATCHDOG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VT_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="batches in the timed region (default: one pass over the sequence = 16 for 1500 frames; "
@@ -692,7 +734,9 @@ def main():
             except Exception as e:          # noqa: BLE001
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
         full96 = next((d_ for d_ in batches if d_["pose"].shape[0] == BATCH), None) or make_batch(ctx, syn, torch, seed=555, dev=dev, res_scale=args.res_scale)
+        leg("calibration", lambda: calibration_leg(torch))
         leg("solo_launch_s", lambda: solo_kernel_leg(ctx, torch, full96))
+        leg("calibration_after_solo", lambda: calibration_leg(torch, reps=1))
 
         def full_schedule():
             d = run(0); torch.cuda.synchronize(); t1 = time.perf_counter()          # the headline's batches (first three of the sequence), fresh copies
@@ -806,6 +850,9 @@ def main():
                          # rocprofv3 kernel trace reports (profiles/rNN_kernel_stats_1stream.csv)
                          "solo_launch_ms": None if solo is None else 1e3 * solo,
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
+                         # box calibration right before / after the solo launches: what THIS box's matrix pipe, clock and L2 path deliver, so that the solo time
+                         # can be read as kernel x box (boxes of the pool differ by +-4 %); *_at_reference_box = solo time rescaled by the MFMA rate ratio
+                         "calibration": calib_summary(extras, None if solo is None else 1e3 * solo),
                          "frac_union": (flops_all / busy_union / 1e12 / PEAK_SPLIT_TFLOPS) if busy_union > 0 else None,
                          "achieved_note": "algorithmic FLOPs of all launches / the kernel's share of the time in which it was executing: per-launch HIP events of both "
                                           "query kernels, a segment with n_h launches of this kernel and n_o of the object stage's one-head query executing counts "

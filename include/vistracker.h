@@ -484,6 +484,14 @@ int vt_gen_scatter_heads(const float *pred, int B, int C, int kmax, const long l
 int vt_gen_resample(const float *samples, const int *order, const long long *cnt, const float *init, int B, int S, int S0, const float *u,
                     const float *pert, int M, float near_scale, float *out, void *stream);
 
+/* ---- box calibration (measurement infrastructure of bench.py; no counterpart in the reference, which times whole processes: README.md:55) ------------------
+ * Two fixed micro-kernels exercising the resources the dominant kernel of the fit is limited by: out[0] = dense f16 MFMA TFLOP/s (v_mfma_f32_16x16x32_f16, two
+ * workgroups of 256 threads per CU, non-trivial operands), out[1] = shader clock sustained during it (MHz: s_memtime against the 100 MHz s_memrealtime),
+ * out[2] = L2 -> register delivery of lane-linear 16-byte loads (TB/s), out[3], out[4] = their durations in ms.  `work`: vt_calibrate_workspace_bytes() bytes
+ * of device memory.  Synchronises `stream`; ~25 ms. */
+long vt_calibrate_workspace_bytes(void);
+int vt_calibrate(void *work, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

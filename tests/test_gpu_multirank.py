@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 
 @pytest.mark.parametrize("mode", ["strong", "weak"])
 def test_bench_two_ranks_on_one_gpu(mode):
-    env = dict(os.environ, VT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, VT_BENCH_WATCHDOG="600", VT_BENCH_TEST_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     # strong (the default): 3 batches of a 250-frame sequence (96 + 96 + 58 frames) over two ranks -> rank 0 two batches, rank 1 the tail
     extra = ["--steps", "3", "--sequence", "250"] if mode == "strong" else ["--steps", "1", "--mode", "weak"]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541"]
@@ -46,7 +46,7 @@ def test_dynamic_handout_two_ranks_balances_a_heavy_batch(tmp_path):
     base = [os.path.join(ROOT, "bench.py"), "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1", "--steps", "6", "--sequence", "540", "--res-scale", "0.5"]
     out_lines = {}
     for tag, n, handout, port in (("one", 1, "static", 29571), ("dyn", 2, "dynamic", 29572), ("sta", 2, "static", 29573)):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", VT_BENCH_FULL_SCHEDULE_BATCH="0", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"))
+        env = dict(os.environ, VT_BENCH_WATCHDOG="600", MASTER_ADDR="127.0.0.1", VT_BENCH_FULL_SCHEDULE_BATCH="0", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"))
         if n > 1:
             env["VT_BENCH_TEST_SHARED_GPU"] = "1"
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + \
@@ -80,7 +80,7 @@ def test_pipeline_two_ranks_equal_one_rank(tmp_path):
         f = tmp_path / f"r{n}.npz"
         # hermetic MIOpen state: a fresh user database per run, so that find results recorded by earlier processes on this box (other tests
         # benchmark convolution algorithms in the default find mode) cannot steer the two runs to different convolution kernels
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"))
+        env = dict(os.environ, VT_BENCH_WATCHDOG="600", MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                script, str(f), "100"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
@@ -107,7 +107,7 @@ def test_rccl_path_with_a_group_of_one(tmp_path):
     """No multi-GPU node has been available to this repository, so the RCCL calls of the N > 1 path (``init_process_group("nccl")``, the barriers, the
     final all_gather of the fitted rows, the MAX all_reduce of the time; ``sharding.gather_params`` of the pipeline) are executed here with a process
     group of ONE rank over RCCL on the test box's GPU (``VT_FORCE_DIST=1``): same calls, same tensors, no peer."""
-    env = dict(os.environ, VT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, VT_BENCH_WATCHDOG="600", VT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29561",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
@@ -144,7 +144,7 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     base = [os.path.join(ROOT, "bench.py"), "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--streams", "1", "--steps", "20", "--res-scale", "0.125"]
     lines = {}
     for tag, n, port in (("one", 1, 29581), ("eight", 8, 29582)):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"), OMP_NUM_THREADS="4")
+        env = dict(os.environ, VT_BENCH_WATCHDOG="600", MASTER_ADDR="127.0.0.1", VT_BENCH_DUMP_ROWS=str(tmp_path / f"{tag}.npy"), OMP_NUM_THREADS="4")
         if n > 1:
             env["VT_BENCH_TEST_SHARED_GPU"] = "1"
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + base + ["--gpus", str(n)]
@@ -175,7 +175,7 @@ def test_pipeline_eight_ranks_equal_one_rank(tmp_path):
     outs = []
     for n, port in ((1, 29591), (8, 29592)):
         f = tmp_path / f"r{n}.npz"
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"), OMP_NUM_THREADS="4")
+        env = dict(os.environ, VT_BENCH_WATCHDOG="600", MASTER_ADDR="127.0.0.1", MIOPEN_FIND_MODE="FAST", MIOPEN_USER_DB_PATH=str(tmp_path / f"miopen_db_{n}"), OMP_NUM_THREADS="4")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                script, str(f), "250"]
         out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=2400, cwd=ROOT)

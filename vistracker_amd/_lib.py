@@ -117,6 +117,8 @@ SIGNATURES = {
     "vt_loss_reduce_and_stop": (ci, [fp, vp, ci, cf, ci, fp, fp, fp, ci, vp]),
     "vt_fill": (ci, [fp, cl, cf, vp]),
     "vt_selftest_mfma": (ci, [fp, fp, fp, vp]),
+    "vt_calibrate_workspace_bytes": (cl, []),
+    "vt_calibrate": (ci, [vp, C.POINTER(C.c_double), vp]),
 }
 
 _lib = None

@@ -116,6 +116,15 @@ __device__ __forceinline__ int map_proj(int mi) { return kMap[mi].y; }
 __device__ __forceinline__ void chunk_info(int i, int &mi, int &co) { const int2 c = kChunk[i]; mi = c.x; co = c.y; }
 
 __device__ __forceinline__ h8 as_h8(const uint4 v) { return __builtin_bit_cast(h8, v); }
+// identity the optimiser cannot see through: what is computed from the result is NOT common with what was computed from the argument (no cross-phase CSE, hence
+// no value kept alive -- or spilled -- from one phase of the kernel to a far later one just to save its recomputation)
+#ifdef NO_LAUNDER      /* A/B builds only */
+__device__ __forceinline__ int launder_s(int x) { return x; }
+__device__ __forceinline__ int launder_v(int x) { return x; }
+#else
+__device__ __forceinline__ int launder_s(int x) { x = __builtin_amdgcn_readfirstlane(x); asm("" : "+s"(x)); return x; }
+__device__ __forceinline__ int launder_v(int x) { asm("" : "+v"(x)); return x; }
+#endif
 // All-reduce over the 16 lanes of a DPP row (lanes j = 0..15 of one lane group q) with data-parallel-primitive operands: xor 1, xor 2 inside the quads,
 // then row_half_mirror and row_mirror -- four VALU instructions with the cross-lane move folded in, instead of four ds_bpermute round trips through
 // the LDS crossbar (address VALU + LDS instruction + wait each), which is what __shfl_xor compiles to.
@@ -280,6 +289,20 @@ __device__ __forceinline__ void taps_issue(const QArgs &a, int b, int mi, int co
 }
 #define TAPSUM_(c_, w_) __builtin_fmaf(se.c_, (w_)[3], __builtin_fmaf(sw.c_, (w_)[2], __builtin_fmaf(ne.c_, (w_)[1], nw.c_ * (w_)[0])))
 // blend the taps to (scaled) features, split, and store into the K-block-major chunk planes [4 kb][64 pt][8 halves] (forward) ...
+// Layout of a chunk's operand planes.  K-block major ([4 kb][64 pt][8 halves], PM = false: what the hidden-activation planes use) makes the STORES of this function a
+// 4-way bank conflict: ds_write_b64 is serviced in groups of 16 consecutive lanes on 32 banks (MI355X_MICROARCH.md, LDS), a group here is 2 points x 8 pieces, and the
+// four K blocks of a point sit 1 KB apart -- the same banks (round 5's counters: SQ_LDS_BANK_CONFLICT = 24 % of the LDS-active cycles; this store is the largest share).
+// PM = true (round 6, -DCHUNK_PM=1): POINT major, [64 pt][4 slots of 8 halves], a point's K block q in slot q ^ m(q) ^ ((pt >> 2) & 3), m = {0, 3, 1, 2}:
+// a group's 16 lanes now write 128 contiguous bytes (conflict-free), and the fragment reads (ds_read_b128: four groups {0-3, 12-15, 20-27}, ... on 64 banks) stay
+// conflict-free because the Latin square puts the 16 lanes of every group on 16 different 16-byte slots of the 256-byte bank row (chunk_slot / k32_step_chunk).
+__device__ __forceinline__ int chunk_slot(int pt, int q) { return pt * 4 + (((pt >> 2) & 3) ^ ((0x2130 >> (4 * q)) & 3)); }       // uint4 index inside a plane
+// MEASURED (round 6, same box, bit-identical results): PM = true is 0.3 % (two-head kernel) / 1.2 % (one-head kernels) SLOWER than the conflicted layout -- the LDS
+// array is 35 % busy in these kernels, the conflicts cost LDS cycles nobody was waiting for, and the swizzled addresses cost a few VALU and a different schedule
+// (profiles/r06_query_ab.txt).  The conflict-free form stays as a switch (-DCHUNK_PM=1) with the explanation of the counter; the default is the old layout.
+#ifndef CHUNK_PM
+#define CHUNK_PM 0
+#endif
+template <bool PM = false>
 __device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> &g, uint2 *hi8, uint2 *lo8, int tid, float &rmax)
 {
     const int sub = tid & 7, pp = tid >> 3;
@@ -289,7 +312,7 @@ __device__ __forceinline__ void taps_store_feat(const Taps &r, const TapGeom<1> 
         const float *w = g.c[0][pass];
         uint2 hi, lo;
         split4(TAPSUM_(x, w), TAPSUM_(y, w), TAPSUM_(z, w), TAPSUM_(w, w), hi, lo, rmax);
-        const int idx = (((sub >> 1) * 64 + pp + 32 * pass) << 1) + (sub & 1);
+        const int idx = PM ? (chunk_slot(pp + 32 * pass, sub >> 1) << 1) + (sub & 1) : (((sub >> 1) * 64 + pp + 32 * pass) << 1) + (sub & 1);
         hi8[idx] = hi; lo8[idx] = lo;
     }
 }
@@ -341,6 +364,26 @@ __device__ __forceinline__ void k32_step(Acc8 &c, const uint4 (&w)[2][2], const 
     h8 xh[4], xl[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[(kb_base + q) * 64 + 16 * p + j]); xl[p] = as_h8(Xlo[(kb_base + q) * 64 + 16 * p + j]); }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xh[p], c.v[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][0]), xl[p], c.v[nt][p]);
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) c.v[nt][p] = MFMAH(as_h8(w[nt][1]), xh[p], c.v[nt][p]);
+}
+// the same K32 step on a chunk's POINT-major planes (taps_store_feat<true>)
+__device__ __forceinline__ void k32_step_chunk(Acc8 &c, const uint4 (&w)[2][2], const uint4 *Xhi, const uint4 *Xlo, int lane)
+{
+    const int q = lane >> 4, j = lane & 15;
+    h8 xh[4], xl[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { xh[p] = as_h8(Xhi[chunk_slot(16 * p + j, q)]); xl[p] = as_h8(Xlo[chunk_slot(16 * p + j, q)]); }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
@@ -651,7 +694,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     float *sGeo = reinterpret_cast<float *>(sOvf + 4);       // [2 slots][64 points][GEO_STRIDE] tap geometry of a map, shared by the workgroup
     float rmax = 0.f;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+    // (the wave index through readfirstlane: a branch on `wave` is then a SCALAR branch and what is computed behind it from uniform inputs -- map indices,
+    //  table addresses, resolutions -- stays in SGPRs instead of being carried, and spilled, in VGPRs: round 6, profiles/r06_kernel_resources.txt)
+    const int tid_raw = threadIdx.x, tid = tid_raw, wave = (G == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, q = lane >> 4, j = lane & 15;
     // XCD-aware block -> (frame, tile) map: the dispatcher places workgroup L on XCD L % 8 (speed only, never correctness), so
     // give every XCD whole frames: all ~108 tiles of a frame then gather from the same few MB of maps through ONE L2.
     int b, tile;
@@ -679,6 +724,10 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         px = a.crop / 2 + px - a.crop_center[2 * b]; py = a.crop / 2 + py - a.crop_center[2 * b + 1];
         const float nx = 2 * px / a.crop - 1, ny = 2 * py / a.crop - 1;
         sIn[tid] = (pn << 1) | (int)((nx >= -1.0f) && (nx <= 1.0f) && (ny >= -1.0f) && (ny <= 1.0f));     // point index | in-image flag
+        // a non-finite coordinate makes every feature of the point NaN; the ReLUs of the hidden epilogues are integer / packed-f16 maxima that send a NaN with
+        // the sign bit set to 0 and the range tracker (v_max3_f32) ignores NaNs, so such a point could come out FINITE and wrong: the whole tile is
+        // made loud instead (NaN outputs through *sOvf, like an operand beyond the split range).  Maps are finite by the caller's contract (the encoders' output).
+        if (!(fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY)) *sOvf = 1;
         const float c0 = x - a.body_center[3 * b], c1 = y - a.body_center[3 * b + 1], c2 = z - a.body_center[3 * b + 2];
         sPt[tid * 3] = x; sPt[tid * 3 + 1] = y; sPt[tid * 3 + 2] = z;
         sUV[(0 * 64 + tid) * 2] = nx;  sUV[(0 * 64 + tid) * 2 + 1] = ny;   // perspective
@@ -766,16 +815,20 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     LOAD_W1(C0)
     // software pipeline: the features of chunk ci+1 are blended / split / stored (VALU + LDS stores) in the same barrier interval
     // as the MFMAs of chunk ci, so the two interleave; the taps of chunk ci+2 are requested as soon as the tap registers are free
-    taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512), reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512 + 256), tid, rmax);
+    taps_store_feat<CHUNK_PM != 0>(tp, tg, reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512), reinterpret_cast<uint2 *>(lds + (C0 & 1) * 512 + 256), tid, rmax);
     { int mi, co; chunk_info(C0 + 1, mi, co); taps_issue(a, b, mi, co, tg, tp); }      // the first map of the loop (im_feat or tmpx) has >= 2 chunks: same geometry
     for (int ci = C0; ci < NCHUNK; ci++) {
         uint4 *buf = lds + (ci & 1) * 512, *nbuf = lds + ((ci + 1) & 1) * 512;      // {hi [4 kb][64], lo [4 kb][64]}
         __syncthreads();                        // chunk ci visible; the other buffer's readers (MFMAs of chunk ci-1) are done
 #pragma unroll
+#if CHUNK_PM
+        for (int g = 0; g < G; g++) k32_step_chunk(acc1[g], wf[g], buf, buf + 256, lane);
+#else
         for (int g = 0; g < G; g++) k32_step(acc1[g], wf[g], buf, buf + 256, 0, lane);
+#endif
         // vmcnt retires loads IN ORDER: the weight fragments of the next chunk are requested BEFORE the taps of chunk ci+2, so that
         // waiting for them (top of the next iteration) does not also wait for the far slower gather
-        if (ci + 1 < NCHUNK) taps_store_feat(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid, rmax);
+        if (ci + 1 < NCHUNK) taps_store_feat<CHUNK_PM != 0>(tp, tg, reinterpret_cast<uint2 *>(nbuf), reinterpret_cast<uint2 *>(nbuf + 256), tid, rmax);
         LOAD_W1(ci + 1)
         if (ci + 2 < NCHUNK) {
             int mi, co; chunk_info(ci + 2, mi, co);
@@ -1174,6 +1227,10 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
 
     // ---- backward through layer 1 and the gathers: wave w owns the 16 points of tile w (one point per lane column j);
     //      d feat[c][pt] = sum_g inv[g][pt] / s_W1[g] * ( W1[g][u][c] . dh1'[g][u][pt] ),  c = the chunk's 32 channels
+    // (the lane-derived indices of this half of the kernel are re-derived from a laundered thread id -- see launder_v: the forward half's copies and every LDS
+    //  address built on them would otherwise stay live across the hidden layers, where the register file is full)
+    const int tid_l1b = launder_v(tid_raw);
+    { const int tid = tid_l1b, wave = (G == 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6), lane = tid & 63, q = lane >> 4, j = lane & 15;
     uint4 dh[G][4][2];      // B fragments of d(hidden-1): point 16 wave + j, hidden units 32 s + 8 q + t
     float kscale[G];
 #pragma unroll
@@ -1195,11 +1252,14 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         // forward blend -- thread = (point, 8-column block group): the four lanes of a point are adjacent and read 128 contiguous bytes of a row
         // per pair of instructions -- with d(hidden-1) taken straight from the operand planes (hi + lo), which are [k block][point] already.
         // Lane 4 j' + seg of wave w works on point 16 w + j': the owner lane (q = 0, j = j') of the SAME wave picks the sums up with one shuffle.
-        const int R = a.res[0];
-        const rsrc_t Pb = make_rsrc(a.proj + (size_t)b * R * R * a.pw, (unsigned)(R * R * a.pw) * 4u);
-        const int spt = tid >> 2, seg = tid & 3;
+        // (the inputs of this phase's address arithmetic go through launder(): the forward blend computed the same resolution-derived floats, LDS addresses and the
+        //  64-bit row base from them a whole kernel ago, and hipcc kept those alive -- in scratch, at 256 / 168 VGPRs -- rather than recompute a handful of
+        //  integer instructions: 44 B per lane of spills, 117 MB of scratch writes per launch in round 5)
+        const int R = launder_s(a.res[0]), pw_ = launder_s(a.pw), b_ = launder_s(b), tid_ = tid;
+        const rsrc_t Pb = make_rsrc(a.proj + (size_t)b_ * R * R * pw_, (unsigned)(R * R * pw_) * 4u);
+        const int spt = tid_ >> 2, seg = tid_ & 3;
         unsigned o[4]; float cu[4], cv[4];
-        proj_geom(sUV, spt, R, a.pw, o, cu, cv, true);
+        proj_geom(sUV, spt, R, pw_, o, cu, cv, true);
 #pragma unroll
         for (int k = 0; k < 4; k++) o[k] = (o[k] + 8u * seg) * 4u;             // byte offset of this thread's first 8-column block in tap row k
         float dot[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1474,6 +1534,7 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         __syncthreads();
         if (tid == 0) atomicAdd(a.term_accel, (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / ((double)(a.B - 2) * (double)a.N * 3.0));
     }
+    }       // (scope of the re-derived lane indices)
 }
 
 

@@ -139,11 +139,40 @@ __device__ __forceinline__ bool sil_inside(const float (&fc)[9], float xp, float
              ((yp - fc[7]) * (fc[0] - fc[6]) < (xp - fc[6]) * (fc[1] - fc[7])));
 }
 // depth of a covered pixel (neural_renderer's barycentric formula, division for division) and the visibility vote
+// Round 6: the ten IEEE divisions only where they can decide something.  The depth of a covered pixel is used for ONE thing -- which face owns the pixel
+// (atomicMin on the depth bits; the owner steers the backward's sweeps) -- and for the near / far test.  Two faces that both cover a pixel centre are either
+// separate depth layers of the object (centimetres apart: an approximate depth, relative error ~1e-6, orders them like the exact one) or neighbours meeting in a
+// shared edge the centre lies on -- then the centre is on the rim of BOTH, i.e. one of its barycentric weights is ~0 in both.  So: pixels whose smallest weight
+// is above SIL_RIM (1/64: >= 0.05 px inside every edge, where the depths of two faces folded over a common edge already differ by >= 1e-5 m) take reciprocal
+// multiplies (v_rcp_f32, 1 ulp); pixels on the rim keep neural_renderer's formula division for division, bit for bit the oracle's.  Images and owner maps stay
+// identical to the oracle's (tests/test_gpu_parity.py: 96 poses at bench size, every pixel's owner).
+#ifndef SIL_FAST_Z
+#define SIL_FAST_Z 1
+#endif
+#define SIL_RIM 0.015625f
 __device__ __forceinline__ void sil_vote(const float (&fc)[9], float den, int f2, float xp, float yp, int xi, int yi, int is, unsigned long long *__restrict__ zrow)
 {
-    float w0 = ((fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4])) / den;
-    float w1 = ((fc[7] - fc[1]) * xp + (fc[0] - fc[6]) * yp + (fc[6] * fc[1] - fc[0] * fc[7])) / den;
-    float w2 = ((fc[1] - fc[4]) * xp + (fc[3] - fc[0]) * yp + (fc[0] * fc[4] - fc[3] * fc[1])) / den;
+    const float n0 = (fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4]);
+    const float n1 = (fc[7] - fc[1]) * xp + (fc[0] - fc[6]) * yp + (fc[6] * fc[1] - fc[0] * fc[7]);
+    const float n2 = (fc[1] - fc[4]) * xp + (fc[3] - fc[0]) * yp + (fc[0] * fc[4] - fc[3] * fc[1]);
+#if SIL_FAST_Z
+    {
+        const float rden = __builtin_amdgcn_rcpf(den);
+        const float a0 = n0 * rden, a1 = n1 * rden, a2 = n2 * rden;
+        if (fminf(a0, fminf(a1, a2)) > SIL_RIM && fmaxf(a0, fmaxf(a1, a2)) < 1.0f - SIL_RIM) {
+            // (inside the rim no weight is clamped) zp = 1 / sum_k (w_k / ws) / z_k = ws / sum_k w_k / z_k
+            const float ws_ = a0 + a1 + a2;
+            const float zp_ = ws_ * __builtin_amdgcn_rcpf(a0 * __builtin_amdgcn_rcpf(fc[2]) + a1 * __builtin_amdgcn_rcpf(fc[5]) + a2 * __builtin_amdgcn_rcpf(fc[8]));
+            if (!(zp_ > SIL_NEAR * 1.001f && zp_ < SIL_FAR * 0.999f)) goto exact;            // (at the clipping planes the exact value decides)
+            atomicMin(zrow + (size_t)yi * is + xi, ((unsigned long long)__float_as_uint(zp_) << 32) | (unsigned)f2);
+            return;
+        }
+    }
+exact:
+#endif
+    float w0 = n0 / den;
+    float w1 = n1 / den;
+    float w2 = n2 / den;
     w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
     const float ws = w0 + w1 + w2;
     const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);

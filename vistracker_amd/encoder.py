@@ -354,10 +354,11 @@ class SIFNetEncoder:
                 maps, graph_done = self._chunk_graph(x)
             else:
                 maps = self._chunk_eager(x)
-            if out is None:
-                # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from; written per chunk
-                out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}
             try:
+                if out is None:
+                    # channels-last NCHW tensors are NHWC in memory: the permuted views are what the query kernel gathers from; written per chunk.
+                    # (Inside the try: _chunk_graph returned with the graph lock HELD, an allocation failure here must release it -- ADVICE r05.)
+                    out = {k: torch.empty(B, m.shape[2], m.shape[3], m.shape[1], device=m.device) for k, m in maps.items()}
                 for k, m in maps.items():
                     out[k][s0:s0 + n] = m[:n].permute(0, 2, 3, 1)
             finally:
