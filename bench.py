@@ -163,6 +163,9 @@ def fit_batch(ctx, torch, d, prof=None, early_stop=True, obj_stream=None):
     return r1, r2
 
 
+SOLO_CLOCK = {}        # filled by solo_kernel_leg: the shader clock sustained during the split-f16 solo launches
+
+
 def solo_kernel_leg(ctx, torch, d, launches=20, fp32=False):
     """The dominant kernel ALONE on the chip: `launches` back-to-back launches of vt_query_human_loss on one stream (what a single-stream
     rocprofv3 kernel trace shows as its average duration), timed with HIP events on the launch stream, outside the timed region.
@@ -185,13 +188,25 @@ def solo_kernel_leg(ctx, torch, d, launches=20, fp32=False):
                                                        ctx.labels.data_ptr(), order.data_ptr(), 50.0, 0.00125, dv.data_ptr(), terms.data_ptr(), L.stream_ptr()))
     for _ in range(3):
         call()
+    # the shader clock the chip sustains DURING these launches, sampled by the kernel itself (vt_query_set_clock_probe: every 1024th workgroup adds its life time
+    # in shader clocks and in 100 MHz ticks): launch time x clock = the launch in SHADER CLOCKS, the figure that does not depend on the box or its thermal state
+    probe = torch.zeros(3, dtype=torch.int64, device=verts.device)
+    if not fp32:
+        torch.cuda.synchronize(); L.check(L.lib().vt_query_set_clock_probe(probe.data_ptr()))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
-    ev[0].record()
-    for i in range(launches):
-        call(); ev[i + 1].record()
-    torch.cuda.synchronize()
+    try:
+        ev[0].record()
+        for i in range(launches):
+            call(); ev[i + 1].record()
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.lib().vt_query_set_clock_probe(None))
     d["maps"].set_force_fp32(was_fp32)
-    return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
+    solo = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(launches)])) * 1e-3
+    pc = probe.cpu().numpy()
+    if not fp32 and pc[1] > 0:
+        SOLO_CLOCK["mhz"] = float(pc[0]) / float(pc[1]) * 100.0; SOLO_CLOCK["samples"] = int(pc[2])
+    return solo
 
 
 # Box calibration.  Reference values: the box of profiles/r06_calibration_reference.txt, on which round 5's kernel (the library of commit
@@ -852,6 +867,9 @@ def main():
                          "frac_single_stream": None if solo is None else flops_h / solo / 1e12 / PEAK_SPLIT_TFLOPS,
                          # box calibration right before / after the solo launches: what THIS box's matrix pipe, clock and L2 path deliver, so that the solo time
                          # can be read as kernel x box (boxes of the pool differ by +-4 %); *_at_reference_box = solo time rescaled by the MFMA rate ratio
+                         # ... and the launch in shader clocks: solo time x the clock the kernel itself saw (every 1024th workgroup samples s_memtime / s_memrealtime)
+                         "solo_sustained_mhz": SOLO_CLOCK.get("mhz"), "solo_clock_samples": SOLO_CLOCK.get("samples"),
+                         "solo_launch_Mclk": None if (solo is None or not SOLO_CLOCK.get("mhz")) else solo * SOLO_CLOCK["mhz"],
                          "calibration": calib_summary(extras, None if solo is None else 1e3 * solo),
                          "frac_union": (flops_all / busy_union / 1e12 / PEAK_SPLIT_TFLOPS) if busy_union > 0 else None,
                          "achieved_note": "algorithmic FLOPs of all launches / the kernel's share of the time in which it was executing: per-launch HIP events of both "

@@ -411,6 +411,13 @@ int vt_sil_setup(const float *mask_h, const float *mask_o, int B, int H, int W, 
 int vt_sil_mask_loss(const float *image, const float *keep, const float *ref, const float *occ, int B, int size,
                      float gscale, double *term, float *per_frame, float *d_image, void *stream);
 
+/* The silhouette term of ONE Adam step of phase 'sil' (recon_fit_trivis_full.py:164-168, 329-375; SilLossROI.forward, obj_pose_roi.py:183-207, and its backward):
+ * vt_sil_forward + vt_sil_mask_loss + vt_sil_backward as 5 launches instead of 10 -- the same arithmetic, operation for operation (owner map, d_image, vertex
+ * gradients bit-identical; *term += mean_b(sum_px (keep sil - ref)^2 occ[b]) accumulated in 2^-34 fixed point, frame order).  face_index, d_image: (B,size,size)
+ * outputs; dverts (B,NV,3); ws: vt_sil_workspace_floats(B,NV,NF,size) floats. */
+int vt_sil_step(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, const float *keep, const float *ref,
+                const float *occ, float gscale, float eps, double *term, int *face_index, float *d_image, float *ws, float *dverts, void *stream);
+
 /* Triplane masks of the SMPL mesh.  Replaces TriplaneNrRenderer.render_3views
  * (render/render_triplane_nr.py:86-139): the mesh centred on `center` (B,3) (the SMPL centre, body25 joint 8) is rendered
  * orthographically from the right (x' = z, y' = -y, depth -x + 10), the back (-x, -y, -z + 10) and the top (x, z, y + 10);
@@ -489,6 +496,10 @@ int vt_gen_resample(const float *samples, const int *order, const long long *cnt
  * workgroups of 256 threads per CU, non-trivial operands), out[1] = shader clock sustained during it (MHz: s_memtime against the 100 MHz s_memrealtime),
  * out[2] = L2 -> register delivery of lane-linear 16-byte loads (TB/s), out[3], out[4] = their durations in ms.  `work`: vt_calibrate_workspace_bytes() bytes
  * of device memory.  Synchronises `stream`; ~25 ms. */
+/* clock probe of the fused-objective query kernels (measurement only): while `counters` (3 device-side 64-bit words, zeroed by the caller) is set, every 1024th
+ * workgroup of every vt_query_* launch adds its life time in shader clocks, in 100 MHz ticks, and 1 -- counters[0] / counters[1] x 100 = the shader clock in MHz the
+ * chip sustained DURING those launches.  NULL switches it off (the default). */
+int vt_query_set_clock_probe(unsigned long long *counters);
 long vt_calibrate_workspace_bytes(void);
 int vt_calibrate(void *work, double *out, void *stream);
 

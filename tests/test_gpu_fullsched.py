@@ -209,18 +209,25 @@ def run_smpl_stage_three_ways(synth, c, fm, mp, with_oracle64=True):
         out[tag] = (r, ops.smplh_forward(ctx.smpl, p, b_, t)[0].cpu().numpy())
     m64 = O64.SmplModel(model)
     run32 = lambda: oracle_optimize_smpl(c["m"], c["b25"], pri, O.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"])
-    if with_oracle64:
-        (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(run32,
-            lambda: oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"], O=O64))
+    run64 = lambda: oracle_optimize_smpl(m64, O64.Landmarks(regs["body25"]), pri, O64.SifNet(c["dec"], mp), labels, c["pose0"], c["betas0"], c["trans0"], c["cc"], c["bc"], c["kp"], O=O64)
+    res, vh = out["hip"]
+    if with_oracle64 == "lazy":
+        # the fp64 arbiter is the escape hatch for a HIP result that is NOT within the bar of the fp32 oracle by itself: when HIP and oracle32 end 10 x inside the
+        # bar (< 1e-4 m) the arbiter has nothing to decide and its run -- three times the fp32 oracle's minutes at bench size -- is skipped (VT_TEST_ARBITER=1 forces it)
+        import os
+        pose, betas, trans, losses, stopped = run32()
+        with_oracle64 = bool(os.environ.get("VT_TEST_ARBITER")) or not (v2v(vh, c["m"].forward(pose, betas, trans)[0])[0] < 1e-4)
+        p64, b64, t64, l64, _ = run64() if with_oracle64 else (pose, betas, trans, losses, None)
+    elif with_oracle64:
+        (pose, betas, trans, losses, stopped), (p64, b64, t64, l64, _) = both(run32, run64)
     else:
         pose, betas, trans, losses, stopped = run32(); p64, b64, t64, l64 = pose, betas, trans, losses
     v32 = c["m"].forward(pose, betas, trans)[0]; v64 = m64.forward(p64, b64, t64)[0] if with_oracle64 else v32
-    res, vh = out["hip"]
     v_start = c["m"].forward(c["pose0"], c["betas0"], c["trans0"])[0]
     n = min(res.steps, len(losses))
     faces = np.asarray(model["f"])
     a0 = (v_start[2:] - v_start[1:-1]) - (v_start[1:-1] - v_start[:-2]) if B >= 3 else np.zeros(1)
-    rep = dict(frames=B, stemp_live=bool(B >= 4), stemp_value_at_start=float((a0.astype(np.float64) ** 2).mean()) if B >= 4 else 0.0,
+    rep = dict(frames=B, oracle64_run=bool(with_oracle64), stemp_live=bool(B >= 4), stemp_value_at_start=float((a0.astype(np.float64) ** 2).mean()) if B >= 4 else 0.0,
                stemp_effect_mean=v2v(vh, out["no_stemp"][1])[0], steps_hip_without_stemp=out["no_stemp"][0].steps)
     rep.update(steps_hip=res.steps, steps_oracle32=len(losses), steps_oracle64=len(l64), stopped=bool(res.stopped_early and stopped),
                loss_history_rel=rel(res.losses[:n], losses[:n]), hip_vs_oracle32_mean=v2v(vh, v32)[0], hip_vs_oracle32_max=v2v(vh, v32)[1],

@@ -162,7 +162,8 @@ def test_full_schedule_at_bench_size(synth):
     frame), B = 4 frames (temporal terms live) -- from the start to the reference's stop rules (recon_fit_behave.py:393-465, recon_fit_trivis_full.py:272-377), HIP against the fp32
     oracle AND the fp64 arbiter on the well-conditioned fixtures (synthetic.body_bowl_decoders / bowl_decoders).  Bar: the north star's, strictly -- v2v mean
     < 1e-3 m and the reference's own Chamfer metric (recon/eval/chamfer_distance.py:43-48: both directions summed) < 1e-3 m.  (tools/fullsize_parity.py is the
-    B = 8 measurement script this test grew out of; profiles/r05_fullsize_parity.json holds its numbers incl. the random-weight field.)"""
+    B = 8 measurement script this test grew out of: profiles/r04_fullsize_parity.json holds its numbers incl. the random-weight field; this test's own numbers
+    of the round are committed as profiles/r06_fullsched_parity.json.)"""
     import test_gpu_fullsched as FS
     from fit_oracle import oracle_optimize_object
     from oracle import oracle as O, oracle64 as O64
@@ -188,9 +189,9 @@ def test_full_schedule_at_bench_size(synth):
     kw = dict(iter_for_obj=15, iter_for_sil=0, joint_iter=10, max_iter=100)
     noise = np.random.default_rng(23).uniform(0, 1, (1250, B, 3, 3)).astype(np.float32)
     run_o = lambda Om: oracle_optimize_object(Om.SifNet(decb, mp), pts, R0, t0_, sc, noise, c["cc"], c["bc"], occ, sverts, labels, sil=None, O=Om, **kw)
-    pool = ThreadPoolExecutor(2); fut32, fut64 = pool.submit(run_o, O), pool.submit(run_o, O64)
-    # ---- SMPL stage
-    rep = FS.run_smpl_stage_three_ways(synth, c, fm, mp)
+    pool = ThreadPoolExecutor(2); fut32 = pool.submit(run_o, O)
+    # ---- SMPL stage (fp64 arbiter only when HIP is not already 10 x inside the bar of the fp32 oracle, or with VT_TEST_ARBITER=1: run_smpl_stage_three_ways)
+    rep = FS.run_smpl_stage_three_ways(synth, c, fm, mp, with_oracle64="lazy")
     FS._report("bench_size_smpl_stage_body_bowl", **rep)
     print("bench-size SMPL stage:", rep)
     FS.assert_strict_smpl_stage(rep)
@@ -202,12 +203,17 @@ def test_full_schedule_at_bench_size(synth):
         R, t, s = cu(R0.copy()), cu(t0_ + np.float32(dt)), torch.ones(B, device="cuda")
         r = ctxb.optimize_smpl_object(fm, cu(sverts), R, t, s, cu(c["cc"]), cu(c["bc"]), cu(occ), noise=cu(noise), **kw)
         outs[tag] = (O.rigid(pts, O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc), r, O.rigid(ov.astype(np.float32), O.so3_project(R.cpu().numpy()), t.cpu().numpy(), sc))
-    (Ro, to, ls, st, hc), (R64, t64, l64, _, _) = fut32.result(), fut64.result(); pool.shutdown()
-    X32 = O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc); X64 = O.rigid(pts, O.so3_project(R64.astype(np.float32)), t64.astype(np.float32), sc)
+    Ro, to, ls, st, hc = fut32.result()
+    X32 = O.rigid(pts, O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc)
+    import os
+    need64 = bool(os.environ.get("VT_TEST_ARBITER")) or not (FS.v2v(outs["hip"][0], X32)[0] < 1e-4)
+    R64, t64, l64, _, _ = run_o(O64) if need64 else (Ro, to, ls, st, hc)
+    pool.shutdown()
+    X64 = O.rigid(pts, O.so3_project(R64.astype(np.float32)), t64.astype(np.float32), sc)
     M32 = O.rigid(ov.astype(np.float32), O.so3_project(Ro.astype(np.float32)), to.astype(np.float32), sc)
     Xh, rh, Mh = outs["hip"]
     n = min(rh.steps, len(ls))
-    repo = dict(steps_hip=rh.steps, steps_oracle32=len(ls), steps_oracle64=len(l64), had_contacts=bool(hc), loss_history_rel=rel(rh.losses[:n], np.array(ls)[:n]),
+    repo = dict(oracle64_run=need64, steps_hip=rh.steps, steps_oracle32=len(ls), steps_oracle64=len(l64), had_contacts=bool(hc), loss_history_rel=rel(rh.losses[:n], np.array(ls)[:n]),
                 hip_vs_oracle32_mean=FS.v2v(Xh, X32)[0], hip_vs_oracle32_max=FS.v2v(Xh, X32)[1], hip_vs_oracle64_mean=FS.v2v(Xh, X64)[0],
                 oracle32_vs_oracle64_mean=FS.v2v(X32, X64)[0], hip_self_1e6_mean=FS.v2v(Xh, outs["self"][0])[0],
                 chamfer_template_mesh_hip_vs_oracle32_mean_max=FS.chamfer_ref_metric(Mh, M32, of))

@@ -436,6 +436,42 @@ def test_silhouette_per_call_at_bench_size(hip):
         f"per-frame gradient cosine min {cos.min():.6f}; relative max error median {np.median(relf):.2e}, worst frame {relf.max():.2e}"
 
 
+def test_sil_step_equals_the_separate_launches(hip):
+    """vt_sil_step (5 launches) against vt_sil_forward + vt_sil_mask_loss + vt_sil_backward (10 launches): owner map, d_image and vertex gradients bit for bit,
+    the mask term to the last bits of its fp64 sum; a second call on the same workspace (the accumulators of the step are re-zeroed by its first launch) repeats it."""
+    from vistracker_amd import _lib as L
+    B = 6
+    verts, faces, K = _sil_case(B, seed=12)
+    NV, NF = verts.shape[1], faces.shape[0]
+    rng = np.random.default_rng(3)
+    from oracle import oracle as O
+    ref = np.roll(O.sil_forward(verts, faces, K, 256), (4, -3), axis=(1, 2)).astype(np.float32)
+    keep = np.ones_like(ref); keep[:, 90:150, :70] = 0; ref = ref * keep
+    occ = rng.uniform(0.3, 1.0, B).astype(np.float32)
+    v, f, k, kp, rf, oc = cu(verts), cu(faces), cu(K), cu(keep), cu(ref), cu(occ)
+    lib = L.lib(); st = L.stream_ptr(); gscale = 0.0009 / 3
+    n_ws = lib.vt_sil_workspace_floats(B, NV, NF, 256)
+
+    def separate():
+        img = torch.empty(B, 256, 256, device="cuda"); fidx = torch.empty(B, 256, 256, dtype=torch.int32, device="cuda"); dimg = torch.empty_like(img)
+        ws = torch.full((n_ws,), float("nan"), device="cuda"); dv = torch.empty_like(v); term = torch.zeros(1, dtype=torch.float64, device="cuda"); per = torch.empty(B, device="cuda")
+        L.check(lib.vt_sil_forward(L.dptr(v), B, NV, L.dptr(f), NF, L.dptr(k), 256, L.dptr(img), L.dptr(fidx), L.dptr(ws), st))
+        L.check(lib.vt_sil_mask_loss(L.dptr(img), L.dptr(kp), L.dptr(rf), L.dptr(oc), B, 256, gscale, term.data_ptr(), L.dptr(per), L.dptr(dimg), st))
+        L.check(lib.vt_sil_backward(L.dptr(v), B, NV, L.dptr(f), NF, L.dptr(k), 256, L.dptr(fidx), L.dptr(dimg), 1e-4, L.dptr(ws), L.dptr(dv), st))
+        return npy(fidx), npy(dimg), npy(dv), float(term.item())
+    a = separate()
+    fidx = torch.empty(B, 256, 256, dtype=torch.int32, device="cuda"); dimg = torch.empty(B, 256, 256, device="cuda")
+    ws = torch.full((n_ws,), float("nan"), device="cuda")          # (poisoned: the call must not depend on what the workspace held)
+    for rep in range(2):
+        dv = torch.full_like(v, float("nan")); term = torch.zeros(1, dtype=torch.float64, device="cuda")
+        L.check(lib.vt_sil_step(L.dptr(v), B, NV, L.dptr(f), NF, L.dptr(k), 256, L.dptr(kp), L.dptr(rf), L.dptr(oc), gscale, 1e-4, term.data_ptr(), L.dptr(fidx), L.dptr(dimg),
+                                L.dptr(ws), L.dptr(dv), st))
+        b = (npy(fidx), npy(dimg), npy(dv), float(term.item()))
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), rep
+        assert np.array_equal(a[2], b[2]), (rep, float(np.abs(a[2] - b[2]).max()))
+        assert a[3] > 0 and abs(a[3] - b[3]) <= 1e-13 * a[3], (a[3], b[3])
+
+
 def test_adam(hip):
     g = golden("adam"); ops = hip["ops"]
     p = cu(g["p0"].copy()); opt = ops.FusedAdam([p], lr=float(g["lr"]))

@@ -31,12 +31,17 @@ v0 = pts[B // 2]; order = morton_order_device(torch.stack([v0[:, 0] / v0[:, 2], 
 rng = np.random.default_rng(3); op = rng.normal(0, 0.25, (3000, 3)).astype(np.float32); op = op[morton_order(op)]
 opts = (t(op)[None] + bc[:, None, :]).contiguous(); occ = torch.rand(B, device=dev, generator=g)
 res = {}
+CLK = {}
 def timeit(run):
     run(); torch.cuda.synchronize()
     for _ in range(3): run()
+    probe = torch.zeros(3, dtype=torch.int64, device=dev); has = hasattr(L.lib(), "vt_query_set_clock_probe")
+    if has: torch.cuda.synchronize(); L.lib().vt_query_set_clock_probe(C.c_void_p(probe.data_ptr()))
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
+    if has: L.lib().vt_query_set_clock_probe(None)
+    pc = probe.cpu().numpy(); CLK["mhz"] = float(pc[0]) / float(pc[1]) * 100 if pc[1] > 0 else float("nan")
     return e0.elapsed_time(e1) / reps
 dp = torch.empty(B, N, 3, device=dev); terms = torch.zeros(2, dtype=torch.float64, device=dev)
 def run_h():
@@ -44,11 +49,11 @@ def run_h():
                                         100.0, 0.0025, dp.data_ptr(), terms.data_ptr(), L.stream_ptr()))
 ms = timeit(run_h); dp.fill_(float("nan")); terms.zero_(); run_h(); torch.cuda.synchronize()
 res.update(human_ms=ms, human_dp=dp.cpu().numpy(), human_terms=terms.cpu().numpy())
-print(f"human kernel: {ms:.4f} ms/launch = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; finite {bool(torch.isfinite(dp).all())}")
+print(f"human kernel: {ms:.4f} ms/launch = {0.59265024 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; sustained {CLK['mhz']:.0f} MHz -> {ms * CLK['mhz'] * 1e-3:.3f} Mclk/launch; finite {bool(torch.isfinite(dp).all())}")
 dpo = torch.empty(B, 3000, 3, device=dev)
 def run_o():
     L.check(L.lib().vt_query_object_loss(net.h, C.byref(fm.c), opts.data_ptr(), cc.data_ptr(), bc.data_ptr(), B, 3000, occ.data_ptr(), 900.0, dpo.data_ptr(), terms.data_ptr(), L.stream_ptr()))
 ms = timeit(run_o); dpo.fill_(float("nan")); terms.zero_(); run_o(); torch.cuda.synchronize()
 res.update(object_ms=ms, object_dp=dpo.cpu().numpy(), object_terms=terms.cpu().numpy())
-print(f"object kernel: {ms:.4f} ms/launch = {0.128 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; finite {bool(torch.isfinite(dpo).all())}")
+print(f"object kernel: {ms:.4f} ms/launch = {0.128 / ms * 1e3 / 838.87:.3f} of the split-f16 roof; sustained {CLK['mhz']:.0f} MHz -> {ms * CLK['mhz'] * 1e-3:.3f} Mclk/launch; finite {bool(torch.isfinite(dpo).all())}")
 np.savez(out, **res)

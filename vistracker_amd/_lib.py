@@ -108,6 +108,7 @@ SIGNATURES = {
     "vt_sil_forward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, vp]),
     "vt_sil_backward": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, cf, fp, fp, vp]),
     "vt_sil_mask_loss": (ci, [fp, fp, fp, fp, ci, ci, cf, fp, fp, fp, vp]),
+    "vt_sil_step": (ci, [fp, ci, ci, fp, ci, fp, ci, fp, fp, fp, cf, cf, fp, fp, fp, fp, fp, vp]),
     "vt_gen_round_compact": (ci, [fp, fp, fp, vp, ci, ci, cf, cf, vp, ci, ci, fp, vp, fp, vp, vp, vp]),
     "vt_gen_scatter_heads": (ci, [fp, ci, ci, ci, vp, vp, ci, fp, vp]),
     "vt_gen_resample": (ci, [fp, vp, vp, fp, ci, ci, ci, fp, fp, ci, cf, fp, vp]),
@@ -117,6 +118,7 @@ SIGNATURES = {
     "vt_loss_reduce_and_stop": (ci, [fp, vp, ci, cf, ci, fp, fp, fp, ci, vp]),
     "vt_fill": (ci, [fp, cl, cf, vp]),
     "vt_selftest_mfma": (ci, [fp, fp, fp, vp]),
+    "vt_query_set_clock_probe": (ci, [vp]),
     "vt_calibrate_workspace_bytes": (cl, []),
     "vt_calibrate": (ci, [vp, C.POINTER(C.c_double), vp]),
 }

@@ -103,6 +103,8 @@ struct QArgs {
     // surface projection step (MODE_PROJECT): w0 = clamp threshold
     int df_idx; float *pts_out, *dft_out;
     const int *skip;        // device-side early stop of the fit that owns the stream (vt_stream_set_skip_flag) or NULL
+    unsigned long long *clk;    // clock probe (vt_query_set_clock_probe: bench.py's solo leg) or NULL: every 1024th workgroup adds its life time in shader clocks
+                                // (s_memtime) and in 100 MHz ticks (s_memrealtime) -- the clock the chip SUSTAINED during the launch, i.e. the launch in clocks
 };
 
 // chunk i (32 channels) -> map index, channel offset inside the map; map -> channels, projection.  Tables in constant memory: the
@@ -678,6 +680,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
     // spill with it and lose 3 %: they keep the per-thread geometry
     constexpr bool SHGEO = (G == 2);
     VT_SKIP_RETURN(a.skip);
+    const bool clk_probe = a.clk != nullptr && (blockIdx.x & 1023u) == 0u;       // (uniform: the two counters live in SGPRs)
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_probe) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     // Region 0 is time-shared: feature-chunk double buffer (layer 1) -> hidden-activation planes per head -> tap-difference
     // buffers + weight slab (layer-1 backward, after the d(hidden-1) fragments moved to registers).
@@ -1534,6 +1539,9 @@ __global__ __launch_bounds__(256, (G == 1) ? 3 : 2) void query_kernel(const QArg
         __syncthreads();
         if (tid == 0) atomicAdd(a.term_accel, (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / ((double)(a.B - 2) * (double)a.N * 3.0));
     }
+    if (clk_probe && tid_l1b == 0) {
+        atomicAdd(a.clk, (unsigned long long)clock64() - clk_c0); atomicAdd(a.clk + 1, (unsigned long long)wall_clock64() - clk_r0); atomicAdd(a.clk + 2, 1ull);
+    }
     }       // (scope of the re-derived lane indices)
 }
 
@@ -1773,6 +1781,11 @@ extern "C" int vt_query_build_projection(const vt_sifnet *h, const vt_maps *maps
     return VT_OK;
 }
 
+// clock probe of the fused-objective kernels (measurement only; NULL = off, the default): `counters` = 3 device-side 64-bit words {shader clocks, 100 MHz ticks,
+// samples}, added to by every 1024th workgroup of every vt_query_* launch while set
+static std::atomic<unsigned long long *> g_clk_probe{nullptr};
+extern "C" int vt_query_set_clock_probe(unsigned long long *counters) { g_clk_probe.store(counters, std::memory_order_relaxed); return VT_OK; }
+
 static size_t lds_bytes(int G)
 {
     const size_t r0 = (size_t)G * 2048 > (size_t)1152 + G * 1024 ? (size_t)G * 2048 : (size_t)1152 + G * 1024;
@@ -1787,7 +1800,7 @@ static int launch_(const QArgs &a, hipStream_t st)
 #endif
     const size_t lds = lds_bytes(G) + LDS_PAD;
     VT_LDS_LIMIT((query_kernel<G, MODE, USEP>), lds);
-    QArgs b = a; b.skip = vt_skip_flag_of(st);
+    QArgs b = a; b.skip = vt_skip_flag_of(st); b.clk = g_clk_probe.load(std::memory_order_relaxed);
     hipLaunchKernelGGL((query_kernel<G, MODE, USEP>), dim3(((a.N + 63) / 64) * a.B), dim3(256), lds, st, b);
     VT_LAUNCH_CHECK();
     return VT_OK;
@@ -1853,7 +1866,17 @@ extern "C" int vt_query_backward(const vt_sifnet *h, const vt_maps *maps, const 
 }
 
 // which kernel serves vt_query_human_loss when the maps carry a projection: 256 (default, the faster one: DESIGN.md 4.1b) or 512 threads per workgroup
-static std::atomic<int> g_human_kernel_threads{[]() { const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); const int v = e ? atoi(e) : 0; return (v == 512 || v == 128) ? v : 256; }()};
+// (the environment switch selects a variant only in the experiments build; the product library holds the 256-thread kernel alone and says so instead of silently
+//  ignoring the request -- the same rule as vt_query_set_human_kernel below: ADVICE r05)
+static std::atomic<int> g_human_kernel_threads{[]() {
+    const char *e = getenv("VT_QUERY_HUMAN_KERNEL"); const int v = e ? atoi(e) : 0;
+#ifdef VT_EXPERIMENTS
+    return (v == 512 || v == 128) ? v : 256;
+#else
+    if (v == 512 || v == 128) fprintf(stderr, "libvistracker_hip: VT_QUERY_HUMAN_KERNEL=%d ignored -- this library holds the default kernel (256) only (make -C vistracker_amd/csrc experiments)\n", v);
+    return 256;
+#endif
+}()};
 extern "C" int vt_query_set_human_kernel(int threads)
 {
 #ifdef VT_EXPERIMENTS

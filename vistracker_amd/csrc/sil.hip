@@ -59,7 +59,7 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
 // workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
 // x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2) fp64 (order-insensitive atomics)
 #define SIL_FIX 17179869184.0      /* 2^34: fixed-point unit of the backward accumulators */
-struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; };
+struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; unsigned long long *cnt; unsigned *ticket; };
 static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
 {
     SilWs w;
@@ -69,11 +69,13 @@ static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
     w.proj = reinterpret_cast<float *>(w.colmask + (size_t)B * is * (is / 64));
     w.fc = w.proj + (size_t)B * NV * 3; w.fbox = reinterpret_cast<int2 *>(w.fc + (size_t)B * 2 * NF * 9);
     w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(w.visible + (size_t)B * 2 * NF) + 7) & ~(uintptr_t)7);     // 8-byte aligned
+    w.cnt = reinterpret_cast<unsigned long long *>(w.gproj + (size_t)B * NV * 2);          // (B) per-frame mask sums, 2^-34 fixed point (vt_sil_step)
+    w.ticket = reinterpret_cast<unsigned *>(w.cnt + B);                                      // workgroups of sil_image_kernel that have finished
     return w;
 }
 extern "C" long vt_sil_workspace_floats(int B, int NV, int NF, int size)
 {
-    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 4 + 16;
+    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 4 + 16 + 2L * B + 8;
 }
 
 // per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
@@ -311,6 +313,9 @@ __global__ __launch_bounds__(256) void sil_sweep_mask_kernel(const int *__restri
                                                      ((unsigned long long)sCol[2][lane] << 32) | ((unsigned long long)sCol[3][lane] << 48);
 }
 
+#ifndef SIL_BWD_FAST
+#define SIL_BWD_FAST 1
+#endif
 // sum over the SIL_G (= 16: one DPP row) lanes of a face's group, every lane gets the result
 __device__ __forceinline__ float group_sum(float v)
 {
@@ -394,22 +399,41 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
             const size_t idx_in = PIX(d0, d1_in, axis), idx_out = PIX(d0, d1_out, axis);
             const float alpha_out = fim[idx_out] >= 0 ? 1.f : 0.f;
             // (... * 2.0f / is): for a power-of-two image size the division is exactly a multiplication by 1 / is
-            const float tA = (p[1][0] - p[0][0]) / (p[1][0] - d0) * 2.0f, tB = (p[1][0] - p[0][0]) / (d0 - p[0][0]) * 2.0f;
+            // SIL_BWD_FAST (round 6): the divisions that only SCALE a term -- tA, tB and diff_grad / dist below -- as reciprocal multiplies (v_rcp_f32, 1 ulp: the
+            // vertex gradients move by ~2e-7 relative, the tests hold them to 1e-5 of the oracle's); d1_cross and d0_cross2, whose floor / ceil pick the PIXELS of a
+            // sweep, keep the IEEE division -- one ulp there moves a sweep boundary (the 1e-4 jumps of section 2 of DESIGN.md)
+#if SIL_BWD_FAST
+#define SIL_DIV(a_, b_) ((a_) * __builtin_amdgcn_rcpf(b_))
+#else
+#define SIL_DIV(a_, b_) ((a_) / (b_))
+#endif
+            const float tA = SIL_DIV(p[1][0] - p[0][0], p[1][0] - d0) * 2.0f, tB = SIL_DIV(p[1][0] - p[0][0], d0 - p[0][0]) * 2.0f;
             const float sA = (p[1][0] != d0) ? (pow2 ? tA * ris : tA / is) : 0.f;   // dist = sA * (d1 - d1_cross) for corner 0
             const float sB = (p[0][0] != d0) ? (pow2 ? tB * ris : tB / is) : 0.f;   // ... for corner 1
+            // Round 6: memory-level parallelism inside a position's chain.  The owner of the in-pixel, the sweep-mask words of the whole row / column (is <= 256: four
+            // words = 32 contiguous bytes) and, above, the owner of the out-pixel are requested TOGETHER (one round trip instead of two); the two sweeps fetch the
+            // next pixel's values while the current one is being added (the adds stay in the same order: bit-identical sums).
+            unsigned long long mw[4] = {0ull, 0ull, 0ull, 0ull};
+            if (wpl <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < wpl) mw[k] = masks[(size_t)d0 * wpl + k];
+            }
             if (fim[idx_in] == f2) {   // sweep outwards from the edge: only flagged pixels have a non-zero term (alpha_in = 1)
                 const int d1_limit = (0 < direction) ? is - 1 : 0;
                 const int d1_from = max(min(d1_out, d1_limit), 0), d1_to = min(max(d1_out, d1_limit), is - 1);
                 for (int wd = d1_from >> 6; wd <= (d1_to >> 6); wd++) {
-                    unsigned long long bits = masks[(size_t)d0 * wpl + wd];
+                    unsigned long long bits = (wpl <= 4) ? (wd == 0 ? mw[0] : wd == 1 ? mw[1] : wd == 2 ? mw[2] : mw[3]) : masks[(size_t)d0 * wpl + wd];
                     const int lo = max(d1_from - wd * 64, 0), hi = min(d1_to - wd * 64, 63);
                     bits &= (~0ull << lo) & (~0ull >> (63 - hi));
+                    float nxt = 0.f;
+                    if (bits) nxt = gal[PIX(d0, wd * 64 + __ffsll((long long)bits) - 1, axis)];
                     while (bits) {
                         const int d1 = wd * 64 + __ffsll((long long)bits) - 1; bits &= bits - 1;
-                        const float diff_grad = -gal[PIX(d0, d1, axis)];
+                        const float diff_grad = -nxt;
+                        if (bits) nxt = gal[PIX(d0, wd * 64 + __ffsll((long long)bits) - 1, axis)];
                         if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= diff_grad / dist; }
-                        if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= diff_grad / dist; }
+                        if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= SIL_DIV(diff_grad, dist); }
+                        if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= SIL_DIV(diff_grad, dist); }
                     }
                 }
             }
@@ -419,13 +443,15 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
                 else d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
                 const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
                 const int d1_from = max(min(d1_in, d1_limit), 0), d1_to = min(max(d1_in, d1_limit), is - 1);
+                int nf_ = 0; float ng_ = 0.f;
+                if (d1_from <= d1_to) { const size_t ix0 = PIX(d0, d1_from, axis); nf_ = fim[ix0]; ng_ = gal[ix0]; }
                 for (int d1 = d1_from; d1 <= d1_to; d1++) {
-                    const size_t ix = PIX(d0, d1, axis);
-                    if (fim[ix] != f2) continue;
-                    const float diff_grad = gal[ix];
+                    const int own = nf_; const float diff_grad = ng_;
+                    if (d1 < d1_to) { const size_t ix1 = PIX(d0, d1 + 1, axis); nf_ = fim[ix1]; ng_ = gal[ix1]; }
+                    if (own != f2) continue;
                     if (diff_grad <= 0) continue;
-                    if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= diff_grad / dist; }
-                    if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= diff_grad / dist; }
+                    if (p[1][0] != d0) { float dist = sA * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; ga -= SIL_DIV(diff_grad, dist); }
+                    if (p[0][0] != d0) { float dist = sB * (d1 - d1_cross); dist = (0 < dist) ? dist + eps : dist - eps; gb -= SIL_DIV(diff_grad, dist); }
                 }
             }
         } while (false);
@@ -494,6 +520,153 @@ __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restr
         if (per_frame) per_frame[b] = (float)per;
         if (term) atomicAdd(term, per * (double)ob / (double)B);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// vt_sil_step (round 6): the whole silhouette term of ONE Adam step of phase 'sil' -- vt_sil_forward + vt_sil_mask_loss + vt_sil_backward -- in 5 launches instead of
+// 10 (project, face set-up, depth-buffer clear, scatter, resolve, mask term, gradient clear, sweep masks, backward walks, un-projection).  The kernels are latency
+// chains on a 256-CU chip: what a step pays for is mostly the NUMBER of them.  Same arithmetic, operation for operation: face corners, owner map,
+// d_image, sweep masks and vertex gradients are bit-identical to the ten-launch path (tests/test_gpu_parity.py::test_sil_step_equals_the_separate_launches).
+//   sil_setup_kernel  = sil_project_kernel (every doubled face projects its own three corners: the same expressions) + sil_face_setup_kernel + the clear of the
+//                       frame's depth keys (grid-stride 16-byte stores);
+//   sil_image_kernel  = sil_resolve_kernel + sil_mask_loss_kernel + sil_sweep_mask_kernel + the clear of the projected-gradient accumulators, one workgroup per
+//                       64 x 64 tile: a pixel's depth key, keep and reference value are read once; owner, d_image and the two sweep-mask words are written.  The mask
+//                       term: per-frame sums in 2^-34 fixed point (integer atomics: order-independent), the LAST workgroup adds mean_b(per[b] occ[b]) to *term in
+//                       frame order (sums and ticket are zeroed by sil_setup_kernel at the start of every step: no state across calls).
+__global__ void sil_setup_kernel(const float *__restrict__ verts, const float *__restrict__ K, const int *__restrict__ faces, int NV, int NF, int is,
+                                 float *__restrict__ fcbuf, int2 *__restrict__ fbox, int *__restrict__ visible, unsigned long long *__restrict__ zbuf,
+                                 unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, const int *skip)
+{
+    VT_SKIP_RETURN(skip);
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[b] = 0ull; if (b == 0) *ticket = 0u; }      // the mask sums of the step start from zero (no state across calls)
+    {   // depth keys of frame b <- ~0 (no face): is * is * 8 bytes over the gridDim.x * 256 threads of the frame
+        uint4 *z4 = reinterpret_cast<uint4 *>(zbuf + (size_t)b * is * is);
+        const int n4 = is * is / 2;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) z4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    const int f2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f2 >= 2 * NF) return;
+    const int f = f2 < NF ? f2 : f2 - NF;
+    int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+    if (f2 >= NF) { const int t = vi[1]; vi[1] = vi[2]; vi[2] = t; }
+    const float *k = K + 9 * b;
+    float fc[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {       // sil_project_kernel, expression for expression
+        const float *v = verts + ((size_t)b * NV + vi[c]) * 3;
+        const float z = v[2], x_ = v[0] / (z + 1e-9f), y_ = v[1] / (z + 1e-9f);
+        const float u = k[0] * x_ + k[1] * y_ + k[2];
+        const float w = 1.0f - (k[3] * x_ + k[4] * y_ + k[5]);
+        fc[3 * c] = 2.0f * (u - 0.5f); fc[3 * c + 1] = 2.0f * (w - 0.5f); fc[3 * c + 2] = z;
+    }
+    float *o = fcbuf + ((size_t)b * 2 * NF + f2) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; e++) o[e] = fc[e];
+    visible[(size_t)b * 2 * NF + f2] = 0;
+    int x0 = 1, x1 = 0, y0 = 1, y1 = 0;
+    if (!((fc[7] - fc[1]) * (fc[3] - fc[0]) < (fc[4] - fc[1]) * (fc[6] - fc[0]))) {     // front side (sil_face_setup_kernel)
+        const float xmin = fminf(fc[0], fminf(fc[3], fc[6])), xmax = fmaxf(fc[0], fmaxf(fc[3], fc[6]));
+        const float ymin = fminf(fc[1], fminf(fc[4], fc[7])), ymax = fmaxf(fc[1], fmaxf(fc[4], fc[7]));
+        const float fx0 = fminf(fmaxf(floorf((xmin * is + is - 1) * 0.5f) - 1.f, -1.f), (float)is), fx1 = fminf(fmaxf(ceilf((xmax * is + is - 1) * 0.5f) + 1.f, -1.f), (float)is);
+        const float fy0 = fminf(fmaxf(floorf((ymin * is + is - 1) * 0.5f) - 1.f, -1.f), (float)is), fy1 = fminf(fmaxf(ceilf((ymax * is + is - 1) * 0.5f) + 1.f, -1.f), (float)is);
+        x0 = max((int)fx0, 0); x1 = min((int)fx1, is - 1); y0 = max((int)fy0, 0); y1 = min((int)fy1, is - 1);
+        if (y0 > y1) { x0 = 1; x1 = 0; }
+    }
+    fbox[(size_t)b * 2 * NF + f2] = make_int2((x0 & 0xffff) | (x1 << 16), (y0 & 0xffff) | (y1 << 16));
+}
+
+__global__ __launch_bounds__(256) void sil_image_kernel(const unsigned long long *__restrict__ zbuf, int NV, int NF, int is, const float *__restrict__ keep,
+                                                        const float *__restrict__ ref, const float *__restrict__ occ, int B, float gs, double *term,
+                                                        int *__restrict__ face_index, float *__restrict__ d_image, float *__restrict__ image, int *__restrict__ visible,
+                                                        unsigned long long *__restrict__ rowmask, unsigned long long *__restrict__ colmask, double *__restrict__ gproj,
+                                                        unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, const int *skip)
+{
+    VT_SKIP_RETURN(skip);
+    __shared__ unsigned sCol[4][64];
+    __shared__ double sSum[4];
+    __shared__ int sLast;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpl = is / 64;
+    const int tile = blockIdx.x, b = blockIdx.y, tiles = wpl * wpl;
+    const int tx = tile % wpl, ty = tile / wpl;                 // internal y-up tile coordinates (as sil_sweep_mask_kernel)
+    const int xi = tx * 64 + lane;
+    {   // this workgroup's share of the frame's projected-gradient accumulators <- 0 (the memset of vt_sil_backward)
+        unsigned long long *g = reinterpret_cast<unsigned long long *>(gproj) + (size_t)b * NV * 2;
+        for (int i = tile * 256 + threadIdx.x; i < NV * 2; i += tiles * 256) g[i] = 0ull;
+    }
+    const float ob = occ[b];
+    unsigned long long key[16]; float kp[16], rf[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int yi = ty * 64 + wave * 16 + r;
+        const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;          // pixel (xi, yi) lives at image row is - 1 - yi
+        key[r] = zbuf[((size_t)b * is + yi) * is + xi]; kp[r] = keep[o]; rf[r] = ref[o];
+    }
+    unsigned col = 0; double acc = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int yi = ty * 64 + wave * 16 + r;
+        const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;
+        const int f = key[r] == ~0ull ? -1 : (int)(unsigned)(key[r] & 0xffffffffull);
+        const float im = f >= 0 ? 1.0f : 0.0f;
+        face_index[o] = f;
+        if (image) image[o] = im;
+        if (f >= 0) visible[(size_t)b * 2 * NF + f] = 1;                       // benign race: every writer stores 1
+        const float d = kp[r] * im - rf[r];                                    // sil_mask_loss_kernel
+        acc += (double)(d * d);
+        const float gd = 2.f * d * kp[r] * ob * gs;
+        d_image[o] = gd;
+        const bool p = f < 0 && gd < 0.f;                                      // sil_sweep_mask_kernel
+        const unsigned long long m = __ballot(p);
+        if (lane == 0) rowmask[((size_t)b * is + yi) * wpl + tx] = m;
+        col |= (unsigned)p << r;
+    }
+    sCol[wave][lane] = col;
+    for (int o_ = 32; o_ > 0; o_ >>= 1) acc += __shfl_xor(acc, o_, 64);
+    if (lane == 0) sSum[wave] = acc;
+    __syncthreads();
+    if (wave == 0)
+        colmask[((size_t)b * is + xi) * wpl + ty] = (unsigned long long)sCol[0][lane] | ((unsigned long long)sCol[1][lane] << 16) |
+                                                     ((unsigned long long)sCol[2][lane] << 32) | ((unsigned long long)sCol[3][lane] << 48);
+    if (threadIdx.x == 0) {
+        const double tsum = sSum[0] + sSum[1] + sSum[2] + sSum[3];
+        atomicAdd(cnt + b, (unsigned long long)__double2ll_rn(tsum * SIL_FIX));
+        __threadfence();
+        sLast = (atomicAdd(ticket, 1u) == (unsigned)(tiles * B) - 1u);
+    }
+    __syncthreads();
+    if (sLast && threadIdx.x == 0) {
+        // every workgroup's sum has landed (each fenced before taking its ticket): the term in frame order, then the accumulators are left clean for the next step
+        __threadfence();
+        double s_ = 0;
+        for (int i = 0; i < B; i++) {
+            const unsigned long long c = atomicAdd(cnt + i, 0ull);             // (an atomic read: the other workgroups' atomics live in L2)
+            s_ += (double)(long long)c * (1.0 / SIL_FIX) * (double)occ[i] / (double)B;
+        }
+        if (term) atomicAdd(term, s_);
+    }
+}
+
+extern "C" int vt_sil_step(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, const float *keep, const float *ref,
+                           const float *occ, float gscale, float eps, double *term, int *face_index, float *d_image, float *ws, float *dverts, void *stream)
+{
+    VT_REQUIRE(verts && faces && K && keep && ref && occ && face_index && d_image && ws && dverts && B > 0 && NV > 0 && NF > 0 && size > 0 && size % 64 == 0 && size < 32768,
+               "vt_sil_step: bad argument (size must be a multiple of 64)");
+    hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
+    const SilWs w = sil_ws(ws, B, NV, NF, size);
+    hipLaunchKernelGGL(sil_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, verts, K, faces, NV, NF, size, w.fc, w.fbox, w.visible, w.zbuf, w.cnt, w.ticket, skip);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_GS) - 1) / (4 * (64 / SIL_GS)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, skip);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_image_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, w.zbuf, NV, NF, size, keep, ref, occ, B, gscale / (float)B, term, face_index,
+                       d_image, (float *)nullptr, w.visible, w.rowmask, w.colmask, w.gproj, w.cnt, w.ticket, skip);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
+                       w.rowmask, w.colmask, eps, w.gproj, skip);
+    VT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, skip);
+    VT_LAUNCH_CHECK();
+    return VT_OK;
 }
 
 extern "C" int vt_sil_forward(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, float *image,

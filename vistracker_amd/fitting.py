@@ -223,6 +223,9 @@ class FitContext:
     # query per object-stage step instead of ~11, one tail instead of 8 in the SMPL stage); False = the single-purpose launches (same arithmetic in
     # the same order: the trajectories are bit-identical, tests/test_gpu_fit.py)
     fused_steps = os.environ.get("VT_FUSED_STEPS", "1") != "0"
+    # phase 'sil' of the fused step: the silhouette term as ONE call of 5 launches (vt_sil_step) instead of vt_sil_forward + vt_sil_mask_loss + vt_sil_backward
+    # (10 launches); bit-identical gradients (tests/test_gpu_parity.py::test_sil_step_equals_the_separate_launches)
+    fused_sil_step = os.environ.get("VT_FUSED_SIL_STEP", "1") != "0"
     # SMPL stage: keypoint chain as one launch + the query adding its gradient and the vertex acceleration stencil in its epilogue (vt_kpts_step /
     # vt_query_human_step: 8 launches per step instead of 11, bit-identical).  MEASURED SLOWER and therefore off: the twelve neighbour-frame loads per
     # point in the tail of the dominant kernel cost it 1 % (1.684 -> 1.700 ms), more than the three small launches it replaces were worth behind
@@ -717,7 +720,12 @@ class FitContext:
             _chk(lib.vt_temporal_loss2(X.data_ptr(), B, N * 3, float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), int(is_sil), st))
         elif is_sil:
             _chk(lib.vt_fill(dX.data_ptr(), dX.numel(), 0.0, st))
-        if is_sil:
+        if is_sil and self.fused_sil_step:
+            # the silhouette term of the step in 5 launches (vt_sil_step) instead of the 10 of the three calls below: same arithmetic, bit-identical gradients
+            _chk(lib.vt_sil_step(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size, sil.keep.data_ptr(),
+                                 sil.ref.data_ptr(), occ.data_ptr(), float(w[3]), 1e-4, terms.ptr("mask"), fidx.data_ptr(), dimg.data_ptr(), sws.data_ptr(),
+                                 dVt.data_ptr(), st))
+        elif is_sil:
             _chk(lib.vt_sil_forward(Vt.data_ptr(), B, NV, self.obj_faces.data_ptr(), self.obj_faces.shape[0], sil.K.data_ptr(), sil.size,
                                     img.data_ptr(), fidx.data_ptr(), sws.data_ptr(), st))
             _chk(lib.vt_sil_mask_loss(img.data_ptr(), sil.keep.data_ptr(), sil.ref.data_ptr(), occ.data_ptr(), B, sil.size, float(w[3]),
