@@ -330,7 +330,9 @@ def sifnet_inference_leg(torch, syn):
     t_proj = timed(lambda: gen.approx_surface(net, pts, 10, {"crop_center": cc, "body_center": bc}, "object"))
     return {"workload": "SIF-Net inference, batch 16 x 512^2, 50 000 samples/frame (BASELINE configs[3])", "frames_per_s": B / (t_enc + t_q),
             "encoder_ms": 1e3 * t_enc, "query_5_heads_ms": 1e3 * t_q, "query_Mpoints_per_s": B * N / t_q / 1e6, "surface_projection_10_steps_ms": 1e3 * t_proj,
-            "encoder_tflops": 0.613 * B / t_enc}
+            "encoder_tflops": 0.613 * B / t_enc,
+            # which route the convolutions took (capture pass + eager warm-up passes): everything but the 7 x 7 stem must be on the HIP kernels
+            "encoder_conv_routes": net.encoder.route_report() if getattr(net, "encoder", None) is not None else None}
 
 
 def pipeline_leg(torch, T=1500):

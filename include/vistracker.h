@@ -289,6 +289,16 @@ int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_verts, const 
                     float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
                     double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
                     void *stream);
+/* vt_objstep_tail with the stencils of vt_temporal_loss2(X_points, B, 3 N, ...) evaluated inside it (the same float additions in the same order: bit-identical
+ * parameters, one launch less per step); init_zero as there (dX_points is then not read).  For the phases in which nothing else adds to dX_points between the
+ * stencils and the tail ('object only', 'sil'). */
+int vt_objstep_tail_temporal(const float *X_points, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, int init_zero,
+                             const float *X0_verts, int NV, const float *dX_verts, const float *X0_points, int N, const float *dX_points, const float *s, int B,
+                             const float *M0, const float *noise, const float *t, const float *t_init, float w_trans, double *term_trans,
+                             float *dR, float *dt, float *dM,
+                             float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
+                             double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                             void *stream);
 int vt_smplstep_tail(float *pose, const float *pose_init, float *dpose, int B, const float *prior_mean, const float *prior_prec, float gscale_prior,
                      double *term_prior, float w_pinit, double *term_pinit,
                      float *p0, int ps0, const float *g0, int gs0, float *m0, float *v0, int n0, float lr0,

@@ -20,3 +20,16 @@ step(); torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
 for _ in range(20): step()
 e1.record(); torch.cuda.synchronize(); print("sil fwd+bwd (autograd wrapper):", e0.elapsed_time(e1) / 20 * 1000, "us")
+# ---- the fused step form (vt_sil_step: 5 launches) on the same inputs
+from vistracker_amd import _lib as L
+NV, NF = verts.shape[1], f.shape[0]
+keep = torch.ones_like(ref); occ = torch.ones(B, device="cuda")
+fidx = torch.empty(B, 256, 256, dtype=torch.int32, device="cuda"); dimg = torch.empty(B, 256, 256, device="cuda"); dv = torch.empty(B, NV, 3, device="cuda")
+ws = torch.empty(L.lib().vt_sil_workspace_floats(B, NV, NF, 256), device="cuda"); term = torch.zeros(1, dtype=torch.float64, device="cuda")
+vd = verts.detach()
+def step2():
+    L.check(L.lib().vt_sil_step(L.dptr(vd), B, NV, L.dptr(f), NF, L.dptr(K), 256, L.dptr(keep), L.dptr(ref), L.dptr(occ), 1e-3, 1e-4, term.data_ptr(), L.dptr(fidx), L.dptr(dimg),
+                                L.dptr(ws), L.dptr(dv), L.stream_ptr()))
+step2(); torch.cuda.synchronize(); e0.record()
+for _ in range(20): step2()
+e1.record(); torch.cuda.synchronize(); print("vt_sil_step:", e0.elapsed_time(e1) / 20 * 1000, "us")

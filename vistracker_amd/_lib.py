@@ -71,6 +71,10 @@ SIGNATURES = {
     "vt_objstep_tail": (ci, [fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,
                              fp, fp, fp, cf, fp, fp, fp, cf, ci, cf, cf, cf,
                              fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
+    "vt_objstep_tail_temporal": (ci, [fp, cf, fp, cf, fp, ci,
+                                      fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,
+                                      fp, fp, fp, cf, fp, fp, fp, cf, ci, cf, cf, cf,
+                                      fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
     "vt_smplstep_tail": (ci, [fp, fp, fp, ci, fp, fp, cf, fp, cf, fp,
                               fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, ci, cf, cf, cf,
                               fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),

@@ -971,17 +971,31 @@ __device__ __forceinline__ void adam_one(const AdamSlice &a, int b, int c, float
     const float denom = sqrtf(vi) / bc2s + eps;
     a.p[(size_t)b * a.pstride + c] = a.p[(size_t)b * a.pstride + c] - a.step_size * (mi / denom);
 }
+#ifndef STEP_END_FENCE
+#define STEP_END_FENCE 0
+#endif
 // the workgroup that takes the last ticket closes the step: weighted loss, history, the reference's stop rule (loss_reduce_kernel), and the term
 // accumulators [0, nzero) zeroed for the next step.  Every other workgroup has finished (its writes fenced) by then.
 __device__ __forceinline__ void step_end(const StepEnd &e, int nblocks, bool stopped)
 {
     __shared__ int last;
+    // What the closing workgroup reads of the others are the TERM accumulators only, and those are device-scope atomics (performed at the memory side, dropped from
+    // the XCD's L2) read back with agent-scope atomic loads: each wave waits until its own atomics have been performed (s_waitcnt vmcnt(0)) before the workgroup
+    // takes its ticket.  No __threadfence(): on a multi-XCD part it writes the XCD's dirty L2 lines back and invalidates the L1 -- ~3.5 us per fencing workgroup,
+    // 2-4 x that with all 256 threads fencing (MI355X_MICROARCH.md; measured round 6 in sil_image_kernel: 110 us with a fence per workgroup, 26 us without) -- for
+    // plain stores (parameters, Adam moments, history) that nobody reads before the kernel boundary.  -DSTEP_END_FENCE=1 restores the fences.
+#if STEP_END_FENCE
     __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
     if (threadIdx.x == 0) last = (atomicAdd(e.ticket, 1) == nblocks - 1);
     __syncthreads();
     if (!last) return;
+#if STEP_END_FENCE
     __threadfence();
+#endif
     if (threadIdx.x == 0) {
         *e.ticket = 0;
         if (stopped) { if (e.history) e.history[e.slot] = nanf(""); }
@@ -999,15 +1013,21 @@ __device__ __forceinline__ void step_end(const StepEnd &e, int nblocks, bool sto
 
 // tail of an object-stage step, one workgroup per frame: rigid VJP over the vertex set (phase 'sil') and the surface points, the translation
 // regulariser of phase 'sil', the SO(3) VJP, Adam on the frame's rotation parameters (9) and translation (3), then step_end
-__global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restrict__ X0v, int NV, const float *__restrict__ dXv, const float *__restrict__ X0p, int N,
+// vt_objstep_tail_temporal (round 6): the stencils of vt_temporal_loss2 evaluated INSIDE the tail while it reads the points' gradient -- g = dX (or 0: phase 'sil'),
+// g += gs_a (2 a_0 - a_m - a_p), g += gs_v (d_0 - d_1): the float additions of temporal2_kernel in their order, so the rigid VJP sees the same bits -- one launch
+// (19 us of launch-bound stencil work per object-stage step) less.  mode 0: off (dXp already holds everything), 1: add to dXp, 2: dXp is not read (phase 'sil').
+struct TemporalIn { const float *X; float gs_a, gs_v; double *term_a, *term_v; int mode; };
+__global__ __launch_bounds__(256) void objstep_tail_kernel(TemporalIn tin, const float *__restrict__ X0v, int NV, const float *__restrict__ dXv, const float *__restrict__ X0p, int N,
                                                            const float *__restrict__ dXp, const float *__restrict__ s, const float *__restrict__ M0,
                                                            const float *__restrict__ noise, const float *__restrict__ tpar, const float *__restrict__ t_init,
                                                            float w_trans, double *term_trans, float *__restrict__ dR, float *__restrict__ dt, float *__restrict__ dM,
                                                            AdamSlice aR, AdamSlice aT, float bc2s, float beta1, float beta2, float eps, StepEnd end)
 {
     __shared__ float red12[4][12];
+    __shared__ double redt[4];
     const int b = blockIdx.x, B = gridDim.x;
     const bool stopped = end.stop_flag && *end.stop_flag;          // read before any workgroup can close the step
+    double acc_a = 0, acc_v = 0;
     // phase 'joint' optimises obj_t only (recon_fit_trivis_full.py:343-347: optim.Adam([obj_t], lr=0.002)): the rotation half of the rigid VJP (nine of
     // the twelve sums over the points) and the SO(3) VJP with its second Jacobi SVD feed nothing -- skipped when no rotation slice is optimised
     // (dR / dM are then left untouched; obj_t takes the same three sums in the same order: bit-identical parameters)
@@ -1024,7 +1044,30 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
 #pragma unroll
         for (int e = 0; e < 12; e++) a[e] = 0.f;
         for (int n = threadIdx.x; n < n_; n += 256) {
-            const float *x = X0 + (size_t)n * 3, *g = dX + ((size_t)b * n_ + n) * 3;
+            const float *x = X0 + (size_t)n * 3; const float *g = dX + ((size_t)b * n_ + n) * 3;
+            float gt[3];
+            if (pass == 1 && tin.mode) {
+                // temporal2_kernel for the three elements of point n in frame b (frames clamped exactly like there)
+                const int D = N * 3, f = b;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int i = n * 3 + c;
+                    const float vm2 = tin.X[(size_t)min(max(f - 2, 0), B - 1) * D + i], vm1 = tin.X[(size_t)min(max(f - 1, 0), B - 1) * D + i], v0 = tin.X[(size_t)f * D + i],
+                                vp1 = tin.X[(size_t)min(max(f + 1, 0), B - 1) * D + i], vp2 = tin.X[(size_t)min(max(f + 2, 0), B - 1) * D + i];
+                    const float a_m = (f - 1 >= 1 && f - 1 <= B - 2) ? 2.f * vm1 - vm2 - v0 : 0.f;
+                    const float a_0 = (f >= 1 && f <= B - 2) ? 2.f * v0 - vm1 - vp1 : 0.f;
+                    const float a_p = (f + 1 >= 1 && f + 1 <= B - 2) ? 2.f * vp1 - v0 - vp2 : 0.f;
+                    acc_a += (double)(1.f * a_0 * a_0);
+                    float gg = tin.mode == 2 ? 0.f : g[c];
+                    gg += tin.gs_a * 1.f * (2.f * a_0 - a_m - a_p);
+                    const float d0 = f >= 1 ? v0 - vm1 : 0.f;
+                    const float d1 = f + 1 < B ? vp1 - v0 : 0.f;
+                    acc_v += (double)(d0 * d0);
+                    gg += tin.gs_v * (d0 - d1);
+                    gt[c] = gg;
+                }
+                g = gt;
+            }
             if (rot) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) { const float gc = g[c] * sc; a[9 + c] += gc; a[c] += x[0] * gc; a[3 + c] += x[1] * gc; a[6 + c] += x[2] * gc; }
@@ -1056,6 +1099,11 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(const float *__restri
 #pragma unroll
             for (int c = 0; c < 3; c++) { const float d = tpar[3 * b + c] - t_init[3 * b + c]; tot[9 + c] += 2.f * d * inv_denom * w_trans; }
         }
+    }
+    if (tin.mode) {
+        // the frame's share of the two stencil terms (vt_temporal_loss2 adds per workgroup of 256 elements: the same fp64 atomics, another grouping)
+        term_add(acc_a / ((double)(B - 2) * (N * 3)), tin.term_a, redt);
+        term_add(acc_v / ((double)(B - 1) * (N * 3)), tin.term_v, redt);
     }
     if (threadIdx.x == 0) {
         float g[12];
@@ -1129,7 +1177,29 @@ extern "C" int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_ve
                "vt_objstep_tail: bad optimiser / loss arguments");
     const double bc1 = 1.0 - pow((double)beta1, adam_step), bc2 = 1.0 - pow((double)beta2, adam_step);
     AdamSlice aR = {pR, 9, dM, 9, mR, vR, 9, (float)(lrR / bc1)}, aT = {pT, 3, dt, 3, mT, vT, 3, (float)(lrT / bc1)};
-    hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
+    const TemporalIn tin = {nullptr, 0.f, 0.f, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), tin, X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
+                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
+    VT_LAUNCH_CHECK();
+    return VT_OK;
+}
+extern "C" int vt_objstep_tail_temporal(const float *X_points, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, int init_zero,
+                                        const float *X0_verts, int NV, const float *dX_verts, const float *X0_points, int N, const float *dX_points, const float *s, int B,
+                                        const float *M0, const float *noise, const float *t, const float *t_init, float w_trans, double *term_trans,
+                                        float *dR, float *dt, float *dM,
+                                        float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
+                                        double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
+                                        void *stream)
+{
+    VT_REQUIRE(X_points && term_accel && term_velocity && B >= 3, "vt_objstep_tail_temporal: bad argument (B >= 3)");
+    VT_REQUIRE(X0_points && dX_points && s && M0 && t && dR && dt && dM && B > 0 && N > 0 && (!dX_verts || (X0_verts && NV > 0)) && (!t_init || term_trans), "vt_objstep_tail_temporal: bad argument");
+    VT_REQUIRE(terms && w && state && ticket && nterms > 0 && nterms <= 16 && nzero >= 0 && nzero <= nterms && adam_step >= 1 && (!pR || (mR && vR)) && (!pT || (mT && vT)),
+               "vt_objstep_tail_temporal: bad optimiser / loss arguments");
+    const double bc1 = 1.0 - pow((double)beta1, adam_step), bc2 = 1.0 - pow((double)beta2, adam_step);
+    AdamSlice aR = {pR, 9, dM, 9, mR, vR, 9, (float)(lrR / bc1)}, aT = {pT, 3, dt, 3, mT, vT, 3, (float)(lrT / bc1)};
+    const int D = N * 3;
+    const TemporalIn tin = {X_points, 2.f * gscale_accel / ((float)(B - 2) * (float)D), 2.f * gscale_velocity / ((float)(B - 1) * (float)D), term_accel, term_velocity, init_zero ? 2 : 1};
+    hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), tin, X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
                        dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
     VT_LAUNCH_CHECK();
     return VT_OK;

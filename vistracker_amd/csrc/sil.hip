@@ -59,7 +59,7 @@ __device__ __forceinline__ void load_face(const float *__restrict__ pv, const in
 // workspace layout (floats): proj (B,NV,3) | fc (B,2NF,9) projected face corners | fbox (B,2NF,4 x int16 = 2 floats) pixel bbox,
 // x0 > x1 marks culled (back side / off screen) | visible (B,2NF) int | gproj (B,NV,2) fp64 (order-insensitive atomics)
 #define SIL_FIX 17179869184.0      /* 2^34: fixed-point unit of the backward accumulators */
-struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; unsigned long long *cnt; unsigned *ticket; };
+struct SilWs { unsigned long long *zbuf, *rowmask, *colmask; float *proj, *fc; int2 *fbox; int *visible; double *gproj; unsigned long long *cnt; unsigned *ticket; int *nvis, *vlist; unsigned *ftick; };
 static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
 {
     SilWs w;
@@ -71,11 +71,14 @@ static inline SilWs sil_ws(float *ws, int B, int NV, int NF, int is)
     w.visible = reinterpret_cast<int *>(w.fbox + (size_t)B * 2 * NF); w.gproj = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(w.visible + (size_t)B * 2 * NF) + 7) & ~(uintptr_t)7);     // 8-byte aligned
     w.cnt = reinterpret_cast<unsigned long long *>(w.gproj + (size_t)B * NV * 2);          // (B) per-frame mask sums, 2^-34 fixed point (vt_sil_step)
     w.ticket = reinterpret_cast<unsigned *>(w.cnt + B);                                      // workgroups of sil_image_kernel that have finished
+    w.nvis = reinterpret_cast<int *>(w.ticket + 2);                                          // (B) number of faces that own a pixel (vt_sil_step)
+    w.vlist = w.nvis + B;                                                                    // (B,NF) their doubled-face ids, in order of discovery
+    w.ftick = reinterpret_cast<unsigned *>(w.vlist + (size_t)B * NF);                        // (B) tiles of the frame that sil_image_kernel has finished
     return w;
 }
 extern "C" long vt_sil_workspace_floats(int B, int NV, int NF, int size)
 {
-    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 4 + 16 + 2L * B + 8;
+    return 2L * B * size * size + 4L * B * size * (size / 64) + (long)B * NV * 3 + (long)B * 2 * NF * (9 + 2 + 1) + (long)B * NV * 4 + 16 + 2L * B + 8 + (long)B * (NF + 2);
 }
 
 // per (frame, doubled face): corners, back-face test, pixel bounding box -- so that the per-tile culling below streams 8 B per face
@@ -148,6 +151,12 @@ __device__ __forceinline__ bool sil_inside(const float (&fc)[9], float xp, float
 // is above SIL_RIM (1/64: >= 0.05 px inside every edge, where the depths of two faces folded over a common edge already differ by >= 1e-5 m) take reciprocal
 // multiplies (v_rcp_f32, 1 ulp); pixels on the rim keep neural_renderer's formula division for division, bit for bit the oracle's.  Images and owner maps stay
 // identical to the oracle's (tests/test_gpu_parity.py: 96 poses at bench size, every pixel's owner).
+#ifndef SIL_IMG_ABL
+#define SIL_IMG_ABL 0     /* timing ablations of sil_image_kernel (wrong results): 1 no term / tickets, 2 no flag stores, 4 no gradient clear, 8 no row-mask stores */
+#endif
+#ifndef SIL_COMPACT
+#define SIL_COMPACT 0
+#endif
 #ifndef SIL_FAST_Z
 #define SIL_FAST_Z 1
 #endif
@@ -331,17 +340,26 @@ __device__ __forceinline__ float group_sum(float v)
 // the face itself.  Internal pixel coordinates are y-up: pixel (xi, yi) lives at image row is-1-yi.
 __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restrict__ fcbuf, const int *__restrict__ visible, const int *__restrict__ faces, int NV, int NF, int is,
                                     const int *__restrict__ face_index, const float *__restrict__ d_image, const unsigned long long *__restrict__ rowmask,
-                                    const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj, const int *skip)
+                                    const unsigned long long *__restrict__ colmask, float eps, double *__restrict__ gproj, const int *__restrict__ nvis,
+                                    const int *__restrict__ vlist, const int *skip)
 {
     VT_SKIP_RETURN(skip);
+    // (vlist != NULL: vt_sil_step -- group g of frame b takes the g-th listed owner face; the sums are fixed-point atomics, the order of the list does not matter)
     // a group of SIL_G lanes per ORIGINAL face (see sil_scatter_kernel): at most one of its two orientations won pixels.  A visible face is a chain
     // of dependent memory round trips (record -> face index at the edge -> sweep masks -> image gradient), ~8 us at full occupancy whatever the lane
     // count: four faces per wave share that latency (a face has ~40 walk positions: two or three rounds of 16 lanes instead of one of 64).
     const int lane = threadIdx.x & (SIL_G - 1), b = blockIdx.y;
-    const int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / SIL_G) + ((threadIdx.x & 63) / SIL_G);
+    int f = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / SIL_G) + ((threadIdx.x & 63) / SIL_G);
     if (f >= NF) return;
-    // visibility flags, vertex ids and corners: independent loads, requested before the first branch
-    const int visA = visible[(size_t)b * 2 * NF + f], visB = visible[(size_t)b * 2 * NF + NF + f];
+    int visA, visB;
+    if (vlist) {
+        if (f >= nvis[b]) return;
+        const int fl = vlist[(size_t)b * NF + f];
+        visA = fl < NF; visB = !visA; f = visA ? fl : fl - NF;
+    } else {
+        // visibility flags, vertex ids and corners: independent loads, requested before the first branch
+        visA = visible[(size_t)b * 2 * NF + f]; visB = visible[(size_t)b * 2 * NF + NF + f];
+    }
     int vi[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
     float PA[3][2];         // corners of orientation f in pixel units
 #pragma unroll
@@ -476,10 +494,23 @@ __global__ __launch_bounds__(256) void sil_bwd_face_kernel(const float *__restri
         }
 }
 
+// (cnt != NULL: vt_sil_step -- workgroup (0, 0) also closes the mask term: mean_b(per[b] occ[b]) from sil_image_kernel's per-frame fixed-point sums, added in frame order)
 __global__ void sil_unproject_kernel(const float *__restrict__ verts, const float *__restrict__ K, int NV, const double *__restrict__ gproj,
-                                     float *__restrict__ dverts, const int *skip)
+                                     float *__restrict__ dverts, const unsigned long long *__restrict__ cnt, const float *__restrict__ occ, int B, double *term, const int *skip)
 {
     VT_SKIP_RETURN(skip);
+    if (cnt && term && blockIdx.x == 0 && blockIdx.y == 0) {
+        __shared__ double sPer[256];
+        double s_ = 0;
+        for (int i0 = 0; i0 < B; i0 += (int)blockDim.x) {
+            const int i = i0 + (int)threadIdx.x;
+            sPer[threadIdx.x] = i < B ? (double)(long long)cnt[i] * (1.0 / SIL_FIX) * (double)occ[i] / (double)B : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) for (int k = 0; k < min((int)blockDim.x, B - i0); k++) s_ += sPer[k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicAdd(term, s_);
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= NV) return;
     const float *v = verts + ((size_t)b * NV + i) * 3, *k = K + 9 * b;
@@ -531,15 +562,15 @@ __global__ __launch_bounds__(256) void sil_mask_loss_kernel(const float *__restr
 //                       frame's depth keys (grid-stride 16-byte stores);
 //   sil_image_kernel  = sil_resolve_kernel + sil_mask_loss_kernel + sil_sweep_mask_kernel + the clear of the projected-gradient accumulators, one workgroup per
 //                       64 x 64 tile: a pixel's depth key, keep and reference value are read once; owner, d_image and the two sweep-mask words are written.  The mask
-//                       term: per-frame sums in 2^-34 fixed point (integer atomics: order-independent), the LAST workgroup adds mean_b(per[b] occ[b]) to *term in
-//                       frame order (sums and ticket are zeroed by sil_setup_kernel at the start of every step: no state across calls).
+//                       term: per-frame sums in 2^-34 fixed point (integer atomics: order-independent), workgroup (0, 0) of sil_unproject_kernel -- the step's
+//                       last launch -- adds mean_b(per[b] occ[b]) to *term in frame order (the sums are zeroed by sil_setup_kernel: no state across calls).
 __global__ void sil_setup_kernel(const float *__restrict__ verts, const float *__restrict__ K, const int *__restrict__ faces, int NV, int NF, int is,
                                  float *__restrict__ fcbuf, int2 *__restrict__ fbox, int *__restrict__ visible, unsigned long long *__restrict__ zbuf,
-                                 unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, const int *skip)
+                                 unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, int *__restrict__ nvis, unsigned *__restrict__ ftick, const int *skip)
 {
     VT_SKIP_RETURN(skip);
     const int b = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[b] = 0ull; if (b == 0) *ticket = 0u; }      // the mask sums of the step start from zero (no state across calls)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[b] = 0ull; nvis[b] = 0; ftick[b] = 0u; if (b == 0) *ticket = 0u; }      // the mask sums of the step start from zero (no state across calls)
     {   // depth keys of frame b <- ~0 (no face): is * is * 8 bytes over the gridDim.x * 256 threads of the frame
         uint4 *z4 = reinterpret_cast<uint4 *>(zbuf + (size_t)b * is * is);
         const int n4 = is * is / 2;
@@ -580,19 +611,19 @@ __global__ __launch_bounds__(256) void sil_image_kernel(const unsigned long long
                                                         const float *__restrict__ ref, const float *__restrict__ occ, int B, float gs, double *term,
                                                         int *__restrict__ face_index, float *__restrict__ d_image, float *__restrict__ image, int *__restrict__ visible,
                                                         unsigned long long *__restrict__ rowmask, unsigned long long *__restrict__ colmask, double *__restrict__ gproj,
-                                                        unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, const int *skip)
+                                                        unsigned long long *__restrict__ cnt, unsigned *__restrict__ ticket, int *__restrict__ nvis,
+                                                        int *__restrict__ vlist, unsigned *__restrict__ ftick, const int *skip)
 {
     VT_SKIP_RETURN(skip);
     __shared__ unsigned sCol[4][64];
     __shared__ double sSum[4];
-    __shared__ int sLast;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpl = is / 64;
     const int tile = blockIdx.x, b = blockIdx.y, tiles = wpl * wpl;
     const int tx = tile % wpl, ty = tile / wpl;                 // internal y-up tile coordinates (as sil_sweep_mask_kernel)
     const int xi = tx * 64 + lane;
     {   // this workgroup's share of the frame's projected-gradient accumulators <- 0 (the memset of vt_sil_backward)
         unsigned long long *g = reinterpret_cast<unsigned long long *>(gproj) + (size_t)b * NV * 2;
-        for (int i = tile * 256 + threadIdx.x; i < NV * 2; i += tiles * 256) g[i] = 0ull;
+        if (!(SIL_IMG_ABL & 4)) for (int i = tile * 256 + threadIdx.x; i < NV * 2; i += tiles * 256) g[i] = 0ull;
     }
     const float ob = occ[b];
     unsigned long long key[16]; float kp[16], rf[16];
@@ -602,49 +633,73 @@ __global__ __launch_bounds__(256) void sil_image_kernel(const unsigned long long
         const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;          // pixel (xi, yi) lives at image row is - 1 - yi
         key[r] = zbuf[((size_t)b * is + yi) * is + xi]; kp[r] = keep[o]; rf[r] = ref[o];
     }
+    // The first pixel that finds its owner's flag clear lists the face for the backward walks: the backward kernel then runs over the ~45 % of the faces that own
+    // pixels, densely packed.  The flags of the 16 rows are requested together (16 independent loads, not 16 dependent round trips); the faces a workgroup is first
+    // to see are collected in LDS and appended to the frame's list with ONE global atomic per workgroup (every face its own atomic on nvis[b]: ~1100 same-address
+    // atomics per frame, 90 us of this kernel).
+    // MEASURED (round 6): the list costs the image kernel more than it saves the backward kernel -- 137 us with one atomic per pixel's first sight, 97 us with
+    // rim-only atomics + LDS aggregation, against 40 us without, for 88 -> 84 us in sil_bwd_face (whose time is the dependent chain of a face, not the number of
+    // waves) -> SIL_COMPACT = 0: plain flag stores, the backward kernel tests the flags of all faces.
+    constexpr int LCAP = 1024;
+    __shared__ int sList[LCAP];
+    __shared__ int sN, sBase;
+    if (threadIdx.x == 0) sN = 0;
+    __syncthreads();
+    int fown[16], seen[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        fown[r] = key[r] == ~0ull ? -1 : (int)(unsigned)(key[r] & 0xffffffffull);
+        seen[r] = (SIL_COMPACT && fown[r] >= 0) ? visible[(size_t)b * 2 * NF + fown[r]] : 1;
+    }
     unsigned col = 0; double acc = 0;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int yi = ty * 64 + wave * 16 + r;
         const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;
-        const int f = key[r] == ~0ull ? -1 : (int)(unsigned)(key[r] & 0xffffffffull);
+        const int f = fown[r];
         const float im = f >= 0 ? 1.0f : 0.0f;
         face_index[o] = f;
         if (image) image[o] = im;
-        if (f >= 0) visible[(size_t)b * 2 * NF + f] = 1;                       // benign race: every writer stores 1
+        // (all 1536 workgroups of a launch are resident at once: early on every pixel still reads a clear flag.  Only the pixels at the upper-left rim of a face's
+        //  pixels inside this wave's 16 x 64 block -- left neighbour and upper neighbour owned by someone else -- go to the atomic: ~5 per face instead of ~20)
+#if SIL_COMPACT
+        const int f_left = __shfl_up(f, 1, 64);
+        const bool rim = (lane == 0 || f_left != f) && (r == 0 || fown[r > 0 ? r - 1 : 0] != f);
+        if (seen[r] == 0 && rim && atomicExch(visible + (size_t)b * 2 * NF + f, 1) == 0) {
+            const int k = atomicAdd(&sN, 1);
+            if (k < LCAP) sList[k] = f; else vlist[(size_t)b * NF + atomicAdd(nvis + b, 1)] = f;       // (overflow of the tile's list: straight to the frame's)
+        }
+#else
+#if !(SIL_IMG_ABL & 2)
+        if (f >= 0) visible[(size_t)b * 2 * NF + f] = 1;                       // benign race: every writer stores 1 (sil_resolve_kernel)
+#endif
+#endif
         const float d = kp[r] * im - rf[r];                                    // sil_mask_loss_kernel
         acc += (double)(d * d);
         const float gd = 2.f * d * kp[r] * ob * gs;
         d_image[o] = gd;
         const bool p = f < 0 && gd < 0.f;                                      // sil_sweep_mask_kernel
         const unsigned long long m = __ballot(p);
-        if (lane == 0) rowmask[((size_t)b * is + yi) * wpl + tx] = m;
+        if (lane == 0 && !(SIL_IMG_ABL & 8)) rowmask[((size_t)b * is + yi) * wpl + tx] = m;
         col |= (unsigned)p << r;
     }
     sCol[wave][lane] = col;
     for (int o_ = 32; o_ > 0; o_ >>= 1) acc += __shfl_xor(acc, o_, 64);
     if (lane == 0) sSum[wave] = acc;
     __syncthreads();
+    {   // the tile's newly seen faces -> the frame's list
+        const int nl = min(sN, LCAP);
+        if (threadIdx.x == 0 && nl > 0) sBase = atomicAdd(nvis + b, nl);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nl; i += 256) vlist[(size_t)b * NF + sBase + i] = sList[i];
+    }
     if (wave == 0)
         colmask[((size_t)b * is + xi) * wpl + ty] = (unsigned long long)sCol[0][lane] | ((unsigned long long)sCol[1][lane] << 16) |
                                                      ((unsigned long long)sCol[2][lane] << 32) | ((unsigned long long)sCol[3][lane] << 48);
-    if (threadIdx.x == 0) {
-        const double tsum = sSum[0] + sSum[1] + sSum[2] + sSum[3];
-        atomicAdd(cnt + b, (unsigned long long)__double2ll_rn(tsum * SIL_FIX));
-        __threadfence();
-        sLast = (atomicAdd(ticket, 1u) == (unsigned)(tiles * B) - 1u);
-    }
-    __syncthreads();
-    if (sLast && threadIdx.x == 0) {
-        // every workgroup's sum has landed (each fenced before taking its ticket): the term in frame order, then the accumulators are left clean for the next step
-        __threadfence();
-        double s_ = 0;
-        for (int i = 0; i < B; i++) {
-            const unsigned long long c = atomicAdd(cnt + i, 0ull);             // (an atomic read: the other workgroups' atomics live in L2)
-            s_ += (double)(long long)c * (1.0 / SIL_FIX) * (double)occ[i] / (double)B;
-        }
-        if (term) atomicAdd(term, s_);
-    }
+    // the tile's share of the frame's mask sum: ONE fixed-point atomic.  (A first form closed the step here -- __threadfence + ticket, the last workgroup adding the
+    // frames up: an agent-scope fence on a multi-XCD part writes the XCD's L2 back, and 1536 of them made this kernel 110 us instead of 26; the sums are now added
+    // up by the first workgroup of sil_unproject_kernel, the step's last launch, behind the kernel boundary.)
+    if (threadIdx.x == 0 && !(SIL_IMG_ABL & 1)) atomicAdd(cnt + b, (unsigned long long)__double2ll_rn((sSum[0] + sSum[1] + sSum[2] + sSum[3]) * SIL_FIX));
 }
 
 extern "C" int vt_sil_step(const float *verts, int B, int NV, const int *faces, int NF, const float *K, int size, const float *keep, const float *ref,
@@ -654,17 +709,17 @@ extern "C" int vt_sil_step(const float *verts, int B, int NV, const int *faces, 
                "vt_sil_step: bad argument (size must be a multiple of 64)");
     hipStream_t st = vt_stream(stream); const int *skip = vt_skip_flag_of(st);
     const SilWs w = sil_ws(ws, B, NV, NF, size);
-    hipLaunchKernelGGL(sil_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, verts, K, faces, NV, NF, size, w.fc, w.fbox, w.visible, w.zbuf, w.cnt, w.ticket, skip);
+    hipLaunchKernelGGL(sil_setup_kernel, dim3((2 * NF + 255) / 256, B), dim3(256), 0, st, verts, K, faces, NV, NF, size, w.fc, w.fbox, w.visible, w.zbuf, w.cnt, w.ticket, w.nvis, w.ftick, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_scatter_kernel, dim3((NF + 4 * (64 / SIL_GS) - 1) / (4 * (64 / SIL_GS)), B), dim3(256), 0, st, w.fc, w.fbox, NF, size, w.zbuf, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_image_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, w.zbuf, NV, NF, size, keep, ref, occ, B, gscale / (float)B, term, face_index,
-                       d_image, (float *)nullptr, w.visible, w.rowmask, w.colmask, w.gproj, w.cnt, w.ticket, skip);
+                       d_image, (float *)nullptr, w.visible, w.rowmask, w.colmask, w.gproj, w.cnt, w.ticket, w.nvis, w.vlist, w.ftick, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
-                       w.rowmask, w.colmask, eps, w.gproj, skip);
+                       w.rowmask, w.colmask, eps, w.gproj, SIL_COMPACT ? w.nvis : (const int *)nullptr, SIL_COMPACT ? w.vlist : (const int *)nullptr, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, skip);
+    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, w.cnt, occ, B, term, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -719,9 +774,9 @@ extern "C" int vt_sil_backward(const float *verts, int B, int NV, const int *fac
     hipLaunchKernelGGL(sil_sweep_mask_kernel, dim3((size / 64) * (size / 64), B), dim3(256), 0, st, face_index, d_image, size, w.rowmask, w.colmask, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(sil_bwd_face_kernel, dim3((NF + 4 * (64 / SIL_G) - 1) / (4 * (64 / SIL_G)), B), dim3(256), 0, st, w.fc, w.visible, faces, NV, NF, size, face_index, d_image,
-                       w.rowmask, w.colmask, eps, w.gproj, skip);
+                       w.rowmask, w.colmask, eps, w.gproj, (const int *)nullptr, (const int *)nullptr, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, skip);
+    hipLaunchKernelGGL(sil_unproject_kernel, dim3((NV + 255) / 256, B), dim3(256), 0, st, verts, K, NV, w.gproj, dverts, (const unsigned long long *)nullptr, (const float *)nullptr, B, (double *)nullptr, skip);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

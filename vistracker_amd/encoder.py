@@ -97,6 +97,16 @@ class HGFilterEncoder:
     # GroupNorm statistics of a block's input from the partial sums its PRODUCER left behind (previous block's epilogue, pooling, up-sampling, the 1 x 1
     # sum at the end of a stack) instead of a statistics pass over the tensor; False = round 2's passes (A/B, tests)
     producer_stats = True
+    # Which route every convolution of a pass took (a checkpoint with other widths must not quietly measure MIOpen): ``routes`` counts
+    # "hip3x3" / "hip1x1" / "miopen:<layer>" per call; with ``strict_routes`` any convolution other than the 7 x 7 stem that leaves the HIP kernels raises.
+    strict_routes = os.environ.get("VT_ENCODER_STRICT_ROUTES", "0") != "0"
+
+    def _miopen(self, what, x, w, b=None, stride=1, padding=0):
+        self.routes["miopen:" + what] += 1
+        if self.strict_routes and what != "stem7x7" and x.is_cuda and self.use_hip_conv:
+            raise L.VtError(f"HGFilterEncoder: convolution '{what}' (weight {tuple(w.shape)}, input {tuple(x.shape)}) is not served by the HIP kernels and "
+                            f"VT_ENCODER_STRICT_ROUTES is set")
+        return F.conv2d(x, w, b, stride, padding)
 
     def __init__(self, sd: dict, prefix: str, num_stack=3, num_hourglass=2, norm="group", hg_down="ave_pool", device="cuda:0"):
         """``sd``: state dict (tensors or arrays); ``prefix`` e.g. 'image_filter.' or 'triplane_encoder.' (a leading 'module.' is stripped)"""
@@ -114,6 +124,8 @@ class HGFilterEncoder:
             raise KeyError(f"no encoder weights under prefix '{prefix}'")
         self.in_channels = self.sd["conv1.weight"].shape[1]
         self._conv_handles = {}
+        import collections
+        self.routes = collections.Counter()
 
     def __del__(self):
         try:
@@ -166,6 +178,7 @@ class HGFilterEncoder:
         if want_stats:
             tiles = lib.vt_conv3x3_tiles(H, W)
             ws_out = torch.empty(B * 32 + tiles * B * cout * 2, dtype=torch.float64, device=x.device)
+        self.routes["hip1x1"] += 1
         L.check(lib.vt_conv1x1_forward(self._conv1x1_handle(wname, bname, x.device), x.data_ptr(), Cin, 0,
                                        gn[0].data_ptr() if gn else None, sd[gn[1] + ".weight"].data_ptr() if gn else None, sd[gn[1] + ".bias"].data_ptr() if gn else None, 32,
                                        B, H, W, out.data_ptr(), cout, 0, res.data_ptr() if res is not None else None, cout, 0,
@@ -192,9 +205,9 @@ class HGFilterEncoder:
         if x.is_cuda and all(self._hip_conv_ok(p + f"conv{i}.weight", H, W, True) for i in (1, 2, 3)):
             return self._conv_block_fused(x, p, couts)
         if not (x.is_cuda and any(self._hip_conv_ok(p + f"conv{i}.weight", H, W, True) for i in (1, 2, 3))):
-            o1 = F.conv2d(_gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
-            o2 = F.conv2d(_gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
-            o3 = F.conv2d(_gn(o2, sd, p + "bn3", relu=True), sd[p + "conv3.weight"], None, 1, 1)
+            o1 = self._miopen(p + "conv1", _gn(x, sd, p + "bn1", relu=True), sd[p + "conv1.weight"], None, 1, 1)
+            o2 = self._miopen(p + "conv2", _gn(o1, sd, p + "bn2", relu=True), sd[p + "conv2.weight"], None, 1, 1)
+            o3 = self._miopen(p + "conv3", _gn(o2, sd, p + "bn3", relu=True), sd[p + "conv3.weight"], None, 1, 1)
             out = torch.cat((o1, o2, o3), 1)
         else:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -216,20 +229,21 @@ class HGFilterEncoder:
                         L.check(lib.vt_groupnorm_finalize(ws.data_ptr(), tiles, B, H * W, C, 32, 1e-5, L.stream_ptr()))
                     nxt = i < 3 and self._hip_conv_ok(p + f"conv{i + 1}.weight", H, W, True)
                     ws_out = torch.empty(B * 32 + tiles * B * co * 2, dtype=torch.float64, device=x.device) if nxt else None
+                    self.routes["hip3x3"] += 1
                     L.check(lib.vt_conv3x3_forward_gn_stats(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(),
                                                             sd[gn + ".weight"].data_ptr(), sd[gn + ".bias"].data_ptr(), 32, B, H, W, out.data_ptr(), Ct, off,
                                                             ws_out.data_ptr() if nxt else None, 32, L.stream_ptr()))
                     ws_prev = ws_out
                 else:
                     xin = src if (cstride == C and coff == 0) else src[:, coff:coff + C]
-                    out[:, off:off + co] = F.conv2d(_gn(xin, sd, gn, relu=True), sd[wn], None, 1, 1)
+                    out[:, off:off + co] = self._miopen(wn[:-7], _gn(xin, sd, gn, relu=True), sd[wn], None, 1, 1)
                     ws_prev = None
                 src, cstride, coff, C = out, Ct, off, co
                 off += co
         if p + "downsample.2.weight" in sd:
             # downsample = Sequential(bn4, ReLU, conv1x1): the norm is the module the state dict also lists as "bn4" (same tensors in a
             # real checkpoint); "downsample.0" is the name that is loaded last, i.e. the one the reference ends up using
-            x = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"])
+            x = self._miopen(p + "downsample", _gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"])
         return out + x
 
     def _conv_block_fused(self, x, p, couts):
@@ -251,7 +265,7 @@ class HGFilterEncoder:
                 # the projection's GroupNorm normalises the same tensor as bn1: same {mean, rstd}, its own gamma / beta, fused into the staging
                 res = self._conv1x1(x, p + "downsample.2.weight", None, gn=(ws, p + "downsample.0"))
             else:
-                res = F.conv2d(_gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"]).contiguous(memory_format=torch.channels_last)
+                res = self._miopen(p + "downsample", _gn(x, sd, p + "downsample.0", relu=True), sd[p + "downsample.2.weight"]).contiguous(memory_format=torch.channels_last)
         assert res.shape[1] == Ct
         raw = torch.empty(B, Cr, H, W, device=x.device, memory_format=torch.channels_last)
         fin = torch.empty(B, Ct, H, W, device=x.device, memory_format=torch.channels_last)
@@ -260,6 +274,7 @@ class HGFilterEncoder:
         for i, co in zip((1, 2, 3), couts):
             wn, gn = p + f"conv{i}.weight", p + f"bn{i}"
             ws_out = torch.empty(B * 32 + tiles * B * co * 2, dtype=torch.float64, device=x.device) if i < 3 else None
+            self.routes["hip3x3"] += 1
             L.check(lib.vt_conv3x3_forward_block_stats(self._conv_handle(wn, x.device), src.data_ptr(), cstride, coff, ws.data_ptr(), sd[gn + ".weight"].data_ptr(),
                                                        sd[gn + ".bias"].data_ptr(), 32, B, H, W, raw.data_ptr() if i < 3 else None, Cr, off if i < 3 else 0,
                                                        res.data_ptr(), Ct, off, fin.data_ptr(), Ct, off, ws_out.data_ptr() if i < 3 else None, 32,
@@ -285,7 +300,7 @@ class HGFilterEncoder:
         """x (B,C,H,W) -> (outputs [num_stack x (B,hourglass_dim,H/4,W/4)], tmpx (B,tmpx_dim,H/2,W/2), normx (B,128,H/4,W/4)); channels-last"""
         sd = self.sd
         x = x.to(self.device).float().contiguous(memory_format=torch.channels_last)
-        x = _gn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1", relu=True)
+        x = _gn(self._miopen("stem7x7", x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1", relu=True)
         tmpx = x
         x = self._conv_block(x, "conv2.")
         x = avgpool2x2(x) if self.producer_stats else F.avg_pool2d(x, 2, stride=2)
@@ -306,11 +321,11 @@ class HGFilterEncoder:
                     tmp = self._conv1x1(raw, f"bl{i}.weight", f"bl{i}.bias", gn=(ws, f"bn_end{i}"), res=previous)
                     previous, _ = self._conv1x1(out, f"al{i}.weight", f"al{i}.bias", res=tmp, want_stats=True)      # the next stack's b1 normalises it
                 continue
-            ll = _gn(F.conv2d(ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}", relu=True)
-            out = F.conv2d(ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
+            ll = _gn(self._miopen(f"conv_last{i}", ll, sd[f"conv_last{i}.weight"], sd[f"conv_last{i}.bias"]), sd, f"bn_end{i}", relu=True)
+            out = self._miopen(f"l{i}", ll, sd[f"l{i}.weight"], sd[f"l{i}.bias"])
             outputs.append(out)
             if i < self.num_stack - 1:
-                previous = previous + F.conv2d(ll, sd[f"bl{i}.weight"], sd[f"bl{i}.bias"]) + F.conv2d(out, sd[f"al{i}.weight"], sd[f"al{i}.bias"])
+                previous = previous + self._miopen(f"bl{i}", ll, sd[f"bl{i}.weight"], sd[f"bl{i}.bias"]) + self._miopen(f"al{i}", out, sd[f"al{i}.weight"], sd[f"al{i}.bias"])
         return outputs, tmpx, normx
 
 
@@ -331,6 +346,15 @@ class SIFNetEncoder:
     def from_state_dict(cls, sd, **kw):
         keys = [k[7:] if k.startswith("module.") else k for k in sd]
         return cls(sd, shared_encoder=any(k.startswith("triplane_encoder.") for k in keys), **kw)
+
+    def route_report(self):
+        """convolution routes taken since construction, summed over the image and triplane encoders: {'hip3x3': n, 'hip1x1': n, 'miopen:<layer>': n}
+        (under a captured HIP graph only the capture pass counts)"""
+        import collections
+        c = collections.Counter()
+        for e in {id(e): e for e in [self.image] + list(self.tri)}.values():
+            c.update(e.routes)
+        return dict(c)
 
     chunk = 16      # frames per encoder pass
     _full_chunk_seen = False

@@ -226,6 +226,8 @@ class FitContext:
     # phase 'sil' of the fused step: the silhouette term as ONE call of 5 launches (vt_sil_step) instead of vt_sil_forward + vt_sil_mask_loss + vt_sil_backward
     # (10 launches); bit-identical gradients (tests/test_gpu_parity.py::test_sil_step_equals_the_separate_launches)
     fused_sil_step = os.environ.get("VT_FUSED_SIL_STEP", "1") != "0"
+    # phases 'object only' / 'sil': the temporal stencils inside the step's tail (vt_objstep_tail_temporal) instead of a launch of their own; bit-identical parameters
+    fused_tail_temporal = os.environ.get("VT_FUSED_TAIL_TEMPORAL", "1") != "0"
     # SMPL stage: keypoint chain as one launch + the query adding its gradient and the vertex acceleration stencil in its epilogue (vt_kpts_step /
     # vt_query_human_step: 8 launches per step instead of 11, bit-identical).  MEASURED SLOWER and therefore off: the twelve neighbour-frame loads per
     # point in the tail of the dominant kernel cost it 1 % (1.684 -> 1.700 ms), more than the three small launches it replaces were worth behind
@@ -716,9 +718,12 @@ class FitContext:
             _chk(lib.vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
                                           occ.data_ptr(), float(w[0]), dX.data_ptr(), terms.ptr("object"), st))
             _ev_end(prof, "object", ev, B, k)
-        if B >= 4:
+        # phases 'object only' / 'sil': nothing adds to dX between the stencils and the tail, so the tail evaluates them itself (vt_objstep_tail_temporal: the same
+        # float additions in the same order, one launch less per step); phase 'joint' keeps the stencil launch (the contact term's additions come after it)
+        tail_temporal = B >= 4 and phase != "joint" and self.fused_tail_temporal
+        if B >= 4 and not tail_temporal:
             _chk(lib.vt_temporal_loss2(X.data_ptr(), B, N * 3, float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), dX.data_ptr(), int(is_sil), st))
-        elif is_sil:
+        elif is_sil and not tail_temporal:
             _chk(lib.vt_fill(dX.data_ptr(), dX.numel(), 0.0, st))
         if is_sil and self.fused_sil_step:
             # the silhouette term of the step in 5 launches (vt_sil_step) instead of the 10 of the three calls below: same arithmetic, bit-identical gradients
@@ -745,10 +750,14 @@ class FitContext:
                 gR = (p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), lr_)
             else:
                 gT = (p_.data_ptr(), m_.data_ptr(), v_.data_ptr(), lr_)
-        _chk(lib.vt_objstep_tail(self.obj_verts.data_ptr() if is_sil else None, NV, dVt.data_ptr() if is_sil else None, self.obj_points.data_ptr(), N, dX.data_ptr(),
-                                 obj_s.data_ptr(), B, obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), trans_init.data_ptr() if is_sil else None, float(w[4]),
-                                 terms.ptr("trans"), dR.data_ptr(), dt.data_ptr(), dM.data_ptr(), *gR, *gT, adam.t, 0.9, 0.999, 1e-8,
-                                 terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, st))
+        tail_args = (self.obj_verts.data_ptr() if is_sil else None, NV, dVt.data_ptr() if is_sil else None, self.obj_points.data_ptr(), N, dX.data_ptr(),
+                     obj_s.data_ptr(), B, obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), trans_init.data_ptr() if is_sil else None, float(w[4]),
+                     terms.ptr("trans"), dR.data_ptr(), dt.data_ptr(), dM.data_ptr(), *gR, *gT, adam.t, 0.9, 0.999, 1e-8,
+                     terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, st)
+        if tail_temporal:
+            _chk(lib.vt_objstep_tail_temporal(X.data_ptr(), float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), int(is_sil), *tail_args))
+        else:
+            _chk(lib.vt_objstep_tail(*tail_args))
 
     def _contact_term(self, contact, X, dX, w, terms):
         """the contact Chamfer term of a 'joint' step (recon_fit_trivis_full.py:449-457): the object-side contact points are read out of X and their gradient
