@@ -161,6 +161,18 @@ __device__ __forceinline__ bool sil_inside(const float (&fc)[9], float xp, float
 #define SIL_FAST_Z 1
 #endif
 #define SIL_RIM 0.015625f
+// the visibility vote.  SIL_ZPRETEST: look before the atomic -- keys only ever decrease, so a (possibly stale) value that is already below this face's key means
+// the atomic cannot change anything; a stale larger value only costs the atomic it would have cost anyway
+#ifndef SIL_ZPRETEST
+#define SIL_ZPRETEST 0
+#endif
+__device__ __forceinline__ void sil_zmin(unsigned long long *p, unsigned long long key)
+{
+#if SIL_ZPRETEST
+    if (*(volatile unsigned long long *)p <= key) return;
+#endif
+    atomicMin(p, key);
+}
 __device__ __forceinline__ void sil_vote(const float (&fc)[9], float den, int f2, float xp, float yp, int xi, int yi, int is, unsigned long long *__restrict__ zrow)
 {
     const float n0 = (fc[4] - fc[7]) * xp + (fc[6] - fc[3]) * yp + (fc[3] * fc[7] - fc[6] * fc[4]);
@@ -175,7 +187,7 @@ __device__ __forceinline__ void sil_vote(const float (&fc)[9], float den, int f2
             const float ws_ = a0 + a1 + a2;
             const float zp_ = ws_ * __builtin_amdgcn_rcpf(a0 * __builtin_amdgcn_rcpf(fc[2]) + a1 * __builtin_amdgcn_rcpf(fc[5]) + a2 * __builtin_amdgcn_rcpf(fc[8]));
             if (!(zp_ > SIL_NEAR * 1.001f && zp_ < SIL_FAR * 0.999f)) goto exact;            // (at the clipping planes the exact value decides)
-            atomicMin(zrow + (size_t)yi * is + xi, ((unsigned long long)__float_as_uint(zp_) << 32) | (unsigned)f2);
+            sil_zmin(zrow + (size_t)yi * is + xi, ((unsigned long long)__float_as_uint(zp_) << 32) | (unsigned)f2);
             return;
         }
     }
@@ -189,7 +201,7 @@ exact:
     const float zp = 1.0f / (w0 / ws / fc[2] + w1 / ws / fc[5] + w2 / ws / fc[8]);
     if (!(zp > SIL_NEAR && zp < SIL_FAR)) return;
     const unsigned long long key = ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)f2;     // zp > 0: float order == uint order
-    atomicMin(zrow + (size_t)yi * is + xi, key);
+    sil_zmin(zrow + (size_t)yi * is + xi, key);
 }
 // pixels start, start + stride, ... < npx of the box (x0, y0, width w) of face f2 with corners fc (the whole-wave path of large boxes)
 __device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den, int f2, int x0, int y0, int w, int npx, int start, int stride, int is,

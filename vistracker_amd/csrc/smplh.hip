@@ -40,7 +40,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define KG_SLAB 24                   /* 16-row K groups per split-K slab (384 rows) */
 #define NKS_ (KTOT_ / 16 / KG_SLAB)  /* 54 slabs */
 
-struct SmplParents { int p[J_]; };
+// parents + the reverse-chain schedule of smplh_bwd_frame_kernel (built once in vt_smplh_create): step t pushes the joints sched[t][0..9] (-1: none) into their
+// parents at the same time -- deepest tree level first, inside a level by sibling rank, so that the joints of a step have different parents, a parent receives its
+// children in descending index order and every joint is complete before it is pushed; nsteps = 0: no schedule (a tree outside its limits), the serial loop runs
+#define SCHED_STEPS 32
+#define SCHED_WIDTH 10
+struct SmplParents { int p[J_]; int nsteps; short sched[SCHED_STEPS][SCHED_WIDTH]; };
 
 #define SP_K 8                          /* most non-zero skinning weights per vertex the sparse LBS takes (SMPL / SMPL-H: 4) */
 struct vt_smplh {
@@ -137,12 +142,21 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
             sJ[j * 3 + c] = a; w[WS_J + j * 3 + c] = a;
         }
     }
+    // G_0 = [R_0 | J_0];  G_i = G_parent . [R_i | J_i - J_parent].  Round 6: the chain by tree LEVEL (SMPL-H: 11 levels for 52 joints), lane = joint, instead of
+    // one thread walking the 51 joints in turn (15 us of dependent LDS round trips): every joint's twelve values are the same expressions -- bit-identical.
+    __shared__ int sPar[J_];
+    if (j < J_) sPar[j] = par.p[j];
     __syncthreads();
-    if (j == 0) {
-        // G_0 = [R_0 | J_0];  G_i = G_parent . [R_i | J_i - J_parent]
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sG[r * 4 + c] = sR[r * 3 + c]; sG[r * 4 + 3] = sJ[r]; }
-        for (int i = 1; i < J_; i++) {
-            const int p = par.p[i];
+    int lvl = 0, maxl = 0;
+    if (j < J_) { for (int q = j; q != 0; q = sPar[q]) lvl++; }
+    maxl = lvl;
+    for (int o = 32; o > 0; o >>= 1) maxl = max(maxl, __shfl_xor(maxl, o, 64));
+    maxl = __builtin_amdgcn_readfirstlane(maxl);
+    if (j == 0) { for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sG[r * 4 + c] = sR[r * 3 + c]; sG[r * 4 + 3] = sJ[r]; } }
+    __syncthreads();
+    for (int l = 1; l <= maxl; l++) {
+        if (j < J_ && lvl == l) {
+            const int i = j, p = sPar[i];
             const float *Gp = sG + 12 * p, *Ri = sR + 9 * i;
             const float d0 = sJ[3 * i] - sJ[3 * p], d1 = sJ[3 * i + 1] - sJ[3 * p + 1], d2 = sJ[3 * i + 2] - sJ[3 * p + 2];
             float *Gi = sG + 12 * i;
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
                 Gi[r * 4 + 3] = g0 * d0 + g1 * d1 + g2 * d2 + Gp[r * 4 + 3];
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     if (j < J_) {
         // A_j = G_j - [0 | G_rot J_j]   (th_results2, smpl_layer.py:133-143);  jtr = G_t + trans (:154,172)
         const float *G = sG + 12 * j;
@@ -500,26 +514,33 @@ __global__ __launch_bounds__(256) void smplh_bwd_frame_kernel(const float *__res
     __syncthreads();
     // reverse kinematic chain: joints strictly in order (a parent collects all its children), but the 24 outputs of one joint --
     // 12 of d G_parent, 9 of d R_j, 3 of d J -- are independent: one thread each, one barrier per joint
-    for (int j = J_ - 1; j >= 1; j--) {
-        const int p = par.p[j];
-        const float *Gp = sG + 12 * p, *Rj = sRm + 9 * j, *dGj = sdG + 12 * j;
-        float upd = 0.f; float *dst = nullptr; float upd2 = 0.f; float *dst2 = nullptr;
-        if (tid < 12) {
-            const int r = tid >> 2, c = tid & 3;
-            dst = sdG + 12 * p + tid;
-            if (c < 3) upd = dGj[r * 4] * Rj[3 * c] + dGj[r * 4 + 1] * Rj[3 * c + 1] + dGj[r * 4 + 2] * Rj[3 * c + 2] + dGj[r * 4 + 3] * (sJr[3 * j + c] - sJr[3 * p + c]);
-            else upd = dGj[r * 4 + 3];
-        } else if (tid < 21) {
-            const int e = tid - 12, r = e / 3, c = e - 3 * r;
-            dst = sdR + 9 * j + e;
-            upd = Gp[r] * dGj[c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
-        } else if (tid < 24) {
-            const int c = tid - 21;
-            upd = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
-            dst = sdJ + 3 * j + c; dst2 = sdJ + 3 * p + c; upd2 = -upd;
+    // Round 6: by tree level, deepest first, and inside a level by sibling rank (SmplParents::sched): up to ten joints -- 24 threads each -- per barrier interval,
+    // the additions of the serial loop in their order (bit-identical), ~20 intervals instead of 51.
+    const int jloc = tid / 24, el = tid - 24 * jloc;          // thread = (which joint of the step, which of its 24 outputs)
+    const int nsteps = par.nsteps > 0 ? par.nsteps : J_ - 1;
+    for (int step = 0; step < nsteps; step++) {
+        const int j = par.nsteps > 0 ? (jloc < SCHED_WIDTH ? (int)par.sched[step][jloc < SCHED_WIDTH ? jloc : 0] : -1) : (jloc == 0 ? J_ - 1 - step : -1);
+        if (j >= 1) {
+            const int p = par.p[j];
+            const float *Gp = sG + 12 * p, *Rj = sRm + 9 * j, *dGj = sdG + 12 * j;
+            float upd = 0.f; float *dst = nullptr; float upd2 = 0.f; float *dst2 = nullptr;
+            if (el < 12) {
+                const int r = el >> 2, c = el & 3;
+                dst = sdG + 12 * p + el;
+                if (c < 3) upd = dGj[r * 4] * Rj[3 * c] + dGj[r * 4 + 1] * Rj[3 * c + 1] + dGj[r * 4 + 2] * Rj[3 * c + 2] + dGj[r * 4 + 3] * (sJr[3 * j + c] - sJr[3 * p + c]);
+                else upd = dGj[r * 4 + 3];
+            } else if (el < 21) {
+                const int e = el - 12, r = e / 3, c = e - 3 * r;
+                dst = sdR + 9 * j + e;
+                upd = Gp[r] * dGj[c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
+            } else {
+                const int c = el - 21;
+                upd = Gp[c] * dGj[3] + Gp[4 + c] * dGj[7] + Gp[8 + c] * dGj[11];
+                dst = sdJ + 3 * j + c; dst2 = sdJ + 3 * p + c; upd2 = -upd;
+            }
+            if (dst) *dst += upd;
+            if (dst2) *dst2 += upd2;
         }
-        if (dst) *dst += upd;
-        if (dst2) *dst2 += upd2;
         __syncthreads();
     }
     if (tid < 3) { for (int c = 0; c < 3; c++) sdR[3 * tid + c] += sdG[tid * 4 + c]; sdJ[tid] += sdG[tid * 4 + 3]; }
@@ -555,6 +576,20 @@ extern "C" int vt_smplh_create(vt_smplh **out, const float *v_template, const fl
     vt_smplh *h = new vt_smplh();
     for (int j = 0; j < J_; j++) h->par.p[j] = (j == 0) ? 0 : parents[j];
     for (int j = 1; j < J_; j++) VT_REQUIRE(h->par.p[j] >= 0 && h->par.p[j] < j, "vt_smplh_create: parents[%d]=%d must be in [0,%d)", j, parents[j], j);
+    {   // reverse-chain schedule (SmplParents): slot of joint j = (tree level, rank among its siblings by descending index); steps = distinct slots, deepest first
+        int lvl[J_], rank[J_], maxl = 0;
+        lvl[0] = 0; rank[0] = 0;
+        for (int j = 1; j < J_; j++) { lvl[j] = lvl[h->par.p[j]] + 1; maxl = std::max(maxl, lvl[j]); rank[j] = 0; for (int k = j + 1; k < J_; k++) rank[j] += (h->par.p[k] == h->par.p[j]); }
+        int n = 0; bool ok = true;
+        for (int t = 0; t < SCHED_STEPS; t++) for (int i = 0; i < SCHED_WIDTH; i++) h->par.sched[t][i] = -1;
+        for (int l = maxl; l >= 1 && ok; l--)
+            for (int r = 0; r < J_ && ok; r++) {
+                int cnt = 0;
+                for (int j = J_ - 1; j >= 1; j--) if (lvl[j] == l && rank[j] == r) { if (n >= SCHED_STEPS || cnt >= SCHED_WIDTH) { ok = false; break; } h->par.sched[n][cnt++] = (short)j; }
+                if (cnt) n++;
+            }
+        h->par.nsteps = ok ? n : 0;
+    }
     float *Q_kcv = new float[(size_t)KQ_ * 3 * VP_](), *Q_t = new float[(size_t)VP_ * 3 * NQ_](), *W_jv = new float[(size_t)J_ * VP_](),
           *J_t = new float[J_ * 3], *J_s = new float[J_ * 3 * NB_];
     for (int v = 0; v < V_; v++) for (int c = 0; c < 3; c++) {

@@ -233,6 +233,8 @@ class FitContext:
     # point in the tail of the dominant kernel cost it 1 % (1.684 -> 1.700 ms), more than the three small launches it replaces were worth behind
     # the query (one stream 767.9 -> 777.8 ms per batch, two streams 690 -> 696; same box, two repetitions)
     fused_smpl_query = os.environ.get("VT_FUSED_SMPL_QUERY", "0") != "0"
+    # ... the keypoint chain alone as one launch BEHIND the query (vt_kpts_step, accumulate = 1) instead of vt_landmarks_forward + vt_kpts_loss + vt_landmarks_backward
+    fused_kpts_step = os.environ.get("VT_FUSED_KPTS_STEP", "1") != "0"
     # the query / SMPL-H launches queued behind the step that stopped a fit return at their first instruction (vt_stream_set_skip_flag)
     device_skip = os.environ.get("VT_DEVICE_SKIP", "1") != "0"
     # the host looks at the stop flag of outer iteration k only after it has queued iteration k + 1 (asynchronous copy of the flag to pinned memory + an
@@ -480,7 +482,11 @@ class FitContext:
                                                     self.labels.data_ptr(), vert_order.data_ptr() if vert_order is not None else None, float(w[0]), float(w[1]),
                                                     dverts.data_ptr(), terms.ptr("df_h"), L.stream_ptr()))
                     _ev_end(lp, "human", ev, B, res.steps)
-                    if phase == "kpts":
+                    if phase == "kpts" and fused and self.fused_kpts_step:
+                        # joints, 2-D keypoint term and its gradient ADDED to the query's (accumulate = 1: the float addition of vt_landmarks_backward) in one launch
+                        _chk(_lib().vt_kpts_step(self.b25.h, verts.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 1, self.cam.ctypes.data, net_size,
+                                                 float(w[4]), terms.ptr("j2d"), J.data_ptr(), dverts.data_ptr(), 1, L.stream_ptr()))
+                    elif phase == "kpts":
                         _chk(_lib().vt_landmarks_forward(self.b25.h, verts.data_ptr(), B, J.data_ptr(), L.stream_ptr()))
                         _chk(_lib().vt_kpts_loss(J.data_ptr(), body_kpts.data_ptr(), crop_center.data_ptr(), B, 25, 1, self.cam.ctypes.data, net_size,
                                                  float(w[4]), terms.ptr("j2d"), dJ.data_ptr(), L.stream_ptr()))
