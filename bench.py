@@ -209,10 +209,9 @@ def solo_kernel_leg(ctx, torch, d, launches=20, fp32=False):
     return solo
 
 
-# Box calibration.  Reference values: the box of profiles/r06_calibration_reference.txt, on which round 5's kernel (the library of commit
-# a8c3e7f) took CALIB_REF["r05_solo_ms"] per launch in this very leg -- so a later line can be read as "kernel x box": solo_launch_ms_at_reference_box rescales the
-# measured solo time by the matrix-pipe rate of the box it ran on.
-CALIB_REF = {"mfma_f16_tflops": None, "sustained_mhz": None, "l2_delivery_TBps": None, "r05_solo_ms": None}
+# Box calibration: what THIS box's matrix pipe, clock and L2 path deliver right before / after the solo launches (csrc/calib.hip), next to the
+# launch in shader clocks (solo_launch_Mclk: the query kernel samples the clock itself) -- so that a line can be read as kernel x box.  The comparison of two KERNELS at
+# equal calibration is a same-box A/B (profiles/r06_query_ab.txt), not a rescaling.
 
 
 def calib_summary(extras, solo_ms):
@@ -222,11 +221,6 @@ def calib_summary(extras, solo_ms):
     out = dict(c); after = extras.get("calibration_after_solo")
     if isinstance(after, dict) and "error" not in after:
         out["after_solo"] = {k: after[k] for k in ("mfma_f16_tflops", "sustained_mhz", "l2_delivery_TBps")}
-    out["reference_box"] = CALIB_REF
-    if solo_ms is not None and CALIB_REF["mfma_f16_tflops"]:
-        out["solo_launch_ms_at_reference_box"] = solo_ms * c["mfma_f16_tflops"] / CALIB_REF["mfma_f16_tflops"]
-        if CALIB_REF["r05_solo_ms"]:
-            out["vs_r05_kernel_at_equal_calibration"] = out["solo_launch_ms_at_reference_box"] / CALIB_REF["r05_solo_ms"]
     return out
 
 
