@@ -7,6 +7,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( time timeout 3000 python -m pytest tests -m gpu -q --durations=15 ) > gpurun_out/${tag}_pytest.log 2>&1; python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/${tag}_pytest.log 2>&1
 tail -30 gpurun_out/${tag}_pytest.log
+# the measured-negative kernel variants (512 thin waves, producer / consumer) as INDEPENDENT cross-checks of the default kernel at bench size: the
+# experiments library is not shipped to the box (gpurunignore), so it is built here; the tests pick the variants up when the library they load has them
+( make -s -C vistracker_amd/csrc experiments > gpurun_out/${tag}_exp_build.log 2>&1 && VT_LIB_PATH=$GRAFT_REPO_ROOT/tools/bench_scripts/_exp/libvistracker_hip_exp.so timeout 900 python -m pytest tests/test_gpu_fullsize.py -m gpu -q -k fused_query 2>&1 | grep -v amdgpu | tail -3 ) | tee gpurun_out/${tag}_exp_crosscheck.txt
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/${tag}_bench_driver_cmd.json 2> gpurun_out/${tag}_bench.err
 tail -c 3000 gpurun_out/${tag}_bench_driver_cmd.json; tail -5 gpurun_out/${tag}_bench.err
 grep -h '^{' gpurun_out/${tag}_bench_driver_cmd.json | python -c "
