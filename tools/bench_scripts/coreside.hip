@@ -21,3 +21,11 @@ extern "C" int cs_spin(int vgprs, int blocks, long long clocks, float *sink, voi
     else hipLaunchKernelGGL(spin<128>, dim3(blocks), dim3(256), 0, st, clocks, sink);
     return (int)hipGetLastError();
 }
+
+// a stream whose kernels may only run on the CUs of `mask` (8 x 32 bits; hipExtStreamCreateWithCUMask): packs the co-running kernels on few CUs
+extern "C" void *cs_masked_stream(const unsigned *mask, int words)
+{
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) return nullptr;
+    return (void *)st;
+}

@@ -47,3 +47,18 @@ for vg in (24, 64, 128, 24, 64):
     torch.cuda.synchronize()
     q = e0.elapsed_time(e1) / 30; sp_ms = s0.elapsed_time(s1)
     print(f"beside spin<{vg} VGPRs> ({blocks} blocks x {us:.0f} us, {n_spin} launches in {sp_ms:.1f} ms = {sp_ms / n_spin * 1e3:.1f} us each): query {q:.3f} ms per launch (+{100 * (q / alone - 1):.1f} %)")
+
+# ---- the same spin kernels CONFINED to a quarter / an eighth of the CUs (hipExtStreamCreateWithCUMask): does packing them cost the query less?
+cs.cs_masked_stream.restype = C.c_void_p; cs.cs_masked_stream.argtypes = [C.c_void_p, C.c_int]
+for label, words in (("every 4th CU", [0x11111111] * 8), ("every 8th CU", [0x01010101] * 8), ("CUs 0..63", [0xffffffff, 0xffffffff, 0, 0, 0, 0, 0, 0])):
+    m = (C.c_uint * 8)(*words); ms_ = cs.cs_masked_stream(m, 8)
+    if not ms_:
+        print("masked stream not available"); break
+    for vg in (64,):
+        n_spin = int(30 * alone * 1.3 / (us * 1e-3 * max(1.0, blocks * 4 / 8192.0)))
+        e0, e1 = query(30)
+        t0 = time.perf_counter()
+        for _ in range(n_spin): cs.cs_spin(vg, blocks, clk, sink.data_ptr(), ms_)
+        torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+        q = e0.elapsed_time(e1) / 30
+        print(f"spin<{vg}> confined to {label}: query {q:.3f} ms per launch (+{100 * (q / alone - 1):.1f} %), the {n_spin} spin launches took {wall:.1f} ms")
