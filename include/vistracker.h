@@ -198,6 +198,15 @@ int vt_conv3x3_forward_block(const vt_conv3x3 *h, const float *in, int in_cstrid
                              const float *res, int res_cstride, int res_coff, float *fin, int fin_cstride, int fin_coff,
                              double *stats_ws, int stats_groups, void *stream);
 int vt_conv3x3_tiles(int H, int W);
+/* The 7 x 7 / stride 2 / pad 3 convolution at the head of an encoder (model/HGFilters.py:118-130: self.conv1 = nn.Conv2d(in_ch, 64, kernel_size=7, stride=2,
+ * padding=3), applied at HGFilters.py:166 `x = F.relu(self.bn1(self.conv1(x)), True)`): plain fp32 multiply-adds like the reference's, weights as scalar
+ * operands (csrc/stem.hip).  weight (Cout, Cin, 7, 7) fp32 host, bias (Cout) fp32 host or NULL, Cout in {32, 64} (triplane / image encoder), Cin in 1..8.
+ * forward: the input is channels [in_coff, in_coff + Cin) of an NHWC tensor (B, H, W, in_cstride), the result (B, ceil(H / 2), ceil(W / 2), Cout) goes to channels [out_coff, out_coff + Cout)
+ * of an NHWC tensor with out_cstride channels (both multiples of 4).  Replaces the encoder's last MIOpen call (round 6). */
+typedef struct vt_stem7x7 vt_stem7x7;
+int vt_stem7x7_create(vt_stem7x7 **out, const float *weight, const float *bias, int cout, int cin, void *stream);
+void vt_stem7x7_destroy(vt_stem7x7 *h);
+int vt_stem7x7_forward(const vt_stem7x7 *h, const float *in, int in_cstride, int in_coff, int B, int H, int W, float *out, int out_cstride, int out_coff, void *stream);
 /* The 1 x 1 convolutions of the same encoders (conv_last / l / bl / al of a stack, the ConvBlock's down-sampling projection: model/HGFilters.py:150-203,
  * model/net_util.py:364-372) on the same split-f16 kernel (one tap, the 8 x 16 tile as the patch).  weight (Cout, Cin) fp32 host, bias (Cout) or NULL,
  * Cout in {64, 128, 256} (256 runs as two launches of 128), Cin in {32, 64, 128, 256}.  forward: out <- conv(in) + bias [+ res]; gn_stats != NULL applies

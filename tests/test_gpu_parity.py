@@ -831,6 +831,44 @@ def test_conv3x3_split_f16_vs_float64(hip, cin, cout):
     L.lib().vt_conv3x3_destroy(h)
 
 
+@pytest.mark.parametrize("cout,cin,H,W", [(64, 5, 64, 64), (32, 1, 64, 96), (64, 3, 45, 70), (32, 8, 32, 34)])
+def test_stem7x7_vs_float64(hip, cout, cin, H, W):
+    """vt_stem7x7_forward (csrc/stem.hip: the 7 x 7 / stride 2 / pad 3 convolution with bias at the head of an encoder -- 64 outputs in the image encoder, 32 in the triplane one, model/HGFilters.py:118-130,166)
+    against torch's float64 convolution on the host: fp32 FMAs in a fixed order -> fp32 rounding level; image sizes that do not fill the 16 x 16 output
+    tiles (and odd ones), input and output as channel slices of wider NHWC tensors, nothing outside the slice touched."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vistracker_amd import _lib as L
+    g = torch.Generator().manual_seed(cin * 1000 + H + W)
+    B = 3
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 7, 7, generator=g) / np.sqrt(49 * cin)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 2, 3).permute(0, 2, 3, 1).numpy()
+    H2, W2 = ref.shape[1:3]
+    assert (H2, W2) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    h = C.c_void_p()
+    wh = np.ascontiguousarray(w.numpy().reshape(cout, cin, 49)); bh = np.ascontiguousarray(b.numpy())
+    L.check(L.lib().vt_stem7x7_create(C.byref(h), wh.ctypes.data, bh.ctypes.data, cout, cin, L.stream_ptr()))
+    cs, co = cin + 3, 2                                                                                # the input is channels [2, 2 + cin) of a wider tensor
+    xw = torch.full((B, H, W, cs), 3.0); xw[..., co:co + cin] = x.permute(0, 2, 3, 1)
+    xd = xw.cuda()
+    out = torch.full((B, H2, W2, cout + 8), 7.0, device="cuda")
+    L.check(L.lib().vt_stem7x7_forward(h, L.dptr(xd), cs, co, B, H, W, L.dptr(out), cout + 8, 4, L.stream_ptr()))
+    got = npy(out)
+    assert np.abs(got[..., 4:4 + cout] - ref).max() < 2e-6 * np.abs(ref).max()
+    assert (got[..., :4] == 7.0).all() and (got[..., 4 + cout:] == 7.0).all()
+    # no bias: the plain sum
+    h0 = C.c_void_p()
+    L.check(L.lib().vt_stem7x7_create(C.byref(h0), wh.ctypes.data, None, cout, cin, L.stream_ptr()))
+    L.check(L.lib().vt_stem7x7_forward(h0, L.dptr(xd), cs, co, B, H, W, L.dptr(out), cout + 8, 4, L.stream_ptr()))
+    assert np.abs(npy(out)[..., 4:4 + cout] - (ref - b.double().numpy())).max() < 2e-6 * np.abs(ref).max()
+    # argument errors are loud
+    assert L.lib().vt_stem7x7_forward(h, L.dptr(xd), cs, cs - cin + 1, B, H, W, L.dptr(out), cout + 8, 4, L.stream_ptr()) != 0
+    assert L.lib().vt_stem7x7_create(C.byref(C.c_void_p()), wh.ctypes.data, None, 48, cin, L.stream_ptr()) != 0
+    L.lib().vt_stem7x7_destroy(h); L.lib().vt_stem7x7_destroy(h0)
+
+
 def test_conv3x3_block_step_vs_float64(hip):
     """vt_conv3x3_forward_block, one step of a ConvBlock (model/net_util.py:374-394): GroupNorm + ReLU prologue from vt_groupnorm_stats, the plain
     convolution to `out`, convolution + residual to `fin`, and the GroupNorm partial sums of the convolution's output -> vt_groupnorm_finalize gives

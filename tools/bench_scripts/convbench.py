@@ -5,7 +5,7 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from vistracker_amd import _lib as L
 lib = L.lib(); outs = {}; torch.manual_seed(0)
-for (cin, cout, hw) in ((256, 128, 128), (128, 128, 128), (256, 128, 64), (256, 128, 32)):
+for (cin, cout, hw) in ((256, 128, 128), (128, 128, 128), (256, 128, 64), (256, 128, 32), (128, 64, 128), (64, 64, 128), (128, 64, 64), (64, 64, 64), (64, 64, 32), (64, 32, 128)):
     rng = np.random.default_rng(cin + cout)
     w = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(9 * cin)).astype(np.float32)
     h = C.c_void_p(); L.check(lib.vt_conv3x3_create(C.byref(h), w.ctypes.data, cout, cin, L.stream_ptr()))

@@ -80,6 +80,9 @@ SIGNATURES = {
                               fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
     "vt_stream_set_skip_flag": (ci, [vp, vp]),
     "vt_conv1x1_create": (ci, [C.POINTER(vp), vp, vp, ci, ci, vp]),
+    "vt_stem7x7_create": (ci, [C.POINTER(vp), vp, vp, ci, ci, vp]),
+    "vt_stem7x7_destroy": (None, [vp]),
+    "vt_stem7x7_forward": (ci, [vp, fp, ci, ci, ci, ci, ci, fp, ci, ci, vp]),
     "vt_conv1x1_destroy": (None, [vp]),
     "vt_conv1x1_forward": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),
     "vt_conv3x3_forward_block": (ci, [vp, fp, ci, ci, fp, fp, fp, ci, ci, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, ci, fp, ci, vp]),

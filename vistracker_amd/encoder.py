@@ -1,8 +1,10 @@
 """Image encoders of the SIF-Net (encoder half): inference-only mirror of ``model.HGFilters.HGFilter``
 (HGFilters.py:4-203) and of the encoder part of ``CHORETriplane.filter`` (chore.py:128-144, chore_triplane.py:60-95).
 
-The encoder is dense 2-D convolution work that runs ONCE per frame (613 GFLOP/frame); following the survey's plan it
-is expressed on the vendor convolution library (MIOpen through ``torch.nn.functional``: PyTorch-ROCm is the plumbing), in
+The encoder is dense 2-D convolution work that runs ONCE per frame (613 GFLOP/frame).  Round 1 expressed it on the vendor
+convolution library (MIOpen through ``torch.nn.functional``); since round 6 every convolution of the shipped configuration runs on the library's own
+kernels (csrc/conv.hip: 3 x 3 and 1 x 1 as split-f16 implicit GEMMs; csrc/stem.hip: the 7 x 7 stem in fp32) and ``torch.nn.functional`` is only the
+counted fallback for layer shapes those kernels do not serve (``routes``, ``strict_routes``) and the host path of the CPU tests.  Everything is in
 channels-last memory format so that the outputs ARE the NHWC feature maps the fused query kernel gathers from -- no NCHW->NHWC pass.
 Weights are addressed by the reference's ``state_dict`` names, so a VisTracker checkpoint loads unchanged:
 
@@ -92,18 +94,21 @@ def _gn(x, sd, p, groups=32, relu=False):
 
 class HGFilterEncoder:
     # 3x3 convolutions with 32 / 64 / 128 output channels and Cin % 32 == 0 and the 1x1 convolutions (conv_last / l / bl / al of a stack, the
-    # ConvBlocks' projections) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_* / vt_conv1x1_*); the 7x7 stem stays on MIOpen
+    # ConvBlocks' projections) run on the split-f16 implicit-GEMM kernel (csrc/conv.hip, vt_conv3x3_* / vt_conv1x1_*); the 7x7 stem (Cout 32 / 64, Cin <= 8) on
+    # the fp32 kernel of csrc/stem.hip (round 6: until then the encoder's one MIOpen call).  Other shapes fall back to MIOpen -- counted, and refused
+    # in strict mode.
     use_hip_conv = True
     # GroupNorm statistics of a block's input from the partial sums its PRODUCER left behind (previous block's epilogue, pooling, up-sampling, the 1 x 1
     # sum at the end of a stack) instead of a statistics pass over the tensor; False = round 2's passes (A/B, tests)
     producer_stats = True
     # Which route every convolution of a pass took (a checkpoint with other widths must not quietly measure MIOpen): ``routes`` counts
-    # "hip3x3" / "hip1x1" / "miopen:<layer>" per call; with ``strict_routes`` any convolution other than the 7 x 7 stem that leaves the HIP kernels raises.
+    # "hip7x7" / "hip3x3" / "hip1x1" / "miopen:<layer>" per call; with ``strict_routes`` any convolution that leaves the HIP kernels raises.
     strict_routes = os.environ.get("VT_ENCODER_STRICT_ROUTES", "0") != "0"
+    use_hip_stem = os.environ.get("VT_ENCODER_HIP_STEM", "1") != "0"        # 0: the stem on MIOpen as before round 6 (A/B only)
 
     def _miopen(self, what, x, w, b=None, stride=1, padding=0):
         self.routes["miopen:" + what] += 1
-        if self.strict_routes and what != "stem7x7" and x.is_cuda and self.use_hip_conv:
+        if self.strict_routes and x.is_cuda and self.use_hip_conv:
             raise L.VtError(f"HGFilterEncoder: convolution '{what}' (weight {tuple(w.shape)}, input {tuple(x.shape)}) is not served by the HIP kernels and "
                             f"VT_ENCODER_STRICT_ROUTES is set")
         return F.conv2d(x, w, b, stride, padding)
@@ -130,7 +135,7 @@ class HGFilterEncoder:
     def __del__(self):
         try:
             for k, h in getattr(self, "_conv_handles", {}).items():
-                (L.lib().vt_conv1x1_destroy if k.startswith("1x1:") else L.lib().vt_conv3x3_destroy)(h)
+                (L.lib().vt_conv1x1_destroy if k.startswith("1x1:") else L.lib().vt_stem7x7_destroy if k.startswith("7x7:") else L.lib().vt_conv3x3_destroy)(h)
         except Exception:
             pass
 
@@ -145,6 +150,27 @@ class HGFilterEncoder:
                 L.check(L.lib().vt_conv3x3_create(C.byref(h), wh.ctypes.data, cout, cin, L.stream_ptr()))
             self._conv_handles[name] = h
         return h
+
+    def _stem(self, x):
+        """conv1 (HGFilters.py:118-130, 7 x 7 / stride 2 / pad 3 with bias) -> channels-last (B, 64, ceil(H/2), ceil(W/2))"""
+        import ctypes as C
+        w = self.sd["conv1.weight"]; cout, cin = w.shape[:2]
+        if not (x.is_cuda and self.use_hip_conv and self.use_hip_stem and cout in (32, 64) and cin <= 8 and tuple(w.shape[2:]) == (7, 7)):
+            return self._miopen("stem7x7", x, w, self.sd.get("conv1.bias"), 2, 3)
+        h = self._conv_handles.get("7x7:conv1")
+        if h is None:
+            wh = np.ascontiguousarray(w.contiguous().cpu().numpy().reshape(cout, cin, 49), np.float32)
+            bh = np.ascontiguousarray(self.sd["conv1.bias"].cpu().numpy(), np.float32) if "conv1.bias" in self.sd else None
+            h = C.c_void_p()
+            with torch.cuda.device(x.device):
+                L.check(L.lib().vt_stem7x7_create(C.byref(h), wh.ctypes.data, bh.ctypes.data if bh is not None else None, cout, cin, L.stream_ptr()))
+            self._conv_handles["7x7:conv1"] = h
+        B, _, H, W = x.shape
+        x = x.contiguous(memory_format=torch.channels_last)
+        y = torch.empty(B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device, memory_format=torch.channels_last)
+        self.routes["hip7x7"] += 1
+        L.check(L.lib().vt_stem7x7_forward(h, x.data_ptr(), cin, 0, B, H, W, y.data_ptr(), cout, 0, L.stream_ptr()))
+        return y
 
     def _conv1x1_handle(self, wname, bname, device):
         import ctypes as C
@@ -300,7 +326,7 @@ class HGFilterEncoder:
         """x (B,C,H,W) -> (outputs [num_stack x (B,hourglass_dim,H/4,W/4)], tmpx (B,tmpx_dim,H/2,W/2), normx (B,128,H/4,W/4)); channels-last"""
         sd = self.sd
         x = x.to(self.device).float().contiguous(memory_format=torch.channels_last)
-        x = _gn(self._miopen("stem7x7", x, sd["conv1.weight"], sd["conv1.bias"], 2, 3), sd, "bn1", relu=True)
+        x = _gn(self._stem(x), sd, "bn1", relu=True)
         tmpx = x
         x = self._conv_block(x, "conv2.")
         x = avgpool2x2(x) if self.producer_stats else F.avg_pool2d(x, 2, stride=2)
@@ -348,7 +374,7 @@ class SIFNetEncoder:
         return cls(sd, shared_encoder=any(k.startswith("triplane_encoder.") for k in keys), **kw)
 
     def route_report(self):
-        """convolution routes taken since construction, summed over the image and triplane encoders: {'hip3x3': n, 'hip1x1': n, 'miopen:<layer>': n}
+        """convolution routes taken since construction, summed over the image and triplane encoders: {'hip7x7': n, 'hip3x3': n, 'hip1x1': n, 'miopen:<layer>': n}
         (under a captured HIP graph only the capture pass counts)"""
         import collections
         c = collections.Counter()
