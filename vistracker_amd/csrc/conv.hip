@@ -25,12 +25,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define CV_PW (CV_TW + 2)
 #define CV_PX ((CV_TH + 2) * CV_PW)         /* 180 halo pixels */
 #define CV_SPLIT_MAX 65504.0f
-#ifndef CV_W2_WG
-#define CV_W2_WG 3                          /* workgroups per CU the W2 3 x 3 form is compiled for (3 = 168 VGPRs) */
-#endif
-#ifndef CV_W2
-#define CV_W2 0                             /* 1 = 64-output layers as two channel tiles x four rows per wave (round 6, measured: see DESIGN.md 6b); 0 = one tile x eight rows */
-#endif
 
 struct vt_conv3x3 {
     uint4 *w;           // [Cin / 32][9][4 waves][NT][hi|lo][64 lanes]
@@ -61,13 +55,8 @@ __device__ __forceinline__ float cv_row16_sum(float v)
 // "patch" is the 8 x 16 tile itself, one tap, an optional per-channel bias, the GroupNorm + ReLU prologue, the residual add and the output
 // statistics all shared with the 3 x 3 form (stats_cstride / stats_coff: the channel count and offset of the statistics block when a layer of 256
 // output channels runs as two launches of 128).
-//
-// W2 (the 64-output form, NT = 1; round 6): a wave owns TWO 16-channel tiles x FOUR image rows (wave & 1: which 32 channels, wave >> 1: which rows)
-// instead of one tile x eight rows.  Same MFMAs per wave and the same accumulation order per output (bit-identical), but a B fragment read from
-// LDS now feeds two channel tiles: 8 fragment reads per 24 MFMAs instead of 16 -- the ratio of the 128-output form (history 6b: the 64-output form
-// was LDS-bound by construction).  The weight fragments of a 32-channel half are requested by two waves (L1 / L2 hits, like the 128-output form).
-template <int NT, bool K3, int NCH, bool W2 = false>
-__global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
+template <int NT, bool K3, int NCH>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const float *__restrict__ in, int in_cstride, int in_coff, int H, int W, int Cin, const uint4 *__restrict__ wpk,
                                                          const float2 *__restrict__ gn_stats, const float *__restrict__ gamma, const float *__restrict__ beta, int groups,
                                                          float *__restrict__ out, int out_cstride, int out_coff, float inv_scale, int cout, double *__restrict__ stats_part,
                                                          const float *__restrict__ res, int res_cstride, int res_coff, float *__restrict__ fin, int fin_cstride, int fin_coff,
@@ -90,14 +79,11 @@ __global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel
     if (tid == 0) sOvf = 0;
     float rmax = 0.f;
 
-    static_assert(!W2 || NT == 1, "the two-tile wave layout is the 64-output form's");
-    constexpr int NTW = W2 ? 2 : NT, ROWS = W2 ? 4 : CV_TH;    // channel tiles and image rows of a wave
-    const int tile0 = W2 ? 2 * (wave & 1) : wave * NT, row0 = W2 ? 4 * (wave >> 1) : 0;
-    f32x4 acc[NTW][ROWS];
+    f32x4 acc[NT][CV_TH];
 #pragma unroll
-    for (int nt = 0; nt < NTW; nt++)
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int p = 0; p < ROWS; p++) acc[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < CV_TH; p++) acc[nt][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // halo patch of one chunk: 180 px x 8 pieces of 16 B = 1440 items, 6 per thread (the last round partly idle)
     float4 ld[RING][NLD];
@@ -147,15 +133,15 @@ __global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel
             }
         }
     };
-    const unsigned wvo = (unsigned)(tile0 * 128 + lane);
+    const unsigned wvo = (unsigned)(wave * NT * 128 + lane);
     // a 32-channel layer runs the 64-channel kernel with its upper rows packed as zeros: the waves that own none of its output channels take part in
     // the staging only (no weight loads, no MFMAs, no stores)
-    const bool live = tile0 * 16 < cout;
+    const bool live = wave * NT * 16 < cout;
     // weight fragments: a ring of three register sets, requested TWO taps ahead of their use (round 3: one tap = 48 MFMAs was shorter than the latency of
     // an L2 hit under load; nine taps per chunk keep the ring aligned across chunks: slot = tap % 3 (3 x 3), chunk % 3 (1 x 1, unrolled))
-    uint4 wf[3][NTW][2];
+    uint4 wf[3][NT][2];
 #define CV_LOAD_W(slot_, step_)                                                                                      \
-    _Pragma("unroll") for (int nt = 0; nt < NTW; nt++)                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                \
         _Pragma("unroll") for (int hl = 0; hl < 2; hl++) wf[slot_][nt][hl] = wpk[(size_t)(step_) * (4 * NT * 128) + wvo + (nt * 2 + hl) * 64];
     auto chunk_mfma = [&](int c) {
         const uint4 *Xhi = patch[c & 1], *Xlo = Xhi + 4 * PX;
@@ -166,23 +152,23 @@ __global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel
             if (live && step + 2 < nchunk * NTAP) { if (K3) { CV_LOAD_W((t + 2) % 3, step + 2) } else { CV_LOAD_W((c + 2) % 3, step + 2) } }
             const int sl = K3 ? (t % 3) : (c % 3);
 #pragma unroll
-            for (int ph = 0; ph < (live ? ROWS / 4 : 0); ph++) { // halves of four image rows: 8 B fragments live at a time
+            for (int ph = 0; ph < (live ? 2 : 0); ph++) {       // two halves of four image rows: 8 B fragments live at a time
                 h8 xh[4], xl[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    const int px = (row0 + 4 * ph + p + dy) * PW + j + dx;
+                    const int px = (4 * ph + p + dy) * PW + j + dx;
                     xh[p] = cv_h8(Xhi[q * PX + px]); xl[p] = cv_h8(Xlo[q * PX + px]);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
+                for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                     for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][0]), xh[p], acc[nt][4 * ph + p]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
+                for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                     for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][0]), xl[p], acc[nt][4 * ph + p]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
+                for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                     for (int p = 0; p < 4; p++) acc[nt][4 * ph + p] = MFMAH(cv_h8(wf[sl][nt][1]), xh[p], acc[nt][4 * ph + p]);
             }
@@ -223,26 +209,22 @@ __global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel
     float *__restrict__ ob = out ? out + (size_t)b * H * W * out_cstride + out_coff : nullptr;
     float *__restrict__ fb = fin ? fin + (size_t)b * H * W * fin_cstride + fin_coff : nullptr;
     const float *__restrict__ rb = fin ? res + (size_t)b * H * W * res_cstride + res_coff : nullptr;
-    float bv[NTW][4];                                           // bias of this lane's four output channels per channel tile (0 without one)
+    float bv[NT][4];                                            // bias of this lane's four output channels per channel tile (0 without one)
 #pragma unroll
-    for (int nt = 0; nt < NTW; nt++)
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) { const int co = (tile0 + nt) * 16 + 4 * q + r; bv[nt][r] = (bias && co < cout) ? bias[co] : 0.f; }
+        for (int r = 0; r < 4; r++) { const int co = (wave * NT + nt) * 16 + 4 * q + r; bv[nt][r] = (bias && co < cout) ? bias[co] : 0.f; }
     constexpr int TS = 68;                                      // floats per staged pixel row: 64 channels + 4 (bank spread)
     float *tile = reinterpret_cast<float *>(patch);            // 128 x 68 floats = 34 KB of the 46 KB patch buffers (all readers passed the barrier above)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         if (nt) __syncthreads();                                // the readers of the previous pass are done
 #pragma unroll
-        for (int wn = 0; wn < (W2 ? 2 : 1); wn++) {             // W2: both channel tiles of the wave in the one pass (staged column = channel)
-            const int an = W2 ? wn : nt, col = W2 ? (tile0 + wn) * 16 : wave * 16;
-#pragma unroll
-            for (int p = 0; p < ROWS; p++) {
-                float4 v = make_float4(__builtin_fmaf(acc[an][p][0], inv_scale, bv[an][0]), __builtin_fmaf(acc[an][p][1], inv_scale, bv[an][1]),
-                                       __builtin_fmaf(acc[an][p][2], inv_scale, bv[an][2]), __builtin_fmaf(acc[an][p][3], inv_scale, bv[an][3]));
-                if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-                *reinterpret_cast<float4 *>(tile + ((row0 + p) * CV_TW + j) * TS + col + 4 * q) = v;
-            }
+        for (int p = 0; p < CV_TH; p++) {
+            float4 v = make_float4(__builtin_fmaf(acc[nt][p][0], inv_scale, bv[nt][0]), __builtin_fmaf(acc[nt][p][1], inv_scale, bv[nt][1]),
+                                   __builtin_fmaf(acc[nt][p][2], inv_scale, bv[nt][2]), __builtin_fmaf(acc[nt][p][3], inv_scale, bv[nt][3]));
+            if (ovf) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            *reinterpret_cast<float4 *>(tile + (p * CV_TW + j) * TS + wave * 16 + 4 * q) = v;
         }
         __syncthreads();
         float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};       // sum / sum of squares of `fin` over this thread's 8 pixels (4 channels)
@@ -295,36 +277,16 @@ __global__ __launch_bounds__(256, (W2 && K3) ? CV_W2_WG : 2) void conv3x3_kernel
     // block of partials [tile][frame][channel][2] (fp64) for vt_groupnorm_finalize.  Saves the statistics pass over the tensor.
     if (stats_part) {
         double *pp = stats_part + (((size_t)blockIdx.x * gridDim.y + b) * stats_cstride + stats_coff) * 2;
-        // W2: a channel's eight rows live in two waves; the wave of rows 0-3 hands its per-lane partial sums over through LDS and the wave of rows
-        // 4-7 continues them, so the order of the additions (rows 0..7 in the lane, then the 16 columns) is that of the one-wave form
-        float *hand = tile + 128 * TS + 512 + (wave & 1) * 1024;     // [2 halves][tile, r, {sum, sq}][64 lanes] beyond the staged tile and `xw`
-        if (W2) {
-            if (wave < 2) {
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
+        for (int nt = 0; nt < NT; nt++) {
+            const int co = (wave * NT + nt) * 16 + 4 * q;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float sm = 0.f, sq = 0.f;
+            for (int r = 0; r < 4; r++) {
+                float sm = 0.f, sq = 0.f;
 #pragma unroll
-                        for (int p = 0; p < ROWS; p++) { const float v = __builtin_fmaf(acc[nt][p][r], inv_scale, bv[nt][r]); sm += v; sq = __builtin_fmaf(v, v, sq); }
-                        hand[((nt * 4 + r) * 2) * 64 + lane] = sm; hand[((nt * 4 + r) * 2 + 1) * 64 + lane] = sq;
-                    }
-            }
-            __syncthreads();
-        }
-        if (!W2 || wave >= 2) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) {
-                const int co = (tile0 + nt) * 16 + 4 * q;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float sm = 0.f, sq = 0.f;
-                    if (W2) { sm = hand[((nt * 4 + r) * 2) * 64 + lane]; sq = hand[((nt * 4 + r) * 2 + 1) * 64 + lane]; }
-#pragma unroll
-                    for (int p = 0; p < ROWS; p++) { const float v = __builtin_fmaf(acc[nt][p][r], inv_scale, bv[nt][r]); sm += v; sq = __builtin_fmaf(v, v, sq); }
-                    sm = cv_row16_sum(sm); sq = cv_row16_sum(sq);
-                    if (j == 0 && co + r < cout) { pp[(co + r) * 2] = (double)sm; pp[(co + r) * 2 + 1] = (double)sq; }
-                }
+                for (int p = 0; p < CV_TH; p++) { const float v = __builtin_fmaf(acc[nt][p][r], inv_scale, bv[nt][r]); sm += v; sq = __builtin_fmaf(v, v, sq); }
+                sm = cv_row16_sum(sm); sq = cv_row16_sum(sq);
+                if (j == 0 && co + r < cout) { pp[(co + r) * 2] = (double)sm; pp[(co + r) * 2 + 1] = (double)sq; }
             }
         }
     }
@@ -393,7 +355,7 @@ extern "C" int vt_conv3x3_forward_block_stats(const vt_conv3x3 *h, const float *
     VT_REQUIRE(!fin_stats_ws || (fin && fin_stats_groups > 0), "vt_conv3x3_forward_block_stats: the statistics of the result need the result (fin) and a positive group count");
     double *fpart = fin_stats_ws ? fin_stats_ws + (size_t)B * fin_stats_groups : nullptr;
     if (h->nt == 2) hipLaunchKernelGGL((conv3x3_kernel<2, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0, fpart, fin_cstride, fin_coff);
-    else hipLaunchKernelGGL((conv3x3_kernel<1, true, 0, CV_W2 != 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0, fpart, fin_cstride, fin_coff);
+    else hipLaunchKernelGGL((conv3x3_kernel<1, true, 0>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w, st2, gamma, beta, groups, out, out_cstride, out_coff, h->inv_scale, h->cout, part, res, res_cstride, res_coff, fin, fin_cstride, fin_coff, nullptr, h->cout, 0, fpart, fin_cstride, fin_coff);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -480,7 +442,7 @@ extern "C" int vt_conv1x1_forward(const vt_conv1x1 *h, const float *in, int in_c
         // with a residual the sum is the layer's only output (`fin`), without one the plain result (`out`): the statistics are those of what is written
         float *o_plain = res ? nullptr : out; float *o_fin = res ? out : nullptr;
         const float *bs = h->bias ? h->bias + o : nullptr;
-#define CV_L1(NT_, NCH_) hipLaunchKernelGGL((conv3x3_kernel<NT_, false, NCH_, (NT_ == 1 && CV_W2 != 0)>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w[pt], st2, gamma, beta, groups, \
+#define CV_L1(NT_, NCH_) hipLaunchKernelGGL((conv3x3_kernel<NT_, false, NCH_>), grid, dim3(256), 0, vt_stream(stream), in, in_cstride, in_coff, H, W, h->cin, h->w[pt], st2, gamma, beta, groups, \
                                           o_plain, out_cstride, out_coff + o, h->inv_scale, h->pcout, res ? nullptr : part, res, res_cstride, res_coff + o, o_fin, out_cstride, out_coff + o, bs, h->cout, o, \
                                           res ? part : nullptr, h->cout, o)
         const int nch = h->cin / 32;
