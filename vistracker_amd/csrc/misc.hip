@@ -1269,16 +1269,18 @@ extern "C" int vt_smplstep_tail(float *pose, const float *pose_init, float *dpos
 // the keypoint chain of a SMPL-stage step in one launch, one workgroup per frame: body25 joints J = regressor . verts (landmarks_fwd_kernel: wave per
 // joint, lane-strided sum, wave tree), the 2-D keypoint term and dJ (kpts_loss_kernel), d verts = regressor^T dJ written -- not accumulated -- for every
 // vertex (landmarks_bwd_kernel): the query launch that follows adds its gradient to it (vt_query_human_step)
-__global__ __launch_bounds__(256) void kpts_step_kernel(const int *__restrict__ indptr, const int *__restrict__ indices, const float *__restrict__ data,
+__global__ __launch_bounds__(1024) void kpts_step_kernel(const int *__restrict__ indptr, const int *__restrict__ indices, const float *__restrict__ data,
                                                         const int *__restrict__ colptr, const int *__restrict__ rowidx, const float *__restrict__ cdata,
                                                         const float *__restrict__ verts, int V, int K, const float *__restrict__ kpts, const float *__restrict__ cc,
                                                         int mode, Cam5 cam, float net_size, float gscale, float inv_cnt, double *term, float *__restrict__ Jout,
                                                         float *__restrict__ dverts, int accumulate)
 {
     __shared__ float sJ[64 * 3], sdJ[64 * 3];
-    __shared__ double red[4];
-    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = wave; k < K; k += 4) {
+    __shared__ double red[16];
+    // 16 waves per frame (round 6; was 4): the landmark rows and the vertex columns are chains of dependent gathers, 7 rows / 27 columns deep per thread
+    // with 256 threads -- 83 us of latency for microseconds of work; same sums in the same order
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int k = wave; k < K; k += nw) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
         for (int e = indptr[k] + lane; e < indptr[k + 1]; e += 64) {
             const float w = data[e]; const float *v = verts + ((size_t)b * V + indices[e]) * 3;
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(256) void kpts_step_kernel(const int *__restrict__ 
         sdJ[3 * k + 2] = -gpx * cam.fx * x / (z * z) - gpy * cam.fy * y / (z * z);
     }
     term_add(acc * (double)inv_cnt, term, red);          // (its barriers also publish sdJ)
-    for (int v = threadIdx.x; v < V; v += 256) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
         const int s = colptr[v], e = colptr[v + 1];
         if (s == e && accumulate) continue;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -1322,7 +1324,7 @@ extern "C" int vt_kpts_step(const vt_landmarks *h, const float *verts, const flo
     VT_REQUIRE(h && verts && kpts && cam && dverts && B > 0 && h->K <= 64 && (mode == 0 || (mode == 1 && crop_center)), "vt_kpts_step: bad argument (at most 64 landmarks)");
     Cam5 c{cam[0], cam[1], cam[2], cam[3], cam[4]};
     const float inv_cnt = 1.f / (mode == 0 ? (float)(B * h->K * 2) : (float)(B * h->K));
-    hipLaunchKernelGGL(kpts_step_kernel, dim3(B), dim3(256), 0, vt_stream(stream), h->indptr, h->indices, h->data, h->colptr, h->rowidx, h->cdata, verts, h->V, h->K,
+    hipLaunchKernelGGL(kpts_step_kernel, dim3(B), dim3(1024), 0, vt_stream(stream), h->indptr, h->indices, h->data, h->colptr, h->rowidx, h->cdata, verts, h->V, h->K,
                        kpts, crop_center, mode, c, net_size, gscale, inv_cnt, term, J, dverts, accumulate);
     VT_LAUNCH_CHECK();
     return VT_OK;
