@@ -325,7 +325,7 @@ def sifnet_inference_leg(torch, syn):
     return {"workload": "SIF-Net inference, batch 16 x 512^2, 50 000 samples/frame (BASELINE configs[3])", "frames_per_s": B / (t_enc + t_q),
             "encoder_ms": 1e3 * t_enc, "query_5_heads_ms": 1e3 * t_q, "query_Mpoints_per_s": B * N / t_q / 1e6, "surface_projection_10_steps_ms": 1e3 * t_proj,
             "encoder_tflops": 0.613 * B / t_enc,
-            # which route the convolutions took (capture pass + eager warm-up passes): everything but the 7 x 7 stem must be on the HIP kernels
+            # which route the convolutions took (capture pass + eager warm-up passes): every convolution must be on the HIP kernels (hip7x7 / hip3x3 / hip1x1, no 'miopen:' key)
             "encoder_conv_routes": net.encoder.route_report() if getattr(net, "encoder", None) is not None else None}
 
 
@@ -334,7 +334,7 @@ def pipeline_leg(torch, T=1500):
     from vistracker_amd import demo_inputs
     pipe, assets = demo_inputs.pipeline()
     seq = demo_inputs.sequence(T, assets)
-    pipe.run({k: (v[:96] if k != "gender" else v) for k, v in seq.items()}); pipe.log.clear()      # warm-up: MIOpen kernel selection, allocator
+    pipe.run({k: (v[:96] if k != "gender" else v) for k, v in seq.items()}); pipe.log.clear()      # warm-up: weight uploads, graph captures, allocator
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipe.run(seq)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
