@@ -360,15 +360,20 @@ extern "C" int vt_rigid_backward(const float *X0, int shared_x0, const float *s,
 // thread == one ELEMENT (frame f, column i): it sums the (up to three) stencils that touch v[f][i], so every gradient element is
 // written exactly once (no atomics) and the B frames are not walked serially (a thread-per-column walk was latency bound: 59 us).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void accel_loss_kernel(const float *__restrict__ v, int B, int Dcols, int D, const float *__restrict__ elem_w,
+// 1024 threads x at most 256 workgroups (round 6; was 256 x 512): every workgroup ends with ONE fp64 atomic on the term, and same-address atomics are
+// performed one after the other at the memory side (~12 ns each: 512 of them were 6 of the kernel's 20 us; with 2048 workgroups the kernel took 33 us,
+// with 4096 54 us) -- fewer, larger workgroups: 12.3 us at B = 96, D = 20670, `dv` bit-identical (profiles/r06_accel_loss_ab.txt)
+#define ACCEL_T 1024
+#define ACCEL_MAX_BLOCKS 256
+__global__ __launch_bounds__(ACCEL_T) void accel_loss_kernel(const float *__restrict__ v, int B, int Dcols, int D, const float *__restrict__ elem_w,
                                                          float gs, double *term, float *__restrict__ dv)
 {
     // D = row stride (floats per frame), Dcols = columns that take part
-    __shared__ double red[4];
+    __shared__ double red[ACCEL_T / 64];
     double acc = 0;
     // grid-stride over the elements: at most 512 blocks, so the fp64 atomics on the loss term (one per block, all arriving at the end)
     // do not serialise the tail of the kernel
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < B * Dcols; t += gridDim.x * 256) {
+    for (int t = blockIdx.x * ACCEL_T + threadIdx.x; t < B * Dcols; t += gridDim.x * ACCEL_T) {
         const int f = t / Dcols, i = t - f * Dcols;
         const float w = elem_w ? elem_w[i] : 1.f;
         auto at = [&](int b) { return v[(size_t)min(max(b, 0), B - 1) * D + i]; };
@@ -701,7 +706,7 @@ extern "C" int vt_accel_loss(const float *v, int B, int D, const float *elem_w, 
     VT_REQUIRE(v && B >= 3 && D > 0, "vt_accel_loss: needs B >= 3 (the reference returns NaN for empty stencils)");
     // d/dv of mean(w a^2): 2 w a / cnt per stencil element; a's own coefficient 2 is folded in the kernel
     const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
-    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, D, elem_w, gs, term, dv);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + ACCEL_T - 1) / ACCEL_T, ACCEL_MAX_BLOCKS)), dim3(ACCEL_T), 0, vt_stream(stream), v, B, D, D, elem_w, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -709,7 +714,7 @@ extern "C" int vt_accel_loss_strided(const float *v, int B, int D, int stride, c
 {
     VT_REQUIRE(v && B >= 3 && D > 0 && stride >= D, "vt_accel_loss_strided: needs B >= 3 and stride >= D");
     const float gs = 2.f * gscale / ((float)(B - 2) * (float)D);
-    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + 255) / 256, 512)), dim3(256), 0, vt_stream(stream), v, B, D, stride, elem_w, gs, term, dv);
+    hipLaunchKernelGGL(accel_loss_kernel, dim3(min((B * D + ACCEL_T - 1) / ACCEL_T, ACCEL_MAX_BLOCKS)), dim3(ACCEL_T), 0, vt_stream(stream), v, B, D, stride, elem_w, gs, term, dv);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
