@@ -275,6 +275,8 @@ int vt_query_project_step(const vt_sifnet *h, const vt_maps *maps, const float *
  *   vt_objstep_tail   rigid VJP over the vertex set (dX_verts != NULL: phase 'sil') and the points, the translation regulariser
  *                     mean (t - t_init)^2 (t_init != NULL; recon_fit_trivis_full.py:227), SO(3) VJP, Adam (torch.optim.Adam) on pR (B,9) / pT (B,3)
  *                     (NULL: that group is not optimised), step end
+ *   svd_ws            (B, 22) floats or NULL: vt_objstep_head leaves the SVD of M0 + 1e-4 noise there (U, V, s, det sign) and the tail of the SAME step takes
+ *                     it from there instead of decomposing the matrix a second time (the same numbers; ~10 us of one thread per step)
  *   vt_smplstep_tail  body-pose prior th_Mahalanobis on pose[:, 3:66] (th_smpl_prior.py:30-38; gscale_prior = w / B), pinit term mean_B sum
  *                     (pose[:, 3:72] - pose_init)^2 (recon_fit_behave.py:500-503), Adam on up to three column slices (p, stride, g, stride, m, v,
  *                     columns, lr; p == NULL: unused), step end
@@ -289,7 +291,7 @@ int vt_query_human_step(const vt_sifnet *h, const vt_maps *maps, const float *pt
                         int B, int N, const int *labels, const int *order, float w_dfh, float w_part, int accumulate, float w_accel,
                         double *term_accel, float *dpts, double *terms, void *stream);
 int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
-                    const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, void *stream);
+                    const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, float *svd_ws, void *stream);
 int vt_temporal_loss2(const float *v, int B, int D, float gscale_accel, double *term_accel, float gscale_velocity, double *term_velocity, float *dv,
                       int init_zero, void *stream);
 int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_verts, const float *X0_points, int N, const float *dX_points, const float *s, int B,
@@ -297,7 +299,7 @@ int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_verts, const 
                     float *dR, float *dt, float *dM,
                     float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
                     double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
-                    void *stream);
+                    float *svd_ws, void *stream);
 /* vt_objstep_tail with the stencils of vt_temporal_loss2(X_points, B, 3 N, ...) evaluated inside it (the same float additions in the same order: bit-identical
  * parameters, one launch less per step); init_zero as there (dX_points is then not read).  For the phases in which nothing else adds to dX_points between the
  * stencils and the tail ('object only', 'sil'). */
@@ -307,7 +309,7 @@ int vt_objstep_tail_temporal(const float *X_points, float gscale_accel, double *
                              float *dR, float *dt, float *dM,
                              float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
                              double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
-                             void *stream);
+                             float *svd_ws, void *stream);
 int vt_smplstep_tail(float *pose, const float *pose_init, float *dpose, int B, const float *prior_mean, const float *prior_prec, float gscale_prior,
                      double *term_prior, float w_pinit, double *term_pinit,
                      float *p0, int ps0, const float *g0, int gs0, float *m0, float *v0, int n0, float lr0,

@@ -66,15 +66,15 @@ SIGNATURES = {
     "vt_conv3x3_tiles": (ci, [ci, ci]),
     "vt_kpts_step": (ci, [vp, fp, fp, fp, ci, ci, vp, cf, cf, fp, fp, fp, ci, vp]),
     "vt_query_human_step": (ci, [vp, C.POINTER(VtMaps), fp, fp, fp, ci, ci, fp, fp, cf, cf, ci, cf, fp, fp, fp, vp]),
-    "vt_objstep_head": (ci, [fp, fp, fp, fp, ci, fp, ci, fp, fp, ci, fp, fp, fp, ci, vp]),
+    "vt_objstep_head": (ci, [fp, fp, fp, fp, ci, fp, ci, fp, fp, ci, fp, fp, fp, ci, fp, vp]),
     "vt_temporal_loss2": (ci, [fp, ci, ci, cf, fp, cf, fp, fp, ci, vp]),
     "vt_objstep_tail": (ci, [fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,
                              fp, fp, fp, cf, fp, fp, fp, cf, ci, cf, cf, cf,
-                             fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
+                             fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, fp, vp]),
     "vt_objstep_tail_temporal": (ci, [fp, cf, fp, cf, fp, ci,
                                       fp, ci, fp, fp, ci, fp, fp, ci, fp, fp, fp, fp, cf, fp, fp, fp, fp,
                                       fp, fp, fp, cf, fp, fp, fp, cf, ci, cf, cf, cf,
-                                      fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),
+                                      fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, fp, vp]),
     "vt_smplstep_tail": (ci, [fp, fp, fp, ci, fp, fp, cf, fp, cf, fp,
                               fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, fp, ci, fp, ci, fp, fp, ci, cf, ci, cf, cf, cf,
                               fp, vp, ci, cf, ci, fp, fp, fp, ci, fp, ci, vp]),

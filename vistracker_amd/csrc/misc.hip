@@ -191,6 +191,7 @@ extern "C" int vt_mahalanobis(const float *x, int B, int stride, int off, int n,
 // (the same derivative autograd takes through torch.svd/det, without its 1/(s_i^2 - s_j^2) cancellation).
 // ---------------------------------------------------------------------------------------------------
 struct Svd3 { float U[9], V[9], s[3], d; };
+#define SVD_WS 22    /* floats per frame of the head -> tail hand-over: U, V, s, d */
 
 __device__ __forceinline__ void jacobi_pair(float *A, float *V, const int p, const int q)
 {
@@ -876,7 +877,7 @@ extern "C" int vt_loss_reduce_and_stop(const double *terms, const float *w, int 
 __global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restrict__ M0, const float *__restrict__ noise, const float *__restrict__ t,
                                                            const float *__restrict__ s, const float *__restrict__ X0p, int N, float *__restrict__ Xp,
                                                            const float *__restrict__ X0v, int NV, float *__restrict__ Xv, float *__restrict__ Rout,
-                                                           double *terms, int nzero)
+                                                           double *terms, int nzero, float *__restrict__ svd_ws)
 {
     __shared__ float sR[9];
     const int b = blockIdx.y;
@@ -892,6 +893,14 @@ __global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restri
         if (blockIdx.x == 0) {
 #pragma unroll
             for (int e = 0; e < 9; e++) Rout[9 * b + e] = sR[e];
+            // the decomposition itself for the step's tail, which needs the SVD of the SAME matrix for the SO(3) VJP (round 6: the one-sided Jacobi SVD --
+            // 24 rotations with two divisions and two square roots each, ~10 us of one thread -- was computed twice per step)
+            if (svd_ws) {
+                float *o = svd_ws + SVD_WS * b;
+#pragma unroll
+                for (int e = 0; e < 9; e++) { o[e] = sv.U[e]; o[9 + e] = sv.V[e]; }
+                o[18] = sv.s[0]; o[19] = sv.s[1]; o[20] = sv.s[2]; o[21] = sv.d;
+            }
         }
     }
     if (blockIdx.x == 0 && b == 0 && terms && (int)threadIdx.x < nzero) terms[threadIdx.x] = 0.0;
@@ -913,12 +922,12 @@ __global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restri
     }
 }
 extern "C" int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
-                               const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, void *stream)
+                               const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, float *svd_ws, void *stream)
 {
     VT_REQUIRE(M0 && t && s && X0_points && X_points && R && B > 0 && N > 0 && (!X_verts || (X0_verts && NV > 0)) && nzero >= 0 && nzero <= 16, "vt_objstep_head: bad argument");
     const int nmax = X_verts ? max(N, NV) : N;
     hipLaunchKernelGGL(objstep_head_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, vt_stream(stream), M0, noise, t, s, X0_points, N, X_points, X0_verts, NV, X_verts,
-                       R, terms, nzero);
+                       R, terms, nzero, svd_ws);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -1026,7 +1035,8 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(TemporalIn tin, const
                                                            const float *__restrict__ dXp, const float *__restrict__ s, const float *__restrict__ M0,
                                                            const float *__restrict__ noise, const float *__restrict__ tpar, const float *__restrict__ t_init,
                                                            float w_trans, double *term_trans, float *__restrict__ dR, float *__restrict__ dt, float *__restrict__ dM,
-                                                           AdamSlice aR, AdamSlice aT, float bc2s, float beta1, float beta2, float eps, StepEnd end)
+                                                           AdamSlice aR, AdamSlice aT, float bc2s, float beta1, float beta2, float eps, StepEnd end,
+                                                           const float *__restrict__ svd_ws)
 {
     __shared__ float red12[4][12];
     __shared__ double redt[4];
@@ -1038,6 +1048,11 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(TemporalIn tin, const
     // (dR / dM are then left untouched; obj_t takes the same three sums in the same order: bit-identical parameters)
     const bool rot = aR.p != nullptr;
     const float sc = s[b];
+    float svw[SVD_WS];              // thread 0: the head's SVD of this frame, requested before the sums over the points so that its latency hides behind them
+    if (svd_ws && rot && threadIdx.x == 0) {
+#pragma unroll
+        for (int e = 0; e < SVD_WS; e++) svw[e] = svd_ws[SVD_WS * b + e];
+    }
     float tot[12];
 #pragma unroll
     for (int e = 0; e < 12; e++) tot[e] = 0.f;
@@ -1127,8 +1142,16 @@ __global__ __launch_bounds__(256) void objstep_tail_kernel(TemporalIn tin, const
         // SO(3) VJP (so3_bwd_kernel)
         float M[9], G[9]; Svd3 sv;
 #pragma unroll
-        for (int e = 0; e < 9; e++) { M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f); G[e] = g[e]; }
-        svd3(M, sv);
+        for (int e = 0; e < 9; e++) G[e] = g[e];
+        if (svd_ws) {               // the step's head decomposed this matrix already (vt_objstep_head with the same workspace): the same numbers
+#pragma unroll
+            for (int e = 0; e < 9; e++) { sv.U[e] = svw[e]; sv.V[e] = svw[9 + e]; }
+            sv.s[0] = svw[18]; sv.s[1] = svw[19]; sv.s[2] = svw[20]; sv.d = svw[21];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; e++) M[e] = M0[9 * b + e] + (noise ? 1e-4f * noise[9 * b + e] : 0.f);
+            svd3(M, sv);
+        }
         const float D[3] = {1.f, 1.f, sv.d}, h[3] = {sv.s[0], sv.s[1], sv.d * sv.s[2]};
         float UtG[9], Q[9], Z[9], UDZ[9];
 #pragma unroll
@@ -1175,7 +1198,7 @@ extern "C" int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_ve
                                float *dR, float *dt, float *dM,
                                float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
                                double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
-                               void *stream)
+                               float *svd_ws, void *stream)
 {
     VT_REQUIRE(X0_points && dX_points && s && M0 && t && dR && dt && dM && B > 0 && N > 0 && (!dX_verts || (X0_verts && NV > 0)) && (!t_init || term_trans), "vt_objstep_tail: bad argument");
     VT_REQUIRE(terms && w && state && ticket && nterms > 0 && nterms <= 16 && nzero >= 0 && nzero <= nterms && adam_step >= 1 && (!pR || (mR && vR)) && (!pT || (mT && vT)),
@@ -1184,7 +1207,7 @@ extern "C" int vt_objstep_tail(const float *X0_verts, int NV, const float *dX_ve
     AdamSlice aR = {pR, 9, dM, 9, mR, vR, 9, (float)(lrR / bc1)}, aT = {pT, 3, dt, 3, mT, vT, 3, (float)(lrT / bc1)};
     const TemporalIn tin = {nullptr, 0.f, 0.f, nullptr, nullptr, 0};
     hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), tin, X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
-                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
+                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero), svd_ws);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }
@@ -1194,7 +1217,7 @@ extern "C" int vt_objstep_tail_temporal(const float *X_points, float gscale_acce
                                         float *dR, float *dt, float *dM,
                                         float *pR, float *mR, float *vR, float lrR, float *pT, float *mT, float *vT, float lrT, int adam_step, float beta1, float beta2, float eps,
                                         double *terms, const float *w, int nterms, float tol, int armed, float *state, int *stop_flag, float *history, int slot, int *ticket, int nzero,
-                                        void *stream)
+                                        float *svd_ws, void *stream)
 {
     VT_REQUIRE(X_points && term_accel && term_velocity && B >= 3, "vt_objstep_tail_temporal: bad argument (B >= 3)");
     VT_REQUIRE(X0_points && dX_points && s && M0 && t && dR && dt && dM && B > 0 && N > 0 && (!dX_verts || (X0_verts && NV > 0)) && (!t_init || term_trans), "vt_objstep_tail_temporal: bad argument");
@@ -1205,7 +1228,7 @@ extern "C" int vt_objstep_tail_temporal(const float *X_points, float gscale_acce
     const int D = N * 3;
     const TemporalIn tin = {X_points, 2.f * gscale_accel / ((float)(B - 2) * (float)D), 2.f * gscale_velocity / ((float)(B - 1) * (float)D), term_accel, term_velocity, init_zero ? 2 : 1};
     hipLaunchKernelGGL(objstep_tail_kernel, dim3(B), dim3(256), 0, vt_stream(stream), tin, X0_verts, NV, dX_verts, X0_points, N, dX_points, s, M0, noise, t, t_init, w_trans, term_trans,
-                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero));
+                       dR, dt, dM, aR, aT, (float)sqrt(bc2), beta1, beta2, eps, make_end(terms, w, nterms, tol, armed, state, stop_flag, history, slot, ticket, nzero), svd_ws);
     VT_LAUNCH_CHECK();
     return VT_OK;
 }

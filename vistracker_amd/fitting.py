@@ -235,6 +235,8 @@ class FitContext:
     fused_smpl_query = os.environ.get("VT_FUSED_SMPL_QUERY", "0") != "0"
     # ... the keypoint chain alone as one launch BEHIND the query (vt_kpts_step, accumulate = 1) instead of vt_landmarks_forward + vt_kpts_loss + vt_landmarks_backward
     fused_kpts_step = os.environ.get("VT_FUSED_KPTS_STEP", "1") != "0"
+    # object stage: the head of a fused step hands its SVD of M0 + noise to the step's tail (same numbers, one ~10 us decomposition less per step); 0: the tail decomposes again
+    share_step_svd = os.environ.get("VT_SHARE_STEP_SVD", "1") != "0"
     # the query / SMPL-H launches queued behind the step that stopped a fit return at their first instruction (vt_stream_set_skip_flag)
     device_skip = os.environ.get("VT_DEVICE_SKIP", "1") != "0"
     # the host looks at the stop flag of outer iteration k only after it has queued iteration k + 1 (asynchronous copy of the flag to pinned memory + an
@@ -548,6 +550,8 @@ class FitContext:
             gen = torch.Generator(device=dev); gen.manual_seed(seed)
             noise = torch.rand(nsteps, B, 3, 3, device=dev, generator=gen)
         R = torch.empty(B, 3, 3, device=dev); X = torch.empty(B, N, 3, device=dev); dX = torch.empty_like(X)
+        # head -> tail hand-over of a fused step's SVD (vt_objstep_head decomposes M0 + noise, the tail's SO(3) VJP needs the same decomposition)
+        R._vt_svd_ws = torch.empty(B, 22, device=dev) if self.share_step_svd else None
         dR = torch.empty(B, 3, 3, device=dev); dM = torch.empty(B, 3, 3, device=dev); dt = torch.empty(B, 3, device=dev)
         stop = torch.zeros(1, dtype=torch.int32, device=dev); state = torch.tensor([300.0, 300.0], device=dev)
         lp = {"human": [], "object": []} if prof is not None else None
@@ -717,8 +721,10 @@ class FitContext:
         launches of _optimize_smpl_object in the same order"""
         lib = _lib(); st = L.stream_ptr()
         is_sil = phase == "sil"
+        svd_ws = getattr(R, "_vt_svd_ws", None)
+        svd_ptr = svd_ws.data_ptr() if svd_ws is not None else None
         _chk(lib.vt_objstep_head(obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), B, self.obj_points.data_ptr(), N, X.data_ptr(),
-                                 self.obj_verts.data_ptr() if is_sil else None, NV, Vt.data_ptr() if is_sil else None, R.data_ptr(), terms.buf.data_ptr(), 7, st))
+                                 self.obj_verts.data_ptr() if is_sil else None, NV, Vt.data_ptr() if is_sil else None, R.data_ptr(), terms.buf.data_ptr(), 7, svd_ptr, st))
         if not is_sil:
             ev = _ev_begin(prof)
             _chk(lib.vt_query_object_loss(self.net.h, C.byref(maps.c), X.data_ptr(), crop_center.data_ptr(), body_center.data_ptr(), B, N,
@@ -759,7 +765,7 @@ class FitContext:
         tail_args = (self.obj_verts.data_ptr() if is_sil else None, NV, dVt.data_ptr() if is_sil else None, self.obj_points.data_ptr(), N, dX.data_ptr(),
                      obj_s.data_ptr(), B, obj_R.data_ptr(), nz.data_ptr(), obj_t.data_ptr(), trans_init.data_ptr() if is_sil else None, float(w[4]),
                      terms.ptr("trans"), dR.data_ptr(), dt.data_ptr(), dM.data_ptr(), *gR, *gT, adam.t, 0.9, 0.999, 1e-8,
-                     terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, st)
+                     terms.buf.data_ptr(), w.ctypes.data, len(names), 1e-4, armed, state.data_ptr(), stop.data_ptr(), hist.data_ptr(), k, ticket.data_ptr(), 0, svd_ptr, st)
         if tail_temporal:
             _chk(lib.vt_objstep_tail_temporal(X.data_ptr(), float(w[1]), terms.ptr("otemp"), float(w[2]), terms.ptr("ovtemp"), int(is_sil), *tail_args))
         else:
