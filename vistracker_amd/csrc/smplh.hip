@@ -192,6 +192,9 @@ __global__ __launch_bounds__(64) void smplh_pose_kernel(const float *__restrict_
 // the frame's A matrices broadcast from LDS).
 // ---------------------------------------------------------------------------------------------------
 #define FWD_FB 16
+#ifndef FWD_PF
+#define FWD_PF 6         /* pair steps of Q rows in flight in the blend-shape GEMM of smplh_verts_kernel */
+#endif
 #define AXS 516   /* LDS stride of an extended pose row [pose_map | betas | 1 | 0 0]: 516 mod 64 = 4 -> conflict-free ds_read_b64 */
 #define SAS 628   /* LDS stride of a frame's 52 x 12 A matrices */
 #define FWD_R0 (FWD_FB * AXS > 8 * SAS ? FWD_FB * AXS : 8 * SAS)    /* floats of the time-shared region: pose rows, then 8 frames of A matrices */
@@ -231,20 +234,30 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
     f32x4 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int s = 0; s < KQ_ / 8; s++) {
-        const float2 av = *reinterpret_cast<const float2 *>(sAx + j * AXS + 8 * s + 2 * q);
-        const float *qk = Q_kcv + (size_t)(8 * s + 2 * q) * 3 * VP_ + v;
-        float bq[2][3];
-#pragma unroll
-        for (int e = 0; e < 2; e++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) bq[e][c] = qk[(size_t)(e * 3 + c) * VP_];
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.x, bq[0][c], acc[c]);
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.y, bq[1][c], acc[c]);
+    // Round 6: the Q rows are requested FWD_PF pair steps ahead of their use (a ring of register sets, the loop fully unrolled so that the ring indices are
+    // constants).  With the loads of a step issued in front of its own MFMAs (unroll 2) the loop ran one round trip to L2 / the fabric per two steps:
+    // ~30 round trips = the kernel's 50 us.  Same MFMAs in the same order: bit-identical.
+    constexpr int NS = KQ_ / 8;
+    float bq[FWD_PF][2][3];
+#define FWD_LOADQ(slot_, s_)                                                                     \
+    {                                                                                            \
+        const float *qk = Q_kcv + (size_t)(8 * (s_) + 2 * q) * 3 * VP_ + v;                      \
+        _Pragma("unroll") for (int e = 0; e < 2; e++)                                            \
+            _Pragma("unroll") for (int c = 0; c < 3; c++) bq[slot_][e][c] = qk[(size_t)(e * 3 + c) * VP_]; \
     }
+#pragma unroll
+    for (int s = 0; s < FWD_PF; s++) FWD_LOADQ(s, s)
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const float2 av = *reinterpret_cast<const float2 *>(sAx + j * AXS + 8 * s + 2 * q);
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.x, bq[s % FWD_PF][0][c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[c] = MFMA16(av.y, bq[s % FWD_PF][1][c], acc[c]);
+        if (s + FWD_PF < NS) FWD_LOADQ(s % FWD_PF, s + FWD_PF)
+        __builtin_amdgcn_sched_barrier(0);      // keeps the request where it is written: the scheduler otherwise sinks it to ~1.5 steps in front of its use
+    }
+#undef FWD_LOADQ
     // hand v_posed over through LDS so that skinning runs with thread == vertex and a wave-uniform frame: the frame's A
     // matrices are then true LDS broadcasts and nothing is indexed dynamically in registers
     __syncthreads();                        // every wave is done with sAx: the region becomes sA
@@ -336,15 +349,24 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
     for (int ks = 0; ks < 64; ks++) w2[ks] = W_v64[(size_t)(v0 + 4 * ks + q) * 64 + wave * 16 + j];
     // (phase 1's K = 52 joints is exactly 13 steps: the all-ones column 52 of W_v64, phase 2's dtrans collector, is never touched)
     __syncthreads();
+    // the vertex's gradient and rest position of frame f + 1 are requested before the MFMA phases of frame f (round 6: a rolled loop paid their round trip
+    // in front of every frame's LDS staging)
+    float dvn[3] = {0.f, 0.f, 0.f}, vpn[3] = {0.f, 0.f, 0.f};
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) { dvn[r] = 0.f; vpn[r] = 0.f; }
+        if (b < B && v < V_) {
+            const size_t o = ((size_t)b * V_ + v) * 3;
+            dvn[0] = dverts[o]; dvn[1] = dverts[o + 1]; dvn[2] = dverts[o + 2];
+            vpn[0] = v_posed[o]; vpn[1] = v_posed[o + 1]; vpn[2] = v_posed[o + 2];
+        }
+    };
+    fetch(b0);
 #pragma unroll 1
     for (int f = 0; f < FB; f++) {
         const int b = b0 + f;
-        float dv[3] = {0.f, 0.f, 0.f}, vp[3] = {0.f, 0.f, 0.f};
-        if (b < B && v < V_) {
-            const size_t o = ((size_t)b * V_ + v) * 3;
-            dv[0] = dverts[o]; dv[1] = dverts[o + 1]; dv[2] = dverts[o + 2];
-            vp[0] = v_posed[o]; vp[1] = v_posed[o + 1]; vp[2] = v_posed[o + 2];
-        }
+        const float dv[3] = {dvn[0], dvn[1], dvn[2]}, vp[3] = {vpn[0], vpn[1], vpn[2]};
+        if (f + 1 < FB) fetch(b + 1);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             sdT[tid * 13 + r * 4 + 0] = dv[r] * vp[0]; sdT[tid * 13 + r * 4 + 1] = dv[r] * vp[1];
@@ -411,6 +433,9 @@ __global__ __launch_bounds__(256) void smplh_bwd_tile_kernel(const float *__rest
 // about the order), so one float4 feeds 4 steps: A from the LDS-staged dvp rows, B from Q packed in exactly that fragment order.
 // ---------------------------------------------------------------------------------------------------
 #define BL_M 96
+#ifndef BL_NW
+#define BL_NW 1
+#endif
 #define BL_AS 132   /* LDS row stride of the staged A chunk (128 k + 4: stride = 4 mod 64 banks) */
 __global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__restrict__ Q_p, const float *__restrict__ dvp_g, int B,
                                                               float *__restrict__ part3, const int *skip)
@@ -418,11 +443,14 @@ __global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__res
     VT_SKIP_RETURN(skip);
     __shared__ __attribute__((aligned(16))) float sA[BL_M * BL_AS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-    const int ks = blockIdx.x, m0 = blockIdx.z * BL_M, nt0 = blockIdx.y * 8 + wave * 2;
-    const bool v0 = nt0 < NQ_ / 16, v1 = nt0 + 1 < NQ_ / 16;
-    f32x4 acc[6][2];
+    // BL_NW = N-tiles per wave (round 6: 1, was 2): 216 workgroups of 1152 dependent-issue MFMAs per wave left the chip three quarters empty for 18 us of
+    // matrix-pipe latency; 432 workgroups of 576 (the staged A chunk is read by twice as many workgroups, from L2)
+    const int ks = blockIdx.x, m0 = blockIdx.z * BL_M, nt0 = blockIdx.y * (4 * BL_NW) + wave * BL_NW;
+    f32x4 acc[6][BL_NW];
 #pragma unroll
-    for (int mt = 0; mt < 6; mt++) { acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+        for (int n = 0; n < BL_NW; n++) acc[mt][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q_p);
 #pragma unroll 1
     for (int c = 0; c < KG_SLAB / 8; c++) {
@@ -437,16 +465,20 @@ __global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__res
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const size_t kg = (size_t)ks * KG_SLAB + c * 8 + g;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 f0 = Q4[(kg * (NQ_ / 16) + min(nt0, NQ_ / 16 - 1)) * 64 + lane], f1 = Q4[(kg * (NQ_ / 16) + min(nt0 + 1, NQ_ / 16 - 1)) * 64 + lane];
-            const float bq0[4] = {f0.x, f0.y, f0.z, f0.w}, bq1[4] = {f1.x, f1.y, f1.z, f1.w};
-            (void)z4;
+            float bq[BL_NW][4];
+#pragma unroll
+            for (int n = 0; n < BL_NW; n++) {
+                const float4 fq = Q4[(kg * (NQ_ / 16) + min(nt0 + n, NQ_ / 16 - 1)) * 64 + lane];
+                bq[n][0] = fq.x; bq[n][1] = fq.y; bq[n][2] = fq.z; bq[n][3] = fq.w;
+            }
 #pragma unroll
             for (int mt = 0; mt < 6; mt++) {
                 const float4 a4 = *reinterpret_cast<const float4 *>(sA + (mt * 16 + j) * BL_AS + g * 16 + q * 4);
                 const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int s = 0; s < 4; s++) { acc[mt][0] = MFMA16(av[s], bq0[s], acc[mt][0]); acc[mt][1] = MFMA16(av[s], bq1[s], acc[mt][1]); }
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int n = 0; n < BL_NW; n++) acc[mt][n] = MFMA16(av[s], bq[n][s], acc[mt][n]);
             }
         }
     }
@@ -457,8 +489,9 @@ __global__ __launch_bounds__(256) void smplh_bwd_blend_kernel(const float *__res
             const int b = m0 + mt * 16 + 4 * q + r;
             if (b < B) {
                 float *dst = part3 + ((size_t)ks * B + b) * NQ_;
-                if (v0) dst[nt0 * 16 + j] = acc[mt][0][r];
-                if (v1) dst[(nt0 + 1) * 16 + j] = acc[mt][1][r];
+#pragma unroll
+                for (int n = 0; n < BL_NW; n++)
+                    if (nt0 + n < NQ_ / 16) dst[(nt0 + n) * 16 + j] = acc[mt][n][r];
             }
         }
     }
@@ -682,7 +715,7 @@ extern "C" int vt_smplh_backward(const vt_smplh *h, const float *pose, const flo
     VT_LDS_LIMIT(smplh_bwd_tile_kernel<BWD_FB>, lds);
     hipLaunchKernelGGL(smplh_bwd_tile_kernel<BWD_FB>, dim3(NVT_, (B + BWD_FB - 1) / BWD_FB), dim3(256), lds, st, h->W_v64, ws, v_posed, dverts, B, scratch, dvp_g, skip);
     VT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, 4, (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3, skip);
+    hipLaunchKernelGGL(smplh_bwd_blend_kernel, dim3(NKS_, (NQ_ / 16 + 4 * BL_NW - 1) / (4 * BL_NW), (B + BL_M - 1) / BL_M), dim3(256), 0, st, h->Q_t, dvp_g, B, part3, skip);
     VT_LAUNCH_CHECK();
     hipLaunchKernelGGL(smplh_bwd_frame_kernel, dim3(B), dim3(256), 0, st, pose, h->J_s, h->par, ws, scratch, part3, djtr, B, dpose, dbetas, dtrans, skip);
     VT_LAUNCH_CHECK();
