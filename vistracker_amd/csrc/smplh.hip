@@ -212,13 +212,21 @@ __global__ __launch_bounds__(256) void smplh_verts_kernel(const float *__restric
     float *sTr = sW + (nnz > 0 ? 2 * SP_K * 64 : J_ * 64);     // [16][3]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
     const int b0 = blockIdx.y * FWD_FB, v = blockIdx.x * 64 + wave * 16 + j;
-    for (int i = tid; i < FWD_FB * KQ_; i += 256) {
-        const int f = i / KQ_, k = i % KQ_, b = min(b0 + f, B - 1);
-        float val;
-        if (k < NP_) { const int e = k % 9; val = ws[(size_t)b * WS_FRAME + WS_R + 9 + k] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f); }
-        else if (k < NP_ + NB_) val = betas[b * NB_ + (k - NP_)];
-        else val = (k == NP_ + NB_) ? 1.f : 0.f;
-        sAx[f * AXS + k] = val;
+    // extended pose rows [pose_map | betas | 1 | 0 0] of the block's frames: a thread owns a column k and requests it for all FWD_FB frames at once (round 6: the
+    // element-per-thread loop was 30 rounds of one dependent load each, with a division and a modulo per element -- a third of the kernel's time)
+    for (int k = tid; k < KQ_; k += 256) {
+        const int e9 = k % 9;
+        const float sub = (k < NP_ && (e9 == 0 || e9 == 4 || e9 == 8)) ? 1.f : 0.f;
+        float val[FWD_FB];
+#pragma unroll
+        for (int f = 0; f < FWD_FB; f++) {
+            const int b = min(b0 + f, B - 1);
+            if (k < NP_) val[f] = ws[(size_t)b * WS_FRAME + WS_R + 9 + k];
+            else if (k < NP_ + NB_) val[f] = betas[b * NB_ + (k - NP_)];
+            else val[f] = (k == NP_ + NB_) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < FWD_FB; f++) sAx[f * AXS + k] = val[f] - sub;
     }
     if (nnz > 0) {                          // sparse LBS: sW = [nnz][64] joint indices | [nnz][64] weights of the tile
         for (int i = tid; i < nnz * 64; i += 256) {
