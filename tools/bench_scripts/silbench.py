@@ -33,3 +33,5 @@ def step2():
 step2(); torch.cuda.synchronize(); e0.record()
 for _ in range(20): step2()
 e1.record(); torch.cuda.synchronize(); print("vt_sil_step:", e0.elapsed_time(e1) / 20 * 1000, "us")
+if len(sys.argv) > 1:      # outputs of the fused step for a bitwise A/B between libraries (VT_LIB_PATH)
+    np.savez(sys.argv[1], fidx=fidx.cpu().numpy(), dimg=dimg.cpu().numpy(), dv=dv.cpu().numpy(), term=term.cpu().numpy())

@@ -216,6 +216,9 @@ __device__ __forceinline__ void sil_scatter_box(const float (&fc)[9], float den,
         if (sil_inside(fc, xp, yp)) sil_vote(fc, den, f2, xp, yp, xi, yi, is, zrow);
     }
 }
+#ifndef SIL_WG_BARRIER
+#define SIL_WG_BARRIER 0
+#endif
 __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restrict__ fcbuf, const int2 *__restrict__ fbox, int NF, int is,
                                                           unsigned long long *__restrict__ zbuf, const int *skip)
 {
@@ -267,7 +270,15 @@ __global__ __launch_bounds__(256) void sil_scatter_kernel(const float *__restric
         if (in) qz[n_in + __popc(bits & ((1u << gl) - 1u))] = (unsigned short)p;
         n_in += __popc(bits);
     }
+    // the list of a lane group is written and read by lanes of ONE wave: a wave executes its LDS instructions in program order, so only the compiler has to
+    // be kept from moving the reads above the writes (round 6: a workgroup barrier here made every wave wait for the largest box among the workgroup's 16 faces)
+#if SIL_WG_BARRIER
     __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     for (int i = gl; i < n_in; i += SIL_GS) {
         const int p = qz[i];
         int xi, yi; sil_box_pixel(p, x0, y0, w, rw, xi, yi);
