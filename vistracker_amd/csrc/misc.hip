@@ -874,7 +874,10 @@ extern "C" int vt_loss_reduce_and_stop(const double *terms, const float *w, int 
 // reduction, stop rule, zeroing the term accumulators for the next step) is done by whichever workgroup finishes LAST (ticket counter), after
 // every other workgroup has read the stop flag and stepped its parameters.
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restrict__ M0, const float *__restrict__ noise, const float *__restrict__ t,
+// One workgroup of 1024 threads per frame (round 6; was ceil(N / 256) workgroups of 256): the projection's SVD is ~10 us of ONE thread, and every workgroup of a
+// frame computed it while its other threads waited -- 12-24 x 96 workgroups holding their wave slots for the length of the SVD next to the other batches' query
+// launches, for a point transform of microseconds.  Same arithmetic per point.
+__global__ __launch_bounds__(1024) void objstep_head_kernel(const float *__restrict__ M0, const float *__restrict__ noise, const float *__restrict__ t,
                                                            const float *__restrict__ s, const float *__restrict__ X0p, int N, float *__restrict__ Xp,
                                                            const float *__restrict__ X0v, int NV, float *__restrict__ Xv, float *__restrict__ Rout,
                                                            double *terms, int nzero, float *__restrict__ svd_ws)
@@ -905,28 +908,30 @@ __global__ __launch_bounds__(256) void objstep_head_kernel(const float *__restri
     }
     if (blockIdx.x == 0 && b == 0 && terms && (int)threadIdx.x < nzero) terms[threadIdx.x] = 0.0;
     __syncthreads();
-    const int n = blockIdx.x * 256 + threadIdx.x;
     const float sc = s[b], t0 = t[3 * b], t1 = t[3 * b + 1], t2 = t[3 * b + 2];
     const float tt[3] = {t0, t1, t2};
-    if (n < N) {
+    float r[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) r[e] = sR[e];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
         const float *x = X0p + (size_t)n * 3; const float x0 = x[0], x1 = x[1], x2 = x[2];
         float *o = Xp + ((size_t)b * N + n) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; c++) o[c] = (x0 * sR[c] + x1 * sR[3 + c] + x2 * sR[6 + c] + tt[c]) * sc;
+        for (int c = 0; c < 3; c++) o[c] = (x0 * r[c] + x1 * r[3 + c] + x2 * r[6 + c] + tt[c]) * sc;
     }
-    if (Xv && n < NV) {
-        const float *x = X0v + (size_t)n * 3; const float x0 = x[0], x1 = x[1], x2 = x[2];
-        float *o = Xv + ((size_t)b * NV + n) * 3;
+    if (Xv)
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < NV; n += gridDim.x * blockDim.x) {
+            const float *x = X0v + (size_t)n * 3; const float x0 = x[0], x1 = x[1], x2 = x[2];
+            float *o = Xv + ((size_t)b * NV + n) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; c++) o[c] = (x0 * sR[c] + x1 * sR[3 + c] + x2 * sR[6 + c] + tt[c]) * sc;
-    }
+            for (int c = 0; c < 3; c++) o[c] = (x0 * r[c] + x1 * r[3 + c] + x2 * r[6 + c] + tt[c]) * sc;
+        }
 }
 extern "C" int vt_objstep_head(const float *M0, const float *noise, const float *t, const float *s, int B, const float *X0_points, int N, float *X_points,
                                const float *X0_verts, int NV, float *X_verts, float *R, double *terms, int nzero, float *svd_ws, void *stream)
 {
     VT_REQUIRE(M0 && t && s && X0_points && X_points && R && B > 0 && N > 0 && (!X_verts || (X0_verts && NV > 0)) && nzero >= 0 && nzero <= 16, "vt_objstep_head: bad argument");
-    const int nmax = X_verts ? max(N, NV) : N;
-    hipLaunchKernelGGL(objstep_head_kernel, dim3((nmax + 255) / 256, B), dim3(256), 0, vt_stream(stream), M0, noise, t, s, X0_points, N, X_points, X0_verts, NV, X_verts,
+    hipLaunchKernelGGL(objstep_head_kernel, dim3(1, B), dim3(1024), 0, vt_stream(stream), M0, noise, t, s, X0_points, N, X_points, X0_verts, NV, X_verts,
                        R, terms, nzero, svd_ws);
     VT_LAUNCH_CHECK();
     return VT_OK;
