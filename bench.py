@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# Kernel arguments in device memory instead of host memory the GPU reads over the link at every dispatch: the fit is thousands of short dependent launches per
+# batch, and the flag is worth +1.3-2 % on the headline (profiles/r06_dev_kernarg_ab.txt).  Read by the HIP runtime when it initialises: set before
+# torch is imported (bench.py imports it lazily); `import vistracker_amd` sets the same default for a host that imports the package first.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
